@@ -1,0 +1,108 @@
+/*
+ * crt_oracle.h -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference
+ * hot path (crt_modulate + crt_demodulate of LMP88959/NTSC-CRT v2.3.2), written
+ * from scratch as explicit stages over explicit state.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * shipped library (ntsc-crt_amd/) never does.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every stage output
+ * (analog, inp, ccf, hsync, vsync, rn, out) of this file against the real
+ * reference compiled from /root/reference into oracle/_ref/libref_*.so, and
+ * tests/golden/ holds fixtures generated from that same reference build
+ * (the reference itself ships no tests or golden vectors).
+ *
+ * Unlike the reference, the "system" (crt_core.h:30-59) is a run-time table
+ * (struct orc_sys) so one library covers NTSC, VHS and NES (pattern 0 and 2).
+ */
+#ifndef CRT_ORACLE_H
+#define CRT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_SYS_NTSC = 0, ORC_SYS_NES = 1, ORC_SYS_VHS = 5 };
+
+/* bytes of the reference's struct CRT that follow inp[] and that the decoder can
+ * over-read deterministically (outw, outh, out_format, 4 bytes of zeroed padding):
+ * crt_core.h:76-80 + crt_core.c:511,539-543 */
+#define ORC_TAIL 16
+
+/* every constant that the reference derives from its per-system header */
+struct orc_sys {
+    int system;          /* ORC_SYS_* */
+    int chroma_pattern;  /* CRT_CHROMA_PATTERN */
+    int hres, vres, input_size;
+    int top, bot, lines;
+    int cc_vper;
+    int hsync_window, vsync_window;
+    int hsync_thresh, vsync_thresh; /* already multiplied by sync_level */
+    int sync_beg, bw_beg, cb_beg, av_beg, av_len;
+    int lav_beg, vs_sep_end;        /* NES only */
+    int white_level, burst_level, black_level, blank_level, sync_level;
+    int iir_c[3];        /* encoder 1-pole coefficients Y,I,Q (Q11) */
+    int eq_lf[3], eq_hf[3], eq_g[3][3]; /* decoder equaliser, Y,I,Q */
+};
+
+struct orc_crt {
+    int8_t *analog;      /* input_size bytes */
+    int8_t *inp;         /* input_size + ORC_TAIL bytes */
+    int outw, outh, out_format;
+    uint8_t *out;
+    int hue, brightness, contrast, saturation;
+    int black_point, white_point;
+    int scanlines, blend;
+    unsigned v_fac;
+    int ccf[3][4];
+    int hsync, vsync, rn;
+};
+
+/* union of the three NTSC_SETTINGS flavours */
+struct orc_settings {
+    const void *data;    /* u8*bpp pixels, or u16 PPU pixels for NES */
+    int format, w, h;
+    int raw, as_color, field, frame, hue, xoffset, yoffset;
+    int do_aberration;            /* VHS */
+    unsigned border_color;        /* NES */
+    int dot_crawl_offset;         /* NES */
+    int initialized;              /* iirs_initialized / field_initialized */
+};
+
+/* per decoded line, what the serial sync chain hands to the filter stage */
+struct orc_line {
+    int valid;           /* 0: line skipped (beg >= outh), nothing else set */
+    int pos;             /* first sample of the active window in inp[] */
+    int wave0, wave1;    /* demodulation carrier (wave[2],wave[3] are negations) */
+    int beg, end;        /* output rows [beg, end) owned by this line */
+    int hsync;           /* hsync after this line */
+};
+
+void orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern);
+void orc_sincos14(int *s, int *c, int n);
+int  orc_bpp4fmt(int format);
+int  orc_expx(int n);
+
+void orc_crt_init(const struct orc_sys *sys, struct orc_crt *v,
+                  int8_t *analog, int8_t *inp, int w, int h, int f, uint8_t *out);
+
+void orc_modulate(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *s);
+void orc_demodulate(const struct orc_sys *sys, struct orc_crt *v, int noise);
+/* same, additionally returning the per-line sync chain (lines top..bot-1) */
+void orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise,
+                          struct orc_line *trace);
+
+/* individual stages (used by the stage-level GPU parity tests) */
+int  orc_stage_noise(const struct orc_sys *sys, const int8_t *analog, int8_t *inp,
+                     int rn, int noise);
+void orc_lcg_jump(unsigned k, unsigned *mul, unsigned *add);
+
+/* timing helper for bench.py cpu_baseline (kind = "port") */
+double orc_time_fieldpasses(const struct orc_sys *sys, struct orc_crt *v,
+                            struct orc_settings *s, int noise, int reps, int interlaced);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
