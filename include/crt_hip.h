@@ -1,0 +1,223 @@
+/*
+ * crt_hip.h -- C ABI of the MI355X (gfx950) implementation of NTSC-CRT's per-field
+ * composite encode -> noisy channel -> decode hot path.
+ *
+ * Two layers live behind this ABI:
+ *
+ *  (1) The reference's own entry points (crt_core.h:100-139 of LMP88959/NTSC-CRT):
+ *      crt_init / crt_resize / crt_reset / crt_modulate / crt_demodulate /
+ *      crt_bpp4fmt / crt_sincos14, with layout-identical `struct CRT` and
+ *      `struct NTSC_SETTINGS` (include/crt_core.h and friends).  They are exported
+ *      by libntsccrt_hip_<system>.so, one library per CRT_SYSTEM exactly like the
+ *      reference is one build per CRT_SYSTEM (crt_core.h:39-59), so the unchanged
+ *      crt_main.c / extra/video_convert.c drivers link against it.
+ *
+ *  (2) The device-resident batch ABI below (crthip_*), exported by libcrthip.so.
+ *      It has no counterpart in the reference (which has no batching, SURVEY.md
+ *      section 2); layer (1) is a thin C89 client of it.  Plain pointers and sizes
+ *      only; device pointers are raw `void *` (e.g. torch.Tensor.data_ptr()).
+ *
+ * Unit of work: a FIELD-PASS = one crt_modulate (crt_ntsc.c:128 / crt_ntscvhs.c:129 /
+ * crt_nes.c:106) followed by one crt_demodulate (crt_core.c:291) on one image.
+ * All arithmetic is the reference's 32-bit integer fixed point; results are
+ * bit-exact with the CPU path (tests/).
+ */
+#ifndef CRT_HIP_H
+#define CRT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRTHIP_ABI_VERSION 1
+
+/* CRT_SYSTEM_* of crt_core.h:30-36 (only the systems in scope) */
+#define CRTHIP_SYSTEM_NTSC    0
+#define CRTHIP_SYSTEM_NES     1
+#define CRTHIP_SYSTEM_NTSCVHS 5
+
+/* CRT_PIX_FORMAT_* of crt_core.h:62-67 */
+#define CRTHIP_FMT_RGB  0
+#define CRTHIP_FMT_BGR  1
+#define CRTHIP_FMT_ARGB 2
+#define CRTHIP_FMT_RGBA 3
+#define CRTHIP_FMT_ABGR 4
+#define CRTHIP_FMT_BGRA 5
+
+/* Bytes of `struct CRT` behind inp[] (outw, outh, out_format, zeroed padding) that the
+ * reference's filter window can over-read deterministically when ypos == VRES-1 and
+ * hsync >= 5 (crt_core.c:511,539-543).  Mirrored behind every
+ * device inp[] so those pixels stay bit-exact.  Deeper over-reads are undefined
+ * behaviour in the reference and outside the parity contract. */
+#define CRTHIP_TAIL 16
+
+/* error codes (0 = ok).  The reference API is all-void (no error channel,
+ * crt_core.h:100-139); layer (1) therefore reports on stderr and aborts. */
+#define CRTHIP_OK            0
+#define CRTHIP_E_ARG        -1   /* bad argument / unsupported configuration */
+#define CRTHIP_E_NODEVICE   -2   /* no HIP device, or device is not gfx950 */
+#define CRTHIP_E_HIP        -3   /* HIP runtime error, see crthip_error_string */
+#define CRTHIP_E_NOMEM      -4
+
+/* crthip_params.flags */
+#define CRTHIP_F_NES_SETUP    2  /* crthip_modulate, NES: NTSC_SETTINGS.field_initialized == 0, i.e. also
+                                    write the whole-field sync skeleton (setup_field, crt_nes.c:81-104) */
+
+/*
+ * Everything that is uniform over a batch of field-passes.  Plain old data, no
+ * pointers: this is also the blob rank 0 broadcasts over RCCL in the multi-GPU
+ * driver.  Fill the USER part, then call crthip_params_finalize(), which derives
+ * the rest on the host exactly as the reference does per call (crt_ntsc.c:142-203,
+ * crt_core.c:272-280, :305-320, :403-407, :528).
+ */
+typedef struct crthip_params {
+    /* ---- user part ------------------------------------------------------- */
+    int system;           /* CRTHIP_SYSTEM_*                                   */
+    int chroma_pattern;   /* CRT_CHROMA_PATTERN (crt_ntsc.h:25, crt_nes.h:30)  */
+    /* encoder input: struct NTSC_SETTINGS minus data/field/frame
+     * (crt_ntsc.h:111-124, crt_ntscvhs.h:133-147, crt_nes.h:132-143) */
+    int w, h;             /* image size                                        */
+    int format;           /* CRTHIP_FMT_* of the input image (ignored for NES) */
+    int raw, as_color;
+    int hue;              /* encoder hue                                       */
+    int xoffset, yoffset;
+    /* decoder: the caller-visible part of struct CRT (crt_core.h:77-86) */
+    int outw, outh, out_format;
+    int mon_hue, brightness, contrast, saturation;
+    int black_point, white_point;
+    int scanlines, blend;
+    unsigned v_fac;
+    int noise;            /* crt_demodulate's `noise` argument                 */
+    int flags;            /* CRTHIP_F_*                                        */
+    /* ---- derived part (crthip_params_finalize) --------------------------- */
+    int finalized;        /* magic, set by crthip_params_finalize              */
+    int in_bpp, out_bpp;
+    int destw, desth, xo, yo;      /* crt_ntsc.c:132-133,163-173,194-203       */
+    int burst[3][4];               /* colour-burst samples per (line phase, t%4)*/
+    int modI[4], modQ[4];          /* crt_ntsc.c:174-188                       */
+    int iir_c[3];                  /* crt_ntsc.c:98-106, Q11                   */
+    int eq_lf[3], eq_hf[3];        /* crt_core.c:171-196, Q16                  */
+    int eq_g[3][3];                /* crt_core.c:278-280                       */
+    int huesn, huecs;              /* crt_core.c:318-320, 4-bit                */
+    int bright;                    /* crt_core.c:305                           */
+    int white;                     /* WHITE_LEVEL*white_point/100, crt_ntsc.c:318 */
+    int ire_base;                  /* BLACK_LEVEL + black_point, crt_ntsc.c:311 */
+    int dx;                        /* crt_core.c:528                           */
+    int ratio;                     /* crt_core.c:404-405                       */
+    int reserved[8];
+} crthip_params;
+
+/*
+ * Per-field state, device resident, one entry per field-pass of a batch.  These are
+ * the members of struct CRT / NTSC_SETTINGS that vary from field to field and carry
+ * over between calls.
+ */
+typedef struct crthip_state {
+    int field, frame;     /* in : NTSC_SETTINGS.field / .frame (NTSC, VHS)     */
+    int aux;              /* in : NES dot_crawl_offset; VHS aberration lines    */
+    int hsync, vsync;     /* i/o: crt_core.h:89                                */
+    int rn;               /* i/o: crt_core.h:91                                */
+    int ccf[3][4];        /* i/o: crt_core.h:88 (rows >= CRT_CC_VPER unused)   */
+    int odd_field;        /* out: field parity found by the vsync search        */
+    int reserved;
+} crthip_state;           /* 80 bytes */
+
+/* What the serial sync chain (crt_core.c:428-479) hands to the filter stage, per
+ * decoded line (CRT_TOP..CRT_BOT-1), device resident. */
+typedef struct crthip_line {
+    int pos;              /* first sample of the active window in inp[] (:454) */
+    int wave0, wave1;     /* wave[0], wave[1] (:476-477); [2],[3] = negations   */
+    int beg;              /* first output row (:428)                            */
+    int nrows;            /* rows written: 1 + duplicates (:661-664); 0 = line skipped (:431) */
+    int hsync;            /* hsync after this line (diagnostic)                 */
+} crthip_line;            /* 24 bytes */
+
+typedef struct crthip_ctx crthip_ctx;
+
+/* kernels, for crthip_profile_read() */
+#define CRTHIP_K_TEMPLATE 0   /* M4: blanking / sync / burst skeleton           */
+#define CRTHIP_K_ACTIVE   1   /* M5: RGB->YIQ, band-limit, quadrature modulate  */
+#define CRTHIP_K_NOISE    2   /* D1: channel noise                              */
+#define CRTHIP_K_SYNC     3   /* D2-D7: vsync, hsync, burst lock (serial chain) */
+#define CRTHIP_K_DECODE   4   /* D8-D10: equalisers, resample, YIQ->RGB, rows   */
+#define CRTHIP_K_COUNT    5
+
+int  crthip_abi_version(void);
+int  crthip_device_count(void);
+
+/* Host-only helpers (no device needed). */
+int  crthip_params_default(crthip_params *p, int system, int chroma_pattern);
+int  crthip_params_finalize(crthip_params *p);
+int  crthip_input_size(int system, int chroma_pattern);      /* CRT_INPUT_SIZE */
+int  crthip_hres(int system, int chroma_pattern);            /* CRT_HRES       */
+int  crthip_lines(int system);                               /* CRT_LINES      */
+size_t crthip_field_stride(int system, int chroma_pattern);  /* bytes between consecutive
+                                   fields in analog[] / inp[] device buffers (>= INPUT_SIZE+CRTHIP_TAIL) */
+
+/* Context = one device + one stream + the jump tables of the noise LCG. */
+int  crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern);
+void crthip_destroy(crthip_ctx *ctx);
+int  crthip_set_stream(crthip_ctx *ctx, void *hip_stream);   /* hipStream_t; NULL = own stream */
+int  crthip_synchronize(crthip_ctx *ctx);
+const char *crthip_error_string(const crthip_ctx *ctx);
+
+/* Pre-allocate the per-field workspace (inp[], line table) for up to n fields so that
+ * crthip_fieldpass() performs no allocation inside a timed region. */
+int  crthip_reserve(crthip_ctx *ctx, int n_fields);
+
+/*
+ * One batch of n independent field-passes, everything device resident:
+ *   d_images : n images, image k at d_images + k*image_stride (w*h*bpp bytes, or
+ *              w*h u16 PPU pixels for NES)
+ *   d_out    : n output images, k at d_out + k*out_stride (outw*outh*bpp bytes);
+ *              read as well as written when blend != 0, and rows this field does not
+ *              own keep their contents (crt_core.c:431,:608,:662)
+ *   d_state  : n crthip_state, updated in place
+ * Each field starts from a crt_init-clean analog[] (all zero where crt_modulate does
+ * not write, crt_ntsc.c:236-238).  Asynchronous on the context's stream.
+ */
+int  crthip_fieldpass(crthip_ctx *ctx, const crthip_params *p, int n,
+                      const void *d_images, size_t image_stride,
+                      void *d_out, size_t out_stride,
+                      crthip_state *d_state);
+
+/*
+ * Stage-level entry points (used by the drop-in layer, which must keep the host's
+ * struct CRT coherent between crt_modulate and crt_demodulate, and by the stage
+ * parity tests).  d_analog / d_inp hold n fields at crthip_field_stride() spacing.
+ */
+/* crt_modulate: writes exactly the samples the reference writes (crt_ntsc.c:205-324),
+ * leaving all other samples of d_analog untouched; updates state.ccf (and VHS hsync). */
+int  crthip_modulate(crthip_ctx *ctx, const crthip_params *p, int n,
+                     const void *d_images, size_t image_stride,
+                     signed char *d_analog, crthip_state *d_state);
+/* crt_demodulate D1: d_inp = clamp(d_analog + noise), state.rn advanced (crt_core.c:346-367) */
+int  crthip_noise(crthip_ctx *ctx, const crthip_params *p, int n,
+                  const signed char *d_analog, signed char *d_inp, crthip_state *d_state);
+/* crt_demodulate D2-D7: vsync, per-line hsync / burst lock -> line table (crt_core.c:379-479) */
+int  crthip_sync(crthip_ctx *ctx, const crthip_params *p, int n,
+                 const signed char *d_inp, crthip_state *d_state, crthip_line *d_lines);
+/* crt_demodulate D8-D10 (crt_core.c:534-664) */
+int  crthip_decode(crthip_ctx *ctx, const crthip_params *p, int n,
+                   const signed char *d_inp, const crthip_line *d_lines,
+                   void *d_out, size_t out_stride);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg).
+ * While enabled every launch is bracketed by an event pair. */
+int  crthip_profile_enable(crthip_ctx *ctx, int on);
+int  crthip_profile_read(crthip_ctx *ctx, double total_ms[CRTHIP_K_COUNT],
+                         int launches[CRTHIP_K_COUNT]);   /* synchronises; resets */
+
+/* Raw device memory helpers for hosts without a tensor library (the C89 drop-in layer). */
+void *crthip_malloc(crthip_ctx *ctx, size_t bytes);
+void  crthip_free(crthip_ctx *ctx, void *d_ptr);
+int   crthip_upload(crthip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int   crthip_download(crthip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int   crthip_memset(crthip_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1210 @@
+/*
+ * crt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) + the crthip_* C ABI.
+ *
+ * The reference (LMP88959/NTSC-CRT, C89, single threaded) processes one field with
+ * strictly serial per-scanline recurrences that floor after every multiply
+ * (crt_ntsc.c:117-126 iirf, crt_core.c:206-233 eqf), so no parallel scan can be
+ * bit-exact.  What IS independent: scanlines (filter state is reset per line,
+ * crt_ntsc.c:267-269, crt_core.c:534-536) and fields.  The design is therefore
+ *
+ *     one LANE per scanline, 64 scanlines per wavefront, many fields per launch
+ *
+ * with wave-uniform control flow: all 64 lanes are at the same sample x at the same
+ * time, so everything that depends only on x (source column, carrier phase, which
+ * output pixels become ready and their interpolation weights) lives in SGPRs / the
+ * scalar unit and costs no vector issue slots.
+ *
+ * Kernels (stage names M0-M6 / D0-D10 as in DESIGN.md):
+ *   k_template  M4      blanking / sync / burst skeleton        (elementwise)
+ *   k_active    M5      RGB->YIQ, 3x 1-pole IIR, quadrature mod  (lane per image row)
+ *   k_noise     D1      LCG noise via affine jump-ahead tables   (elementwise)
+ *   k_sync      D2-D7   vsync, hsync, burst lock                 (wave per field, serial chain)
+ *   k_decode    D8-D10  3x 3-band IIR equaliser, resample, YIQ->RGB, row duplication
+ *                                                                (lane per CRT line)
+ * Integer-only; signed overflow wraps, >> of negatives is arithmetic, / truncates --
+ * identical to the reference on x86-64.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "crt_hip.h"
+#include "crt_setup.h"
+
+/* ------------------------------------------------------------------------- */
+/* compile-time system tables (device side); cross-checked against the C89    */
+/* host table crt_sysdef_get() when a context is created                      */
+/* ------------------------------------------------------------------------- */
+template <int CC_LINE>
+struct RgbTiming {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h */
+    static constexpr int HRES = CC_LINE * 4 / 10;
+    static constexpr int VRES = 262;
+    static constexpr int INPUT_SIZE = HRES * VRES;
+    static constexpr int TOP = 21, BOT = 261, LINES = BOT - TOP;
+    static constexpr int VPER = 1;
+    static constexpr int HWIN = 8, VWIN = 8;
+    static constexpr int WHITE = 100, BURST = 20, BLACK = 7, BLANK = 0, SYNC = -40;
+    static constexpr int HTHR = 4 * SYNC, VTHR = 94 * SYNC;
+    static constexpr int SYNC_BEG = 1500 * HRES / 63500;
+    static constexpr int BW_BEG = 6200 * HRES / 63500;
+    static constexpr int CB_BEG = 6800 * HRES / 63500;
+    static constexpr int AV_BEG = 10900 * HRES / 63500;
+    static constexpr int AV_LEN = 52600 * HRES / 63500;
+    static constexpr int VS_SEP_END = 0;
+    static constexpr bool IS_NES = false;
+};
+template <int CC_LINE>
+struct NesTiming {   /* crt_nes.h:30-126 */
+    static constexpr int HRES = CC_LINE * 4 / 10;
+    static constexpr int VRES = 262;
+    static constexpr int INPUT_SIZE = HRES * VRES;
+    static constexpr int TOP = 15, BOT = 255, LINES = BOT - TOP;
+    static constexpr int VPER = 3;
+    static constexpr int HWIN = 6, VWIN = 6;
+    static constexpr int WHITE = 110, BURST = 30, BLACK = 0, BLANK = 0, SYNC = -37;
+    static constexpr int HTHR = 4 * SYNC, VTHR = 94 * SYNC;
+    static constexpr int SYNC_BEG = 9 * HRES / 341;
+    static constexpr int BW_BEG = 34 * HRES / 341;
+    static constexpr int CB_BEG = 38 * HRES / 341;
+    static constexpr int AV_BEG = 74 * HRES / 341;
+    static constexpr int AV_LEN = 256 * HRES / 341;
+    static constexpr int VS_SEP_END = 327 * HRES / 341;
+    static constexpr bool IS_NES = true;
+};
+struct SysNTSC : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 1; static constexpr bool IS_VHS = false; };
+struct SysNTSC0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 0; static constexpr bool IS_VHS = false; };
+struct SysVHS : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 1; static constexpr bool IS_VHS = true; };
+struct SysVHS0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 0; static constexpr bool IS_VHS = true; };
+struct SysNES2 : NesTiming<2273> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 2; static constexpr bool IS_VHS = false; };
+struct SysNES1 : NesTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 1; static constexpr bool IS_VHS = false; };
+struct SysNES0 : NesTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 0; static constexpr bool IS_VHS = false; };
+
+static_assert(SysNTSC::HRES == 910 && SysNTSC::AV_BEG == 156 && SysNTSC::AV_LEN == 753 &&
+              SysNTSC::SYNC_BEG == 21 && SysNTSC::CB_BEG == 97, "NTSC timing (SURVEY.md section 8)");
+static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES == 912 &&
+              SysNES0::AV_LEN == 684, "NES timing (SURVEY.md section 8)");
+
+#define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
+#define LCG_MUL 214019u          /* crt_core.c:359 */
+#define LCG_ADD 140327895u
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) unaligned16 { v4i v; };
+struct __attribute__((packed)) unaligned4 { int v; };
+
+__device__ __forceinline__ v4i load16u(const void *p) { return ((const unaligned16 *) p)->v; }
+__device__ __forceinline__ void store16u(void *p, v4i v) { ((unaligned16 *) p)->v = v; }
+__device__ __forceinline__ int load4u(const void *p) { return ((const unaligned4 *) p)->v; }
+__device__ __forceinline__ void store4u(void *p, int v) { ((unaligned4 *) p)->v = v; }
+
+__device__ __forceinline__ int posmod(int x, int n) { return ((x % n) + n) % n; }  /* crt_core.c:17 */
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* noise LCG, crt_core.c:359-364 */
+__device__ __forceinline__ unsigned lcg_step(unsigned rn) { return LCG_MUL * rn + LCG_ADD; }
+__device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)
+{
+    int s = sample + (((int) ((rn >> 16) & 0xffu) - 0x7f) * noise >> 8);
+    return clampi(s, -127, 127);
+}
+/* LCG state after `idx` steps from rn0; jump16[q] = affine map of 16*q steps */
+__device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, unsigned rn0, int idx)
+{
+    uint2 j = jump16[idx >> 4];
+    unsigned rn = j.x * rn0 + j.y;
+    for (int k = idx & 15; k > 0; k--) rn = lcg_step(rn);
+    return rn;
+}
+
+/* ------------------------------------------------------------------------- */
+/* M4: blanking / sync / burst skeleton                                        */
+/* ------------------------------------------------------------------------- */
+/* value of skeleton sample (line n, column t) and whether crt_modulate writes it.
+ * RGB systems: crt_ntsc.c:205-252 (+ crt_ntscvhs.c:234-238);  NES: crt_nes.c:81-104,173-178 */
+template <class S>
+__device__ __forceinline__ bool
+skeleton(const crthip_params &P, int n, int t, int field, int inv_phase, int aux, bool nes_setup, int &val)
+{
+    if constexpr (S::IS_NES) {
+        bool written = nes_setup;
+        val = S::BLANK;
+        if (t >= S::SYNC_BEG && t < (n >= 259 ? S::VS_SEP_END : S::BW_BEG)) val = S::SYNC;
+        if (n >= P.yo && n < P.yo + S::LINES && t >= S::CB_BEG && t < S::CB_BEG + CB_SAMPLES) {
+            int cb = P.burst[(n % 3 + aux) % 3][t & 3];
+            val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
+            written = true;
+        }
+        return written;
+    } else {
+        if (n <= 3 || (n >= 7 && n <= 9)) {            /* equalising pulses */
+            val = (t < 4 * S::HRES / 100 || (t >= 50 * S::HRES / 100 && t < 54 * S::HRES / 100)) ? S::SYNC : S::BLANK;
+            return true;
+        }
+        if (n >= 4 && n <= 6) {                        /* vertical sync */
+            int a = (field == 1 ? 4 : 46) * S::HRES / 100;
+            val = (t < a || (t >= 50 * S::HRES / 100 && t < 96 * S::HRES / 100)) ? S::SYNC : S::BLANK;
+            return true;
+        }
+        if (t >= S::AV_BEG) {                          /* active part: only cleared above CRT_TOP */
+            val = S::BLANK;
+            return n < S::TOP;
+        }
+        val = S::BLANK;
+        if (t >= S::SYNC_BEG && t < S::BW_BEG && n < S::VRES - aux) val = S::SYNC;
+        if (t >= S::CB_BEG && t < S::CB_BEG + CB_SAMPLES) {
+            int cb = S::PATTERN == 1 ? P.burst[0][(t + inv_phase * 2) & 3] : P.burst[0][t & 3];
+            val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
+        }
+        return true;
+    }
+}
+
+/* One lane per 16 consecutive samples.  FULL=false: write exactly the reference's
+ * write-set into analog[] (drop-in semantics, other samples keep their contents).
+ * FULL=true: every sample outside the active rectangle gets skeleton-or-zero plus
+ * channel noise, i.e. dst is inp[] of a field that started from a clean analog[]. */
+template <class S, bool FULL>
+__global__ void __launch_bounds__(256)
+k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
+           const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16, int nes_setup)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_fields * CHUNKS) return;
+    const int f = gid / CHUNKS;
+    const int q = gid - f * CHUNKS;
+    const int idx0 = q * 16;
+    const crthip_state st = state[f];
+    const int field = st.field & 1;
+    const int inv_phase = (field == (st.frame & 1));
+    int line = idx0 / S::HRES;
+    int t = idx0 - line * S::HRES;
+    signed char *out = dst + (size_t) f * fstride;
+
+    /* chunks entirely inside the active rectangle belong to k_active */
+    {
+        int t1 = t + 15;   /* may spill into the next line; then not "entirely inside" */
+        if (t >= P.xo && t1 < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth) return;
+    }
+    unsigned rn = 0;
+    if (FULL) {
+        uint2 j = jump16[q];
+        rn = j.x * (unsigned) st.rn + j.y;
+    }
+    int vals[16];
+    unsigned wmask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int v = 0;
+        bool in_field = idx0 + k < S::INPUT_SIZE;
+        bool active = t >= P.xo && t < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth;
+        bool wr = skeleton<S>(P, line, t, field, inv_phase, st.aux, nes_setup != 0, v);
+        if (FULL) {
+            rn = lcg_step(rn);
+            if (!wr) v = 0;
+            v = noisy(v, rn, P.noise);
+            wr = true;
+        }
+        if (wr && !active && in_field) wmask |= 1u << k;
+        vals[k] = v;
+        if (++t == S::HRES) { t = 0; line++; }
+    }
+    if (wmask == 0xffffu) {
+        v4i pk;
+        pk.x = (vals[0] & 255) | (vals[1] & 255) << 8 | (vals[2] & 255) << 16 | vals[3] << 24;
+        pk.y = (vals[4] & 255) | (vals[5] & 255) << 8 | (vals[6] & 255) << 16 | vals[7] << 24;
+        pk.z = (vals[8] & 255) | (vals[9] & 255) << 8 | (vals[10] & 255) << 16 | vals[11] << 24;
+        pk.w = (vals[12] & 255) | (vals[13] & 255) << 8 | (vals[14] & 255) << 16 | vals[15] << 24;
+        store16u(out + idx0, pk);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (wmask >> k & 1u) out[idx0 + k] = (signed char) vals[k];
+        }
+    }
+    if (FULL && q == 0) {
+        /* mirror of the struct members behind inp[] (see CRTHIP_TAIL) */
+        signed char *tail = out + S::INPUT_SIZE;     /* INPUT_SIZE % 4 != 0 for NES pattern 2 */
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* M5: active video, one lane per destination row                              */
+/* ------------------------------------------------------------------------- */
+/* 0x00RRGGBB from the 6 byte orders, crt_ntsc.c:278-305 */
+__device__ __forceinline__ void fetch_rgb(const unsigned char *p, int format, int bpp, int &r, int &g, int &b)
+{
+    unsigned w;
+    if (bpp == 4) {
+        w = (unsigned) load4u(p);
+    } else {
+        w = (unsigned) p[0] | (unsigned) p[1] << 8 | (unsigned) p[2] << 16;
+    }
+    int b0 = w & 255, b1 = (w >> 8) & 255, b2 = (w >> 16) & 255, b3 = w >> 24;
+    switch (format) {
+    case CRTHIP_FMT_RGB: case CRTHIP_FMT_RGBA: r = b0; g = b1; b = b2; break;
+    case CRTHIP_FMT_BGR: case CRTHIP_FMT_BGRA: r = b2; g = b1; b = b0; break;
+    case CRTHIP_FMT_ARGB: r = b1; g = b2; b = b3; break;
+    case CRTHIP_FMT_ABGR: r = b3; g = b2; b = b1; break;
+    default: r = g = b = 0; break;
+    }
+}
+
+/* NES PPU square wave, crt_nes.c:21-61 */
+__device__ __forceinline__ int ppu_level(int p, int phase)
+{
+    const int hue = p & 15;
+    if (hue >= 14) return 0;
+    int high = ((hue + phase) % 12) < 6;
+    if (hue == 0) high = 1;
+    if (hue == 13) high = 0;
+    /* active[] = {0300,0100,0500,0400,0600,0200}: emphasis bits attenuating this phase */
+    const int slot = (phase >> 1) % 6;
+    const int mask = slot == 0 ? 0300 : slot == 1 ? 0100 : slot == 2 ? 0500 : slot == 3 ? 0400 : slot == 4 ? 0600 : 0200;
+    const int emph = (p & 0700 & mask) != 0;
+    const int lum = (p >> 4) & 3;
+    /* IRE[(high<<3) + (emph<<2) + lum] */
+    int v;
+    if (high) {
+        v = emph ? (lum == 0 ? 26951 : lum == 1 ? 52181 : 83721)
+                 : (lum == 0 ? 43581 : lum == 1 ? 75693 : 112965);
+    } else {
+        v = emph ? (lum == 0 ? -17203 : lum == 1 ? -8028 : lum == 2 ? 19497 : 57342)
+                 : (lum == 0 ? -12042 : lum == 1 ? 0 : lum == 2 ? 34406 : 81427);
+    }
+    return v;
+}
+
+template <class S, bool NOISE>
+__global__ void __launch_bounds__(64)
+k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
+         signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
+         const uint2 *__restrict__ jump16)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const int rows = P.desth;
+    if (gid >= n_fields * rows) return;
+    const int f = gid / rows;
+    const int y = gid - f * rows;
+    const crthip_state st = state[f];
+    const unsigned char *img = images + (size_t) f * istride;
+    const int start = (y + P.yo) * S::HRES + P.xo;
+    signed char *out = dst + (size_t) f * fstride + start;
+    unsigned rn = 0;
+    if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, start);
+
+    const int w = P.w, destw = P.destw;
+    const int qstep = w / destw, rstep = w - qstep * destw;   /* column = floor(x*w/destw), incrementally */
+    int col = 0, err = 0;                                     /* wave-uniform */
+    const int ngroups = (destw + 3) >> 2;
+
+    if constexpr (S::IS_NES) {
+        /* crt_nes.c:162-193 */
+        int sy = (y * P.h) / S::LINES;
+        if (sy >= P.h) sy = P.h;
+        if (sy < 0) sy = 0;
+        const unsigned short *row = (const unsigned short *) img + (size_t) sy * w;
+        int phase = 4 * ((y + P.yo + st.aux) % 3);           /* phasetab {0,4,8} */
+        for (int g = 0; g < ngroups; g++) {
+            unsigned pack = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = 4 * g + k;
+                if (x < destw) {
+                    int p = row[col];
+                    int ire = S::BLACK + P.black_point;
+                    ire += ppu_level(p, phase + 0);
+                    ire += ppu_level(p, phase + 1);
+                    ire += ppu_level(p, phase + 2);
+                    ire += ppu_level(p, phase + 3);
+                    ire = (ire * P.white_point / 100) >> 12;
+                    ire = (int) (signed char) ire;
+                    if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                    pack |= (unsigned) (ire & 255) << (8 * k);
+                    phase += 3;
+                    col += qstep; err += rstep;
+                    if (err >= destw) { err -= destw; col++; }
+                }
+            }
+            if (4 * g + 3 < destw) {
+                store4u(out + 4 * g, (int) pack);
+            } else {
+                for (int k = 4 * g; k < destw; k++) { out[k] = (signed char) (pack & 255); pack >>= 8; }
+            }
+        }
+    } else {
+        /* crt_ntsc.c:254-324 */
+        const int field = st.field & 1;
+        const int inv_phase = (field == (st.frame & 1));
+        const int ph = (S::PATTERN == 1 && (inv_phase & 1)) ? -1 : 1;
+        const int field_offset = (field * P.h + P.desth) / P.desth / 2;
+        int sy = (y * P.h) / P.desth + field_offset;
+        if (sy >= P.h) sy = P.h;                             /* (sic) crt_ntsc.c:263 */
+        const unsigned char *row = img + (size_t) sy * w * P.in_bpp;
+        /* (h * ph) * cc == h * (ph * cc) in wrapping arithmetic; xo is a multiple of 4 (crt_ntsc.c:203)
+         * so the carrier phase (x + xo) % 4 is x & 3 */
+        const int cI0 = ph * P.modI[0], cI1 = ph * P.modI[1], cI2 = ph * P.modI[2], cI3 = ph * P.modI[3];
+        const int cQ0 = ph * P.modQ[0], cQ1 = ph * P.modQ[1], cQ2 = ph * P.modQ[2], cQ3 = ph * P.modQ[3];
+        const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
+        int hy = 0, hi = 0, hq = 0;
+        for (int g = 0; g < ngroups; g++) {
+            unsigned pack = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = 4 * g + k;
+                if (x < destw) {
+                    int r, gg, b;
+                    fetch_rgb(row + (size_t) col * P.in_bpp, P.format, P.in_bpp, r, gg, b);
+                    const int fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
+                    const int fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
+                    const int fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
+                    hy += ((fy - hy) * cy_) >> 11;               /* iirf, crt_ntsc.c:117-126 */
+                    hi += ((fi - hi) * ci_) >> 11;
+                    hq += ((fq - hq) * cq_) >> 11;
+                    const int mi = hi * (k == 0 ? cI0 : k == 1 ? cI1 : k == 2 ? cI2 : cI3) >> 4;
+                    const int mq = hq * (k == 0 ? cQ0 : k == 1 ? cQ1 : k == 2 ? cQ2 : cQ3) >> 4;
+                    int ire = P.ire_base + ((hy + mi + mq) * P.white >> 10);
+                    ire = clampi(ire, 0, 110);
+                    if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                    pack |= (unsigned) (ire & 255) << (8 * k);
+                    col += qstep; err += rstep;
+                    if (err >= destw) { err -= destw; col++; }
+                }
+            }
+            if (4 * g + 3 < destw) {
+                store4u(out + 4 * g, (int) pack);
+            } else {
+                for (int k = 4 * g; k < destw; k++) { out[k] = (signed char) (pack & 255); pack >>= 8; }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* D1: channel noise (elementwise, 16 samples per lane)                        */
+/* ------------------------------------------------------------------------- */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+        signed char *__restrict__ inp, size_t fstride, const crthip_state *__restrict__ state,
+        const uint2 *__restrict__ jump16)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_fields * CHUNKS) return;
+    const int f = gid / CHUNKS;
+    const int q = gid - f * CHUNKS;
+    const signed char *src = analog + (size_t) f * fstride + q * 16;
+    signed char *dst = inp + (size_t) f * fstride + q * 16;
+    const uint2 j = jump16[q];
+    unsigned rn = j.x * (unsigned) state[f].rn + j.y;
+    const v4i in = load16u(src);
+    const int wds[4] = { in.x, in.y, in.z, in.w };
+    int outw[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        unsigned o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int s = (wds[d] << (24 - 8 * k)) >> 24;
+            rn = lcg_step(rn);
+            o |= (unsigned) (noisy(s, rn, P.noise) & 255) << (8 * k);
+        }
+        outw[d] = (int) o;
+    }
+    if (q * 16 + 16 <= S::INPUT_SIZE) {
+        v4i o4; o4.x = outw[0]; o4.y = outw[1]; o4.z = outw[2]; o4.w = outw[3];
+        store16u(dst, o4);
+    } else {
+        for (int k = 0; q * 16 + k < S::INPUT_SIZE; k++) dst[k] = (signed char) (outw[k >> 2] >> (8 * (k & 3)));
+    }
+    if (q == 0) {
+        signed char *tail = inp + (size_t) f * fstride + S::INPUT_SIZE;
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+    }
+}
+
+/* rn <- rn after INPUT_SIZE steps (crt_core.c:367) */
+__global__ void k_advance_rn(int n_fields, crthip_state *state, uint2 whole_field)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_fields) state[f].rn = (int) (whole_field.x * (unsigned) state[f].rn + whole_field.y);
+}
+
+/* ------------------------------------------------------------------------- */
+/* D2-D7: the serial sync chain, one wavefront per field                       */
+/* ------------------------------------------------------------------------- */
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <class S>
+__global__ void __launch_bounds__(64)
+k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+       crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn)
+{
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (f >= n_fields) return;
+    const signed char *in = inp + (size_t) f * fstride;
+    crthip_state *st = state + f;
+    int hsync = st->hsync, vsync = st->vsync;
+    int ccr[S::VPER];                                   /* lane holds ccf[r][lane & 3] */
+#pragma unroll
+    for (int r = 0; r < S::VPER; r++) ccr[r] = st->ccf[r][lane & 3];
+
+    /* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR */
+    int vline = 0, vj = S::HRES;
+    {
+        bool found = false;
+        for (int i = -S::VWIN; i < S::VWIN && !found; i++) {
+            vline = posmod(vsync + i, S::VRES);
+            const signed char *sig = in + vline * S::HRES + lane * 16;
+            const v4i raw = load16u(sig);
+            const int wds[4] = { raw.x, raw.y, raw.z, raw.w };
+            int pre[16];
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
+                if (lane * 16 + k >= S::HRES) s = 0;
+                run += s;
+                pre[k] = run;
+            }
+            const int excl = wave_incl_scan(run, lane) - run;
+            int first = 16;
+#pragma unroll
+            for (int k = 15; k >= 0; k--) {
+                if (lane * 16 + k < S::HRES && excl + pre[k] <= S::VTHR) first = k;
+            }
+            const unsigned long long m = __ballot(first < 16);
+            if (m) {
+                const int L = __ffsll((long long) m) - 1;
+                vj = L * 16 + __shfl(first, L);
+                found = true;
+            }
+        }
+        if (!found) vj = S::HRES;
+    }
+    vsync = vline;
+    const int odd = vj > S::HRES / 2;
+    const int field_rows = odd * (P.ratio / 2);                       /* crt_core.c:407 */
+
+    for (int line = S::TOP; line < S::BOT; line++) {
+        crthip_line lp;
+        /* D4, crt_core.c:428-432 (unsigned arithmetic: v_fac is unsigned) */
+        int beg = (int) ((unsigned) (line - S::TOP + 0) * ((unsigned) P.outh + P.v_fac) / (unsigned) S::LINES + (unsigned) field_rows);
+        int end = (int) ((unsigned) (line - S::TOP + 1) * ((unsigned) P.outh + P.v_fac) / (unsigned) S::LINES + (unsigned) field_rows);
+        if (beg >= P.outh) {
+            if (lane == 0) {
+                lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = hsync;
+                lines[(size_t) f * S::LINES + (line - S::TOP)] = lp;
+            }
+            continue;
+        }
+        if (end > P.outh) end = P.outh;
+
+        /* D5 hsync, crt_core.c:437-450 */
+        const int ln = posmod(line + vsync, S::VRES) * S::HRES;
+        int sv = 0;
+        if (lane < 2 * S::HWIN) sv = in[ln + hsync + S::SYNC_BEG - S::HWIN + lane];
+        const int pref = wave_incl_scan(sv, lane);
+        const unsigned long long hm = __ballot(lane < 2 * S::HWIN && pref <= S::HTHR);
+        const int hi = hm ? (__ffsll((long long) hm) - 1 - S::HWIN) : S::HWIN;
+        hsync = posmod(hi + hsync, S::HRES);
+
+        const int xpos = posmod(S::AV_BEG + hsync - 3, S::HRES);       /* :452-454 */
+        const int ypos = posmod(line + vsync + 3, S::VRES);
+        const int pos = xpos + ypos * S::HRES;
+
+        /* D6 burst lock, crt_core.c:456-467.  Lane l integrates phase (l & 3). */
+        int bs = 0;
+        if (lane < CB_SAMPLES) bs = in[ln + (hsync & ~3) + S::CB_BEG + lane];
+        const int r = S::VPER == 1 ? 0 : ypos % S::VPER;
+        int acc = ccr[0];
+#pragma unroll
+        for (int k = 1; k < S::VPER; k++) if (r == k) acc = ccr[k];
+        const int k0 = ((lane & 3) - S::CB_BEG) & 3;                    /* first burst sample of my phase */
+#pragma unroll
+        for (int j = 0; j < CB_SAMPLES / 4; j++) {
+            const int nsmp = __shfl(bs, k0 + 4 * j);
+            const int t127 = acc * 127;
+            acc = ((t127 + ((t127 >> 31) & 127)) >> 7) + nsmp;          /* C's truncating /128 */
+        }
+#pragma unroll
+        for (int k = 0; k < S::VPER; k++) if (r == k) ccr[k] = acc;
+
+        /* D7 carrier table, crt_core.c:469-479 */
+        const int pa = hsync & 3;
+        const int c1 = __shfl(acc, (pa + 1) & 3), c3 = __shfl(acc, (pa + 3) & 3);
+        const int c2 = __shfl(acc, (pa + 2) & 3), c0 = __shfl(acc, pa);
+        const int dci = c1 - c3, dcq = c2 - c0;
+        if (lane == 0) {
+            lp.pos = pos;
+            lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
+            lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
+            lp.beg = beg;
+            int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
+            lp.nrows = nrows < 1 ? 1 : nrows;
+            lp.hsync = hsync;
+            lines[(size_t) f * S::LINES + (line - S::TOP)] = lp;
+        }
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int r = 0; r < S::VPER; r++) st->ccf[r][lane] = ccr[r];
+    }
+    if (lane == 0) {
+        st->hsync = hsync;
+        st->vsync = vsync;
+        st->odd_field = odd;
+        if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* D8-D10: equalisers + resample + YIQ->RGB, one lane per CRT line              */
+/* ------------------------------------------------------------------------- */
+struct Eq3 { int lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3, h0, h1, h2; };
+
+/* eqf, crt_core.c:206-233; G0 is always 65536 (crt_core.c:278-280) */
+template <int G1, int G2>
+__device__ __forceinline__ int eq_step(Eq3 &f, const int lf, const int hf, const int s)
+{
+    f.lo0 += (lf * (s - f.lo0) + 32768) >> 16;
+    f.hi0 += (hf * (s - f.hi0) + 32768) >> 16;
+    f.lo1 += (lf * (f.lo0 - f.lo1) + 32768) >> 16;
+    f.hi1 += (hf * (f.hi0 - f.hi1) + 32768) >> 16;
+    f.lo2 += (lf * (f.lo1 - f.lo2) + 32768) >> 16;
+    f.hi2 += (hf * (f.hi1 - f.hi2) + 32768) >> 16;
+    f.lo3 += (lf * (f.lo2 - f.lo3) + 32768) >> 16;
+    f.hi3 += (hf * (f.hi2 - f.hi3) + 32768) >> 16;
+    int r = (f.lo3 * 65536) >> 16;
+    r += ((f.hi3 - f.lo3) * G1) >> 16;
+    if (G2 != 0) {
+        r += ((f.h2 - f.hi3) * G2) >> 16;
+        f.h2 = f.h1; f.h1 = f.h0; f.h0 = s;
+    }
+    return r;
+}
+
+/* pack 0x00RRGGBB into the little-endian dword of a 4-byte output format, crt_core.c:613-656 */
+__device__ __forceinline__ unsigned pack_px4(int rgb, int format)
+{
+    const unsigned u = (unsigned) rgb;
+    switch (format) {
+    case CRTHIP_FMT_BGRA: return 0xff000000u | u;
+    case CRTHIP_FMT_RGBA: return 0xff000000u | (u & 0xff00u) | (u >> 16 & 0xffu) | (u & 0xffu) << 16;
+    case CRTHIP_FMT_ARGB: return 0xffu | (u >> 16 & 0xffu) << 8 | (u >> 8 & 0xffu) << 16 | (u & 0xffu) << 24;
+    default /* ABGR */:   return 0xffu | u << 8;
+    }
+}
+/* inverse, for blend (crt_core.c:587-605) */
+__device__ __forceinline__ int unpack_px4(unsigned d, int format)
+{
+    switch (format) {
+    case CRTHIP_FMT_BGRA: return (int) (d & 0xffffffu);
+    case CRTHIP_FMT_RGBA: return (int) ((d & 0xffu) << 16 | (d & 0xff00u) | (d >> 16 & 0xffu));
+    case CRTHIP_FMT_ARGB: return (int) ((d >> 8 & 0xffu) << 16 | (d >> 16 & 0xffu) << 8 | d >> 24);
+    default /* ABGR */:   return (int) (d >> 8);
+    }
+}
+
+template <class S>
+__global__ void __launch_bounds__(64)
+k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const bool live = gid < n_fields * S::LINES;
+    crthip_line lp;
+    lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
+    const int f = live ? gid / S::LINES : 0;
+    if (live) lp = lines[gid];
+    const bool act = live && lp.nrows > 0;
+    const signed char *sig = inp + (size_t) f * fstride + lp.pos;
+    const int bpp = P.out_bpp;
+    const size_t pitch = (size_t) P.outw * bpp;
+    unsigned char *orow = outp + (size_t) f * ostride + (size_t) lp.beg * pitch;
+    const int nrows = act ? lp.nrows : 0;
+
+    const int w0 = lp.wave0, w1 = lp.wave1, nw0 = -lp.wave0, nw1 = -lp.wave1;
+    const int bright = P.bright, contrast = P.contrast;
+    const int ylf = P.eq_lf[0], yhf = P.eq_hf[0], ilf = P.eq_lf[1], ihf = P.eq_hf[1], qlf = P.eq_lf[2], qhf = P.eq_hf[2];
+    Eq3 ey = {}, ei = {}, eq = {};
+    int py = 0, pi = 0, pq = 0;                    /* yiq of the previous sample */
+
+    /* wave-uniform output pixel schedule, crt_core.c:528-531,555-562 */
+    const unsigned scan_r = (unsigned) (S::AV_LEN - 1) << 12;
+    const unsigned dx = (unsigned) P.dx;
+    unsigned ppos = 0;
+    int px = 0;
+    const int outw = P.outw;
+    unsigned pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;   /* finished pixels awaiting a 16-byte store */
+
+    constexpr int NQ = (S::AV_LEN + 3) / 4;        /* dwords per line window (last one partly beyond AV_LEN:
+                                                      the filters are causal, the extra samples feed nothing) */
+    int word = load4u(sig);
+    for (int xq = 0; xq < NQ; xq++) {
+        const int nextword = load4u(sig + 4 * (xq + 1 < NQ ? xq + 1 : xq));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = xq * 4 + k;
+            const int s = (word << (24 - 8 * k)) >> 24;
+            /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
+            const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
+            const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
+            const int cy = eq_step<8192, 9175>(ey, ylf, yhf, s + bright) << 4;
+            const int ci = eq_step<65536, 1311>(ei, ilf, ihf, s * wi >> 9) >> 3;
+            const int cq = eq_step<65536, 0>(eq, qlf, qhf, s * wq >> 9) >> 3;
+            /* D9: every output pixel whose left tap is sample x-1 is now computable */
+            while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
+                const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
+                const int yy = ((py * L) >> 2) + ((cy * R) >> 2);
+                const int ii = ((pi * L) >> 14) + ((ci * R) >> 14);
+                const int qq = ((pq * L) >> 14) + ((cq * R) >> 14);
+                int r = (((yy + 3879 * ii + 2556 * qq) >> 12) * contrast) >> 8;
+                int g = (((yy - 1126 * ii - 2605 * qq) >> 12) * contrast) >> 8;
+                int b = (((yy - 4530 * ii + 7021 * qq) >> 12) * contrast) >> 8;
+                r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
+                int rgb = r << 16 | g << 8 | b;
+                if (bpp == 4) {
+                    if (P.blend && act) {
+                        const int old = unpack_px4(*(const unsigned *) (orow + (size_t) px * 4), P.out_format);
+                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
+                    }
+                    {
+                        const unsigned pk = pack_px4(rgb, P.out_format);
+                        const int slot = px & 3;                      /* wave-uniform */
+                        if (slot == 0) pend0 = pk; else if (slot == 1) pend1 = pk; else if (slot == 2) pend2 = pk; else pend3 = pk;
+                    }
+                    if ((px & 3) == 3 || px == outw - 1) {
+                        const int base = px & ~3;
+                        const int cnt = px - base + 1;
+                        for (int rr = 0; rr < nrows; rr++) {          /* row `beg` + D10 duplicates, :661-664 */
+                            unsigned char *d = orow + (size_t) rr * pitch + (size_t) base * 4;
+                            if (cnt == 4) {
+                                v4i v; v.x = (int) pend0; v.y = (int) pend1; v.z = (int) pend2; v.w = (int) pend3;
+                                store16u(d, v);
+                            } else {
+                                ((unsigned *) d)[0] = pend0;
+                                if (cnt > 1) ((unsigned *) d)[1] = pend1;
+                                if (cnt > 2) ((unsigned *) d)[2] = pend2;
+                            }
+                        }
+                    }
+                } else {
+                    unsigned char *d0 = orow + (size_t) px * 3;
+                    if (P.blend && act) {
+                        const int old = P.out_format == CRTHIP_FMT_RGB ? (d0[0] << 16 | d0[1] << 8 | d0[2])
+                                                                       : (d0[2] << 16 | d0[1] << 8 | d0[0]);
+                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
+                    }
+                    const unsigned char c0 = (unsigned char) (P.out_format == CRTHIP_FMT_RGB ? rgb >> 16 : rgb);
+                    const unsigned char c2 = (unsigned char) (P.out_format == CRTHIP_FMT_RGB ? rgb : rgb >> 16);
+                    for (int rr = 0; rr < nrows; rr++) {
+                        unsigned char *d = d0 + (size_t) rr * pitch;
+                        d[0] = c0; d[1] = (unsigned char) (rgb >> 8); d[2] = c2;
+                    }
+                }
+                ppos += dx;
+                px++;
+            }
+            py = cy; pi = ci; pq = cq;
+        }
+        word = nextword;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* host side: context, dispatch by system, C ABI                               */
+/* ------------------------------------------------------------------------- */
+struct crthip_ctx {
+    int device;
+    int system, pattern;
+    struct crt_sysdef sd;
+    hipStream_t stream;
+    bool own_stream;
+    uint2 *d_jump16;
+    uint2 whole_field;          /* affine map of INPUT_SIZE LCG steps */
+    size_t fstride;
+    /* workspace for crthip_fieldpass */
+    int cap_fields;
+    signed char *d_analog, *d_inp;
+    crthip_line *d_lines;
+    /* profiling */
+    bool prof;
+    double prof_ms[CRTHIP_K_COUNT];
+    int prof_n[CRTHIP_K_COUNT];
+    struct Pending { int k; hipEvent_t a, b; } *pend;
+    int npend, cappend;
+    char err[256];
+};
+
+static int set_err(crthip_ctx *c, int code, const char *what, hipError_t e)
+{
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+    return code;
+}
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(ctx, CRTHIP_E_HIP, #call, e_); } while (0)
+
+static void lcg_jump_host(unsigned k, unsigned *mul, unsigned *add)
+{
+    unsigned am = LCG_MUL, ac = LCG_ADD, rm = 1u, rc = 0u;
+    while (k) {
+        if (k & 1u) { rm = am * rm; rc = am * rc + ac; }
+        ac = am * ac + ac;
+        am = am * am;
+        k >>= 1;
+    }
+    *mul = rm;
+    *add = rc;
+}
+
+template <class S> static bool sysdef_matches(const struct crt_sysdef &d)
+{
+    return d.hres == S::HRES && d.vres == S::VRES && d.input_size == S::INPUT_SIZE && d.top == S::TOP &&
+           d.bot == S::BOT && d.vper == S::VPER && d.hsync_window == S::HWIN && d.vsync_window == S::VWIN &&
+           d.hsync_thresh == S::HTHR && d.vsync_thresh == S::VTHR && d.sync_beg == S::SYNC_BEG &&
+           d.bw_beg == S::BW_BEG && d.cb_beg == S::CB_BEG && d.av_beg == S::AV_BEG && d.av_len == S::AV_LEN &&
+           d.vs_sep_end == S::VS_SEP_END && d.white_level == S::WHITE && d.burst_level == S::BURST &&
+           d.black_level == S::BLACK && d.blank_level == S::BLANK && d.sync_level == S::SYNC;
+}
+
+/* call fn(S{}) with the system table type S of (system, pattern); fn is a generic lambda */
+template <class F> static int dispatch_system(int system, int pattern, F &&fn)
+{
+    if (system == CRTHIP_SYSTEM_NTSC) return pattern == 1 ? fn(SysNTSC{}) : fn(SysNTSC0{});
+    if (system == CRTHIP_SYSTEM_NTSCVHS) return pattern == 1 ? fn(SysVHS{}) : fn(SysVHS0{});
+    if (system == CRTHIP_SYSTEM_NES) {
+        if (pattern == 2) return fn(SysNES2{});
+        if (pattern == 1) return fn(SysNES1{});
+        return fn(SysNES0{});
+    }
+    return CRTHIP_E_ARG;
+}
+
+struct ProfScope {
+    crthip_ctx *c; int k; hipEvent_t a, b; bool on;
+    ProfScope(crthip_ctx *ctx, int kernel) : c(ctx), k(kernel), on(ctx->prof)
+    {
+        if (on) {
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        hipEventRecord(b, c->stream);
+        if (c->npend == c->cappend) {
+            int ncap = c->cappend ? c->cappend * 2 : 64;
+            c->pend = (crthip_ctx::Pending *) realloc(c->pend, sizeof(*c->pend) * (size_t) ncap);
+            c->cappend = ncap;
+        }
+        c->pend[c->npend].k = k; c->pend[c->npend].a = a; c->pend[c->npend].b = b;
+        c->npend++;
+    }
+};
+
+template <class S, bool FULL>
+static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                          signed char *dst, const crthip_state *d_state, int nes_setup)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    {
+        ProfScope ps(c, CRTHIP_K_TEMPLATE);
+        const int total = n * CHUNKS;
+        hipLaunchKernelGGL((k_template<S, FULL>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, c->d_jump16, nes_setup);
+    }
+    {
+        ProfScope ps(c, CRTHIP_K_ACTIVE);
+        const int total = n * p->desth;
+        hipLaunchKernelGGL((k_active<S, FULL>), dim3((total + 63) / 64), dim3(64), 0, c->stream,
+                           *p, n, (const unsigned char *) d_images, istride, dst, c->fstride, d_state, c->d_jump16);
+    }
+    return CRTHIP_OK;
+}
+
+/* after crt_modulate: ccf preset (crt_ntsc.c:325-329, crt_nes.c:196-200), VHS resets (crt_ntscvhs.c:259,332-336) */
+template <class S>
+__global__ void k_encoder_state(const crthip_params P, int n_fields, crthip_state *state)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_fields) return;
+    crthip_state *st = state + f;
+    if constexpr (S::IS_NES) {
+        for (int r = 0; r < 3; r++) {
+            /* iccf[n % 3] is last written by the bottom-most line with that residue; all lines of a
+             * residue class write the same burst, so any line n of the class will do */
+            for (int k = 0; k < 4; k++) {
+                int cb = P.burst[(r + st->aux) % 3][k];
+                st->ccf[r][k] = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
+            }
+        }
+    } else {
+        const int inv_phase = ((st->field & 1) == (st->frame & 1));
+        for (int k = 0; k < 4; k++) {
+            int cb = S::PATTERN == 1 ? P.burst[0][(k + inv_phase * 2) & 3] : P.burst[0][k];
+            int v = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
+            st->ccf[0][k] = S::IS_VHS ? 0 : v;
+        }
+        if (S::IS_VHS) st->hsync = 0;
+        st->field &= 1;
+        st->frame &= 1;
+    }
+}
+
+extern "C" {
+
+int crthip_abi_version(void) { return CRTHIP_ABI_VERSION; }
+
+int crthip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
+{
+    if (!out) return CRTHIP_E_ARG;
+    *out = 0;
+    struct crt_sysdef sd;
+    if (crt_sysdef_get(&sd, system, chroma_pattern) != CRTHIP_OK) return CRTHIP_E_ARG;
+    if (dispatch_system(system, chroma_pattern, [&](auto tag) {
+            return sysdef_matches<decltype(tag)>(sd) ? CRTHIP_OK : CRTHIP_E_ARG; }) != CRTHIP_OK) {
+        fprintf(stderr, "crthip: host/device system tables disagree (system %d pattern %d)\n", system, chroma_pattern);
+        return CRTHIP_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CRTHIP_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CRTHIP_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "crthip: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return CRTHIP_E_NODEVICE;
+    }
+    crthip_ctx *c = new (std::nothrow) crthip_ctx();
+    if (!c) return CRTHIP_E_NOMEM;
+    memset(c, 0, sizeof(*c));
+    c->device = device; c->system = system; c->pattern = chroma_pattern; c->sd = sd;
+    c->fstride = crthip_field_stride(system, chroma_pattern);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return CRTHIP_E_HIP;
+    }
+    c->own_stream = true;
+    /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
+    const int nq = sd.input_size / 16 + 2;
+    uint2 *h = (uint2 *) malloc(sizeof(uint2) * (size_t) nq);
+    if (!h) { crthip_destroy(c); return CRTHIP_E_NOMEM; }
+    unsigned m16, a16;
+    lcg_jump_host(16, &m16, &a16);
+    h[0].x = 1u; h[0].y = 0u;
+    for (int q = 1; q < nq; q++) { h[q].x = m16 * h[q - 1].x; h[q].y = m16 * h[q - 1].y + a16; }
+    lcg_jump_host((unsigned) sd.input_size, &c->whole_field.x, &c->whole_field.y);
+    if (hipMalloc((void **) &c->d_jump16, sizeof(uint2) * (size_t) nq) != hipSuccess ||
+        hipMemcpy(c->d_jump16, h, sizeof(uint2) * (size_t) nq, hipMemcpyHostToDevice) != hipSuccess) {
+        free(h);
+        crthip_destroy(c);
+        return CRTHIP_E_HIP;
+    }
+    free(h);
+    *out = c;
+    return CRTHIP_OK;
+}
+
+void crthip_destroy(crthip_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->npend; i++) { hipEventDestroy(c->pend[i].a); hipEventDestroy(c->pend[i].b); }
+    free(c->pend);
+    if (c->d_jump16) hipFree(c->d_jump16);
+    if (c->d_analog) hipFree(c->d_analog);
+    if (c->d_inp) hipFree(c->d_inp);
+    if (c->d_lines) hipFree(c->d_lines);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int crthip_set_stream(crthip_ctx *c, void *hip_stream)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->stream = 0; }
+    if (hip_stream) {
+        c->stream = (hipStream_t) hip_stream;
+        c->own_stream = false;
+    } else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return CRTHIP_OK;
+}
+
+int crthip_synchronize(crthip_ctx *c)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRTHIP_OK;
+}
+
+const char *crthip_error_string(const crthip_ctx *c) { return c ? c->err : "null context"; }
+
+int crthip_reserve(crthip_ctx *c, int n)
+{
+    if (!c || n <= 0) return CRTHIP_E_ARG;
+    if (n <= c->cap_fields) return CRTHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_analog) hipFree(c->d_analog);
+    if (c->d_inp) hipFree(c->d_inp);
+    if (c->d_lines) hipFree(c->d_lines);
+    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->cap_fields = 0;
+    const size_t bytes = c->fstride * (size_t) n + 4096;
+    if (hipMalloc((void **) &c->d_inp, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc inp", hipSuccess);
+    if (hipMalloc((void **) &c->d_analog, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc analog", hipSuccess);
+    if (hipMalloc((void **) &c->d_lines, sizeof(crthip_line) * (size_t) n * c->sd.lines) != hipSuccess)
+        return set_err(c, CRTHIP_E_NOMEM, "hipMalloc lines", hipSuccess);
+    HIPCHK(c, hipMemsetAsync(c->d_inp, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_analog, 0, bytes, c->stream));
+    c->cap_fields = n;
+    return CRTHIP_OK;
+}
+
+static int check_params(crthip_ctx *c, const crthip_params *p, int n)
+{
+    if (!c || !p || n <= 0) return CRTHIP_E_ARG;
+    if (p->finalized != CRTHIP_PARAMS_MAGIC) return set_err(c, CRTHIP_E_ARG, "params not finalized", hipSuccess);
+    if (p->system != c->system || p->chroma_pattern != c->pattern) return set_err(c, CRTHIP_E_ARG, "params are for another system", hipSuccess);
+    return CRTHIP_OK;
+}
+
+/* the encoder contract: the active rectangle lies inside the field (the reference would
+ * scribble over neighbouring lines / out of bounds otherwise, crt_ntsc.c:322) */
+static int check_encoder(crthip_ctx *c, const crthip_params *p)
+{
+    if (c->system != CRTHIP_SYSTEM_NES && p->in_bpp == 0) return 1;   /* silent no-op, crt_ntsc.c:190-193 */
+    if (p->xo < 0 || p->yo < 0 || p->xo + p->destw > c->sd.hres || p->yo + p->desth > c->sd.vres || p->destw <= 0 || p->desth <= 0)
+        return set_err(c, CRTHIP_E_ARG, "active rectangle leaves the field (xoffset/yoffset out of contract)", hipSuccess);
+    return CRTHIP_OK;
+}
+
+int crthip_modulate(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    signed char *d_analog, crthip_state *d_state)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    rc = check_encoder(c, p);
+    if (rc) return rc < 0 ? rc : CRTHIP_OK;
+    if (!d_images || !d_analog || !d_state) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        int r = launch_encoder<S, false>(c, p, n, d_images, istride, d_analog, d_state, (p->flags & CRTHIP_F_NES_SETUP) != 0);
+        hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
+        return r;
+    });
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+int crthip_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
+                 crthip_state *d_state)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (p->out_bpp == 0) return CRTHIP_OK;                       /* crt_core.c:312-315 */
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS) return set_err(c, CRTHIP_E_ARG, "VHS rand() noise not implemented yet", hipSuccess);
+    if (!d_analog || !d_inp || !d_state) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+        {
+            ProfScope ps(c, CRTHIP_K_NOISE);
+            hipLaunchKernelGGL((k_noise<S>), dim3((n * CHUNKS + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_jump16);
+        }
+        hipLaunchKernelGGL(k_advance_rn, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_state, c->whole_field);
+        return CRTHIP_OK;
+    });
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+static int launch_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
+                       crthip_line *d_lines, int advance_rn)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        ProfScope ps(c, CRTHIP_K_SYNC);
+        hipLaunchKernelGGL((k_sync<S>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                           c->whole_field, advance_rn);
+        return CRTHIP_OK;
+    });
+}
+
+int crthip_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
+                crthip_line *d_lines)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (p->out_bpp == 0) return CRTHIP_OK;
+    if (!d_inp || !d_state || !d_lines) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = launch_sync(c, p, n, d_inp, d_state, d_lines, 0);
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
+                         const crthip_line *d_lines, void *d_out, size_t ostride)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        ProfScope ps(c, CRTHIP_K_DECODE);
+        const int total = n * S::LINES;
+        hipLaunchKernelGGL((k_decode<S>), dim3((total + 63) / 64), dim3(64), 0, c->stream,
+                           *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride);
+        return CRTHIP_OK;
+    });
+}
+
+int crthip_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, const crthip_line *d_lines,
+                  void *d_out, size_t ostride)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (p->out_bpp == 0) return CRTHIP_OK;
+    if (!d_inp || !d_lines || !d_out) return CRTHIP_E_ARG;
+    if (p->outh < c->sd.lines) return set_err(c, CRTHIP_E_ARG, "outh < CRT_LINES (row collisions) not supported by the parallel decoder", hipSuccess);
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = launch_decode(c, p, n, d_inp, d_lines, d_out, ostride);
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                     void *d_out, size_t ostride, crthip_state *d_state)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS) return set_err(c, CRTHIP_E_ARG, "VHS rand() noise not implemented yet", hipSuccess);
+    if (p->out_bpp != 0 && p->outh < c->sd.lines) return set_err(c, CRTHIP_E_ARG, "outh < CRT_LINES not supported", hipSuccess);
+    int enc = check_encoder(c, p);
+    if (enc < 0) return enc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->cap_fields) {
+        rc = crthip_reserve(c, n);
+        if (rc) return rc;
+    }
+    rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        if (enc == 0) {
+            /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
+            launch_encoder<S, true>(c, p, n, d_images, istride, c->d_inp, d_state, 1);
+            hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
+        } else {
+            /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise */
+            hipMemsetAsync(c->d_analog, 0, c->fstride * (size_t) n, c->stream);
+            constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+            hipLaunchKernelGGL((k_noise<S>), dim3((n * CHUNKS + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, c->d_analog, c->d_inp, c->fstride, d_state, c->d_jump16);
+        }
+        return CRTHIP_OK;
+    });
+    if (rc) return rc;
+    if (p->out_bpp != 0) {
+        rc = launch_sync(c, p, n, c->d_inp, d_state, c->d_lines, 1);
+        if (rc) return rc;
+        rc = launch_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_profile_enable(crthip_ctx *c, int on)
+{
+    if (!c) return CRTHIP_E_ARG;
+    c->prof = on != 0;
+    return CRTHIP_OK;
+}
+
+int crthip_profile_read(crthip_ctx *c, double total_ms[CRTHIP_K_COUNT], int launches[CRTHIP_K_COUNT])
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->npend; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->pend[i].a, c->pend[i].b) == hipSuccess) {
+            c->prof_ms[c->pend[i].k] += ms;
+            c->prof_n[c->pend[i].k]++;
+        }
+        hipEventDestroy(c->pend[i].a);
+        hipEventDestroy(c->pend[i].b);
+    }
+    c->npend = 0;
+    for (int k = 0; k < CRTHIP_K_COUNT; k++) {
+        if (total_ms) total_ms[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_n[k];
+        c->prof_ms[k] = 0.0;
+        c->prof_n[k] = 0;
+    }
+    return CRTHIP_OK;
+}
+
+void *crthip_malloc(crthip_ctx *c, size_t bytes)
+{
+    void *p = 0;
+    if (!c || hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return 0;
+    return p;
+}
+
+void crthip_free(crthip_ctx *c, void *d)
+{
+    if (c && d) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); hipFree(d); }
+}
+
+int crthip_upload(crthip_ctx *c, void *d, const void *h, size_t bytes)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRTHIP_OK;
+}
+
+int crthip_download(crthip_ctx *c, void *h, const void *d, size_t bytes)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRTHIP_OK;
+}
+
+int crthip_memset(crthip_ctx *c, void *d, int value, size_t bytes)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipMemsetAsync(d, value, bytes, c->stream));
+    return CRTHIP_OK;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,366 @@
+/*
+ * crt_setup.c -- C89 host code: everything the reference computes once per call or
+ * once per crt_init on the CPU stays on the CPU here too (last
+ * bullet): timing tables, carrier phases, filter coefficients, geometry.  The result
+ * is the `crthip_params` blob handed to the HIP kernels (and broadcast over RCCL in
+ * the multi-GPU driver).
+ */
+#include "crt_setup.h"
+
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* fixed-point trig: 14-bit angle (16384 = one turn) -> 15-bit sine / cosine   */
+/* reference: crt_core.c:19-61                                                */
+/* ------------------------------------------------------------------------- */
+
+/* first quadrant in 16 steps, one guard entry for the interpolation */
+static const int sine_knots[18] = {
+    0, 3208, 6392, 9512, 12536, 15440, 18200, 20784, 23168,
+    25328, 27240, 28896, 30272, 31352, 32136, 32608, 32768, 32608
+};
+
+static int
+sine_q1(int a)
+{
+    int k = (a >> 8) & 255;
+    int t = a & 255;
+    return sine_knots[k] + (((sine_knots[k + 1] - sine_knots[k]) * t) >> 8);
+}
+
+void
+crt_setup_sincos14(int *s, int *c, int n)
+{
+    int a, sn, cs;
+
+    n &= 16383;
+    a = n & 8191;                 /* position inside the half turn */
+    if (a < 4096) {
+        sn = sine_q1(a);
+        cs = sine_q1(4096 - a);
+    } else {
+        sn = sine_q1(8192 - a);
+        cs = -sine_q1(a - 4096);
+    }
+    if (n & 8192) {               /* second half turn: both change sign */
+        sn = -sn;
+        cs = -cs;
+    }
+    *s = sn;
+    *c = cs;
+}
+
+int
+crt_setup_bpp4fmt(int format)
+{
+    switch (format) {
+    case CRTHIP_FMT_RGB:
+    case CRTHIP_FMT_BGR:
+        return 3;
+    case CRTHIP_FMT_ARGB:
+    case CRTHIP_FMT_RGBA:
+    case CRTHIP_FMT_ABGR:
+    case CRTHIP_FMT_BGRA:
+        return 4;
+    default:
+        return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Q11 exponential, reference: crt_ntsc.c:25-83                                */
+/* ------------------------------------------------------------------------- */
+#define Q11 2048
+
+int
+crt_setup_expx(int n)
+{
+    /* e^0 .. e^4 in Q11 */
+    static const int e_int[5] = { Q11, 5567, 15133, 41135, 111817 };
+    int inverse, ip, r, series, term, fact, k;
+
+    if (n == 0) {
+        return Q11;
+    }
+    inverse = (n < 0);
+    if (inverse) {
+        n = -n;
+    }
+    ip = n >> 11;
+    r = Q11;
+    for (k = ip / 4; k > 0; k--) {
+        r = (r * e_int[4]) >> 11;
+    }
+    if (ip & 3) {
+        r = (r * e_int[ip & 3]) >> 11;
+    }
+    /* Taylor series of the fractional part; same truncation rule as the reference */
+    n &= Q11 - 1;
+    series = 0;
+    term = Q11;
+    fact = 1;
+    for (k = 1; k < 17; k++) {
+        series += term / fact;
+        term = (term * n) >> 11;
+        fact *= k;
+        if (fact > term || term <= 0 || fact <= 0) {
+            break;
+        }
+    }
+    r = (r * series) >> 11;
+    if (inverse) {
+        r = (Q11 << 11) / r;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------- */
+/* system tables                                                              */
+/* ------------------------------------------------------------------------- */
+#define L_FREQ 1431818
+
+int
+crt_sysdef_get(struct crt_sysdef *d, int system, int chroma_pattern)
+{
+    int cc_line;
+
+    memset(d, 0, sizeof(*d));
+    d->system = system;
+    d->chroma_pattern = chroma_pattern;
+    d->vres = 262;
+    if (system == CRTHIP_SYSTEM_NTSC || system == CRTHIP_SYSTEM_NTSCVHS) {
+        /* crt_ntsc.h:25-109: times in ns on a 63500 ns line */
+        const int line_ns = 63500;
+        if (chroma_pattern != 0 && chroma_pattern != 1) {
+            return CRTHIP_E_ARG;
+        }
+        cc_line = (chroma_pattern == 1) ? 2275 : 2280;
+        d->hres = cc_line * 4 / 10;
+        d->top = 21;
+        d->bot = 261;
+        d->vper = 1;
+        d->hsync_window = 8;
+        d->vsync_window = 8;
+        d->white_level = 100;
+        d->burst_level = 20;
+        d->black_level = 7;
+        d->blank_level = 0;
+        d->sync_level = -40;
+        d->sync_beg = 1500 * d->hres / line_ns;
+        d->bw_beg = 6200 * d->hres / line_ns;
+        d->cb_beg = 6800 * d->hres / line_ns;
+        d->av_beg = 10900 * d->hres / line_ns;
+        d->av_len = 52600 * d->hres / line_ns;
+        if (system == CRTHIP_SYSTEM_NTSCVHS) {   /* VHS_SP, crt_ntscvhs.h:109-113 */
+            d->y_freq = 300000;
+            d->i_freq = 62700;
+            d->q_freq = 62700;
+        } else {                                 /* crt_ntsc.h:99-102 */
+            d->y_freq = 420000;
+            d->i_freq = 150000;
+            d->q_freq = 55000;
+        }
+    } else if (system == CRTHIP_SYSTEM_NES) {
+        /* crt_nes.h:30-126: positions in PPU pixels on a 341 px line */
+        const int line_px = 341;
+        if (chroma_pattern < 0 || chroma_pattern > 2) {
+            return CRTHIP_E_ARG;
+        }
+        cc_line = (chroma_pattern == 1) ? 2275 : ((chroma_pattern == 2) ? 2273 : 2280);
+        d->hres = cc_line * 4 / 10;
+        d->top = 15;
+        d->bot = 255;
+        d->vper = 3;
+        d->hsync_window = 6;
+        d->vsync_window = 6;
+        d->white_level = 110;
+        d->burst_level = 30;
+        d->black_level = 0;
+        d->blank_level = 0;
+        d->sync_level = -37;
+        d->sync_beg = 9 * d->hres / line_px;
+        d->bw_beg = 34 * d->hres / line_px;
+        d->cb_beg = 38 * d->hres / line_px;
+        d->av_beg = 74 * d->hres / line_px;
+        d->av_len = 256 * d->hres / line_px;
+        d->vs_sep_end = 327 * d->hres / line_px;
+    } else {
+        return CRTHIP_E_ARG;
+    }
+    d->input_size = d->hres * d->vres;
+    d->lines = d->bot - d->top;
+    d->hsync_thresh = 4 * d->sync_level;     /* CRT_HSYNC_THRESH */
+    d->vsync_thresh = 94 * d->sync_level;    /* CRT_VSYNC_THRESH */
+    return CRTHIP_OK;
+}
+
+int
+crthip_input_size(int system, int chroma_pattern)
+{
+    struct crt_sysdef d;
+    if (crt_sysdef_get(&d, system, chroma_pattern) != CRTHIP_OK) {
+        return 0;
+    }
+    return d.input_size;
+}
+
+int
+crthip_hres(int system, int chroma_pattern)
+{
+    struct crt_sysdef d;
+    if (crt_sysdef_get(&d, system, chroma_pattern) != CRTHIP_OK) {
+        return 0;
+    }
+    return d.hres;
+}
+
+int
+crthip_lines(int system)
+{
+    struct crt_sysdef d;
+    if (crt_sysdef_get(&d, system, system == CRTHIP_SYSTEM_NES ? 2 : 1) != CRTHIP_OK) {
+        return 0;
+    }
+    return d.lines;
+}
+
+size_t
+crthip_field_stride(int system, int chroma_pattern)
+{
+    /* INPUT_SIZE + room for the mirrored struct tail and for the widest out-of-contract
+     * window (pos <= INPUT_SIZE-1, window AV_LEN, 16-byte vector reads), rounded to 256 */
+    size_t n = (size_t) crthip_input_size(system, chroma_pattern);
+    if (n == 0) {
+        return 0;
+    }
+    n += 1024;
+    return (n + 255) & ~(size_t) 255;
+}
+
+/* ------------------------------------------------------------------------- */
+/* parameter blob                                                             */
+/* ------------------------------------------------------------------------- */
+
+int
+crthip_params_default(crthip_params *p, int system, int chroma_pattern)
+{
+    struct crt_sysdef d;
+
+    if (p == 0 || crt_sysdef_get(&d, system, chroma_pattern) != CRTHIP_OK) {
+        return CRTHIP_E_ARG;
+    }
+    memset(p, 0, sizeof(*p));
+    p->system = system;
+    p->chroma_pattern = chroma_pattern;
+    p->format = CRTHIP_FMT_BGRA;
+    p->out_format = CRTHIP_FMT_BGRA;
+    p->as_color = 1;
+    /* crt_reset, crt_core.c:250-261 */
+    p->saturation = 10;
+    p->contrast = 180;
+    p->white_point = 100;
+    return CRTHIP_OK;
+}
+
+/* one-pole low-pass coefficient, crt_ntsc.c:98-106 (init_iir) */
+static int
+lowpass_coef(int limit)
+{
+    int rate = (L_FREQ << 9) / limit;
+    return Q11 - crt_setup_expx(-((6434 << 9) / rate));
+}
+
+int
+crthip_params_finalize(crthip_params *p)
+{
+    /* crt_core.c:278-280: band edges in kHz and band gains (Q16) for Y, I, Q */
+    static const int edge_khz[3][2] = { { 1500, 3000 }, { 80, 1150 }, { 80, 1000 } };
+    static const int band_gain[3][3] = {
+        { 65536, 8192, 9175 }, { 65536, 65536, 1311 }, { 65536, 65536, 0 }
+    };
+    struct crt_sysdef d;
+    int k, r, sn, cs;
+
+    if (p == 0 || crt_sysdef_get(&d, p->system, p->chroma_pattern) != CRTHIP_OK) {
+        return CRTHIP_E_ARG;
+    }
+    p->finalized = 0;
+    p->out_bpp = crt_setup_bpp4fmt(p->out_format);
+    if (p->outw <= 0 || p->outh <= 0 || p->w <= 0 || p->h <= 0) {
+        return CRTHIP_E_ARG;
+    }
+
+    memset(p->burst, 0, sizeof(p->burst));
+    memset(p->modI, 0, sizeof(p->modI));
+    memset(p->modQ, 0, sizeof(p->modQ));
+    if (p->system == CRTHIP_SYSTEM_NES) {
+        /* crt_nes.c:110-136.  burst row r serves lines with (n + dot_crawl_offset) % 3 == r */
+        p->in_bpp = 2;
+        p->destw = d.av_len;
+        p->desth = d.lines;
+        p->xo = (d.av_beg + p->xoffset) & ~3;
+        p->yo = d.top + p->yoffset;
+        for (r = 0; r < 3; r++) {
+            for (k = 0; k < 4; k++) {
+                int ang = (p->hue + k * 90 + r * 120 + 33) % 360;
+                crt_setup_sincos14(&sn, &cs, ang * 8192 / 180);
+                p->burst[r][k] = sn >> 10;
+            }
+        }
+        p->iir_c[0] = p->iir_c[1] = p->iir_c[2] = 0;
+    } else {
+        /* crt_ntsc.c:132-133, 163-203 */
+        p->in_bpp = crt_setup_bpp4fmt(p->format);
+        p->destw = d.av_len;
+        p->desth = (d.lines * 64500) >> 16;
+        if (p->raw) {
+            if (p->w < p->destw) {
+                p->destw = p->w;
+            }
+            if (p->h < p->desth) {
+                p->desth = p->h;
+            }
+        }
+        p->xo = (d.av_beg + p->xoffset + (d.av_len - p->destw) / 2) & ~3;
+        p->yo = d.top + p->yoffset + (d.lines - p->desth) / 2;
+        if (p->as_color) {
+            for (k = 0; k < 4; k++) {
+                int ang = p->hue + k * 90;
+                crt_setup_sincos14(&sn, &cs, (ang + 33) * 8192 / 180);
+                p->burst[0][k] = sn >> 10;
+                crt_setup_sincos14(&sn, &cs, ang * 8192 / 180);
+                p->modI[k] = sn >> 10;
+                crt_setup_sincos14(&sn, &cs, (ang - 90) * 8192 / 180);
+                p->modQ[k] = sn >> 10;
+            }
+        }
+        p->iir_c[0] = lowpass_coef(d.y_freq);
+        p->iir_c[1] = lowpass_coef(d.i_freq);
+        p->iir_c[2] = lowpass_coef(d.q_freq);
+    }
+
+    /* crt_core.c:171-196 with EQ_P = 16: cut-off as 2*sin(pi*f/rate), Q16 */
+    for (k = 0; k < 3; k++) {
+        int f_lo = d.hres * (edge_khz[k][0] * 100) / L_FREQ;
+        int f_hi = d.hres * (edge_khz[k][1] * 100) / L_FREQ;
+        crt_setup_sincos14(&sn, &cs, 8192 * f_lo / d.hres);
+        p->eq_lf[k] = 2 * (sn << 1);
+        crt_setup_sincos14(&sn, &cs, 8192 * f_hi / d.hres);
+        p->eq_hf[k] = 2 * (sn << 1);
+        for (r = 0; r < 3; r++) {
+            p->eq_g[k][r] = band_gain[k][r];
+        }
+    }
+
+    /* crt_core.c:305, 318-320, 404-405, 528 */
+    crt_setup_sincos14(&sn, &cs, ((p->mon_hue % 360) + 33) * 8192 / 180);
+    p->huesn = sn >> 11;
+    p->huecs = cs >> 11;
+    p->bright = p->brightness - (d.black_level + p->black_point);
+    p->white = d.white_level * p->white_point / 100;
+    p->ire_base = d.black_level + p->black_point;
+    p->dx = ((d.av_len - 1) << 12) / p->outw;
+    p->ratio = (((p->outh << 16) / d.lines) + 32768) >> 16;
+    p->finalized = CRTHIP_PARAMS_MAGIC;
+    return CRTHIP_OK;
+}

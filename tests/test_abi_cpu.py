@@ -1,0 +1,102 @@
+"""CPU-side checks of the native library: it builds, loads, exports every symbol that
+include/crt_hip.h declares, and its C89 host setup (crt_setup.c) derives the same constants
+as the oracle.  No compute calls -- there is no GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import crtref as R
+
+ROOT = R.ROOT
+PKG = os.path.join(ROOT, "ntsc-crt_amd")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    import crtlib
+    return crtlib
+
+
+def _declared_functions(header):
+    src = open(header).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(crthip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    L = lib.load_library()
+    names = _declared_functions(os.path.join(ROOT, "include", "crt_hip.h"))
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.crthip_abi_version() == 1
+
+
+def test_struct_sizes_match_header(lib):
+    hdr = '#include "crt_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu\\n", sizeof(crthip_params), sizeof(crthip_state), sizeof(crthip_line));return 0;}\n'
+    exe = "/tmp/crthip_sizes"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe],
+                   input=hdr.encode(), check=True)
+    a, b, c = map(int, subprocess.run([exe], capture_output=True, check=True).stdout.split())
+    assert a == C.sizeof(lib.Params)
+    assert b == 4 * lib.STATE_INTS
+    assert c == 4 * lib.LINE_INTS
+
+
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0"])
+def test_host_setup_matches_oracle(lib, name):
+    orc = R.Oracle(name)
+    L = lib.load_library()
+    sysid, pattern = lib.SYSTEMS[name]
+    assert L.crthip_input_size(sysid, pattern) == orc.input_size
+    assert L.crthip_hres(sysid, pattern) == orc.hres
+    assert L.crthip_lines(sysid) == orc.bot - orc.top
+    assert L.crthip_field_stride(sysid, pattern) >= orc.input_size + 16 + 753 + 16
+    p = lib.make_params(name, w=640, h=480, outw=832, outh=624, hue=25, mon_hue=340, brightness=4,
+                        black_point=2, white_point=97)
+    assert list(p.eq_lf) == list(orc.sys.eq_lf)
+    assert list(p.eq_hf) == list(orc.sys.eq_hf)
+    assert [list(r) for r in p.eq_g] == [list(r) for r in orc.sys.eq_g]
+    if name in ("ntsc", "vhs"):
+        assert list(p.iir_c) == list(orc.sys.iir_c)
+        assert (p.destw, p.desth, p.xo, p.yo) == (753, 236, 156, 23)
+    s, c = orc.sincos14(((340 % 360) + 33) * 8192 // 180)
+    assert (p.huesn, p.huecs) == (s >> 11, c >> 11)
+    assert p.bright == 4 - (orc.sys.black_level + 2)
+    assert p.dx == ((orc.av_len - 1) << 12) // 832
+
+
+def test_sincos14_host_matches_oracle(lib):
+    L = lib.load_library()
+    orc = R.Oracle("ntsc")
+    s, c = C.c_int(), C.c_int()
+    for n in range(-17000, 34000, 11):
+        L.crt_setup_sincos14(C.byref(s), C.byref(c), n)
+        assert (s.value, c.value) == orc.sincos14(n)
+    L.crt_setup_expx.restype = C.c_int
+    orc.lib.orc_expx.restype = C.c_int
+    for n in list(range(-30000, 30000, 37)) + [0, 1, -1, 2047, 2048, -2048]:
+        assert L.crt_setup_expx(n) == orc.lib.orc_expx(n), n
+
+
+def test_product_never_loads_the_oracle(lib):
+    """The shipped package must not reference oracle/ (it is the checker, not a fallback)."""
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("libcrt_oracle", "crt_oracle", "oracle/_ref", "libref_", "orc_"):
+                    assert needle not in txt, (f, needle)
+
+
+def test_missing_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        lib.CRT(1, 640, 480)

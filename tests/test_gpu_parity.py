@@ -1,0 +1,136 @@
+"""GPU parity tests proper: the HIP path (through the crthip_* C ABI) against the CPU oracle on
+the same seeded inputs.  Bit-exact: this is integer/byte work, tolerance = 0.  Every stage the
+reference exposes through struct CRT is compared (analog, inp, ccf, hsync, vsync, rn, out) plus
+the internal per-line sync chain."""
+import numpy as np
+import pytest
+
+import crtref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def crtlib():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+    import crtlib
+    return crtlib
+
+
+def _to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _padded(imgs):
+    """[n,h,w,c] -> device tensor view [n,h,w,c] inside an [n,h+1,w,c] allocation (row h is
+    addressable: crt_ntsc.c:263 quirk)."""
+    import torch
+    n, h = imgs.shape[0], imgs.shape[1]
+    full = torch.zeros((n, h + 1) + tuple(imgs.shape[2:]), dtype=torch.uint8, device="cuda:0")
+    full[:, :h] = _to_dev(imgs)
+    full[:, h] = full[:, h - 1]
+    return full[:, :h]
+
+
+def _oracle_batch(name, n, outw, outh, ofmt, knobs):
+    orc = R.Oracle(name)
+    crts = []
+    for _ in range(n):
+        c = orc.new_crt(outw, outh, ofmt)
+        for k, v in knobs.items():
+            c.set(k, v)
+        crts.append(c)
+    return orc, crts
+
+
+CASES = [
+    # name, outw, outh, ofmt, w, h, ifmt, noise, settings, knobs
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 0, dict(as_color=1), {}),
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(scanlines=1)),
+    ("ntsc", 832, 624, R.FMT_ARGB, 640, 480, R.FMT_ABGR, 40, dict(as_color=1, hue=350), dict(hue=17, saturation=14)),
+    ("ntsc", 640, 480, R.FMT_RGB, 320, 200, R.FMT_RGB, 12, dict(as_color=1, hue=30), dict(blend=1)),
+    ("ntsc", 1920, 1080, R.FMT_RGBA, 1920, 1080, R.FMT_BGR, 0, dict(as_color=1), dict(scanlines=1)),
+    ("ntsc", 1920, 1080, R.FMT_BGRA, 1920, 1080, R.FMT_BGRA, 0, dict(as_color=1), dict(scanlines=0, blend=1)),
+    ("ntsc", 753, 240, R.FMT_ABGR, 753, 236, R.FMT_RGBA, 5, dict(as_color=0), dict(brightness=9, contrast=200)),
+    ("ntsc", 500, 300, R.FMT_BGR, 200, 100, R.FMT_ARGB, 60, dict(as_color=1, raw=1), dict(black_point=3, white_point=90)),
+    ("ntsc", 333, 481, R.FMT_RGB, 100, 300, R.FMT_RGB, 100, dict(as_color=1, raw=1, xoffset=8, yoffset=2), dict(v_fac=10)),
+    ("ntsc", 257, 243, R.FMT_BGRA, 800, 600, R.FMT_BGRA, 24, dict(as_color=1, hue=180), dict(scanlines=1, blend=1)),
+]
+
+
+def _run_case(crtlib, case, fused, steps=4, n=3):
+    name, outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = case
+    bpp = R.bpp4fmt(ifmt)
+    imgs = np.stack([R.synth_image(w, h, bpp, 777 + 13 * k, "random" if k % 2 == 0 else "bars") for k in range(n)])
+    dimgs = _padded(imgs)
+    orc, ocrts = _oracle_batch(name, n, outw, outh, ofmt, knobs)
+    g = crtlib.CRT(n, outw, outh, ofmt, name, device=0)
+    for k, v in knobs.items():
+        setattr(g, k, v)
+    fields = [k & 1 for k in range(n)]
+    frames = [(k >> 1) & 1 for k in range(n)]
+    s = crtlib.Settings(dimgs, format=ifmt, field=list(fields), frame=list(frames), **skw)
+    for k, c in enumerate(ocrts):
+        pad = np.concatenate([imgs[k], imgs[k][-1:]], axis=0)
+        c.settings(pad, format=ifmt, w=w, h=h, field=fields[k], frame=frames[k], **skw)
+    for step in range(steps):
+        if fused:
+            g.fieldpass(s, noise)
+        else:
+            g.modulate(s)
+            analog = g.analog.cpu().numpy()
+            ccf_mod = g.ccf.copy()
+            g.demodulate(noise)
+        g.synchronize()
+        gout = g.out.cpu().numpy()
+        gst = {f: g.get(f) for f in ("hsync", "vsync", "rn")}
+        gccf = g.ccf
+        if not fused:
+            ginp = g.inp.cpu().numpy()
+            glines = g.line_table.cpu().numpy()
+        for k, c in enumerate(ocrts):
+            what = "%s fused=%s step %d field %d" % (name, fused, step, k)
+            c.modulate()
+            if not fused:
+                np.testing.assert_array_equal(analog[k, :orc.input_size], c.analog, err_msg=what + " analog")
+                np.testing.assert_array_equal(ccf_mod[k, :orc.vper], c.ccf, err_msg=what + " ccf after modulate")
+            c.demodulate(noise, trace=True)
+            if not fused:
+                np.testing.assert_array_equal(ginp[k, :orc.input_size], c.inp, err_msg=what + " inp")
+                tr = c.trace
+                valid = tr[:, 0] == 1
+                np.testing.assert_array_equal(glines[k][:, 4] > 0, valid, err_msg=what + " valid lines")
+                np.testing.assert_array_equal(glines[k][valid][:, [0, 1, 2, 3, 5]], tr[valid][:, [1, 2, 3, 4, 6]],
+                                              err_msg=what + " line table (pos, wave0, wave1, beg, hsync)")
+            for f in ("hsync", "vsync", "rn"):
+                assert gst[f][k] == c.get(f), "%s %s: gpu %d oracle %d" % (what, f, gst[f][k], c.get(f))
+            np.testing.assert_array_equal(gccf[k, :orc.vper], c.ccf, err_msg=what + " ccf")
+            np.testing.assert_array_equal(gout[k].reshape(-1), c.out, err_msg=what + " out")
+        # next field: interlaced sequence (video_convert.c:259-267)
+        fields = [f ^ 1 for f in fields]
+        if step % 2 == 0:
+            frames = [f ^ 1 for f in frames]
+        s.field, s.frame = list(fields), list(frames)
+        for k, c in enumerate(ocrts):
+            c.sset("field", fields[k])
+            c.sset("frame", frames[k])
+    g.close()
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_stagewise_parity(crtlib, case):
+    _run_case(crtlib, CASES[case], fused=False)
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_fused_fieldpass_parity(crtlib, case):
+    _run_case(crtlib, CASES[case], fused=True)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
