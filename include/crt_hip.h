@@ -159,7 +159,8 @@ size_t crthip_field_stride(int system, int chroma_pattern);  /* bytes between co
 /* Context = one device + one stream + the jump tables of the noise LCG. */
 int  crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern);
 void crthip_destroy(crthip_ctx *ctx);
-int  crthip_set_stream(crthip_ctx *ctx, void *hip_stream);   /* hipStream_t; NULL = own stream */
+int  crthip_set_stream(crthip_ctx *ctx, void *hip_stream);   /* hipStream_t; NULL = the default stream,
+                                                                  which is also the initial setting */
 int  crthip_synchronize(crthip_ctx *ctx);
 const char *crthip_error_string(const crthip_ctx *ctx);
 

@@ -903,11 +903,12 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     memset(c, 0, sizeof(*c));
     c->device = device; c->system = system; c->pattern = chroma_pattern; c->sd = sd;
     c->fstride = crthip_field_stride(system, chroma_pattern);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess) {
         delete c;
         return CRTHIP_E_HIP;
     }
-    c->own_stream = true;
+    c->stream = 0;              /* the device's default stream until crthip_set_stream() */
+    c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;
     uint2 *h = (uint2 *) malloc(sizeof(uint2) * (size_t) nq);
@@ -932,7 +933,7 @@ void crthip_destroy(crthip_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->npend; i++) { hipEventDestroy(c->pend[i].a); hipEventDestroy(c->pend[i].b); }
     free(c->pend);
     if (c->d_jump16) hipFree(c->d_jump16);
@@ -947,14 +948,8 @@ int crthip_set_stream(crthip_ctx *c, void *hip_stream)
 {
     if (!c) return CRTHIP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->stream = 0; }
-    if (hip_stream) {
-        c->stream = (hipStream_t) hip_stream;
-        c->own_stream = false;
-    } else {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t) hip_stream;       /* NULL = the default stream */
     return CRTHIP_OK;
 }
 
