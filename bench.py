@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the NTSC-CRT field-pass hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one pass of the hot path (crt_modulate + crt_demodulate, fused launch sequence)
+over one device-resident batch of synthetic fields.  Workload = BASELINE.json configs[1]:
+640x480 BGRA in -> 640x480 BGRA out, CRT_SYSTEM_NTSC, interlaced (field parity alternates per
+frame), full colour, noise 24, hue 0, scanlines 1.  "frames/sec" = field-passes/sec (one
+field-pass per input frame, as extra/video_convert.c:259-260 does).
+
+Multi-GPU: one process per GPU, frames sharded by rank (weak scaling: fixed batch per GPU);
+the only collective on the data path is the RCCL broadcast of the settings blob from rank 0.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel vs the HBM roofline (bytes per SURVEY.md 8(d) / DESIGN.md)
+  cpu_baseline  the reference (oracle/_ref, unmodified sources) or the oracle port, 1 core
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ntsc-crt_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
+
+
+def algorithmic_bytes(w, h, in_bpp, outw, outh, out_bpp, scanlines, blend, lines=240, desth=236):
+    """compulsory HBM bytes of one field-pass."""
+    rows_in = min(desth, h)
+    rows_out = 0
+    for l in range(lines):                       # crt_core.c:428-432, :661-664 (even field, v_fac 0)
+        beg, end = l * outh // lines, min((l + 1) * outh // lines, outh)
+        if beg < outh:
+            rows_out += max(end - scanlines - beg, 1)
+    b = rows_in * w * in_bpp + rows_out * outw * out_bpp
+    if blend:
+        b += lines * outw * out_bpp
+    return b
+
+
+def cpu_baseline(w, h, outw, outh, noise, scanlines, budget_s):
+    """Time the reference (or the oracle port) on ONE host core on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import crtref as R
+    if R.have_ref("ntsc"):
+        lib, kind = R.RefLib("ntsc"), "reference"
+    else:
+        R.build_oracle()
+        lib, kind = R.Oracle("ntsc"), "port"
+    img = R.synth_image(w, h, 4, 12345)
+    c = lib.new_crt(outw, outh, R.FMT_BGRA)
+    c.set("scanlines", scanlines)
+    c.settings(img, format=R.FMT_BGRA, w=w, h=h, as_color=1, hue=0, field=0, frame=0)
+    t, _, _ = c.time_fieldpasses(noise, 20, True)            # warm-up + calibration
+    reps = max(50, min(4000, int(budget_s / (t / 20))))
+    t, _, _ = c.time_fieldpasses(noise, reps, True)
+    return {"value": reps / t, "unit": "frames/sec", "cores": 1, "kind": kind,
+            "sample": "%d field-passes of the same 640x480 interlaced noise-%d workload, 1 thread" % (reps, noise),
+            "host_cores_visible": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="fields per GPU per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--noise", type=int, default=24)
+    ap.add_argument("--scanlines", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import crtlib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    w, h, n = args.width, args.height, args.batch
+    crt = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=local)
+    crt.scanlines = args.scanlines
+    crt.reserve(n)
+
+    # synthetic input, generated on the device: uniform random BGRA bytes per frame
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12345 + rank)
+    images = torch.randint(0, 256, (n, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)[:, :h]
+    s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
+                        field=[k & 1 for k in range(n)], frame=[(k >> 1) & 1 for k in range(n)])
+
+    # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
+    p = crt.params(s, args.noise)
+    if dist is not None:
+        blob = torch.frombuffer(bytearray(bytes(p)), dtype=torch.uint8).to(dev)
+        dist.broadcast(blob, src=0)
+        C.memmove(C.byref(p), bytes(blob.cpu().numpy().tobytes()), C.sizeof(p))
+    crt._load_field_state(s)
+
+    def step(k):
+        crt.fieldpass(s, args.noise, params=p)
+        # next field of the interlaced sequence (video_convert.c:261-267)
+        crt.state[:, crtlib.ST_FIELD] ^= 1
+        if k % 2 == 0:
+            crt.state[:, crtlib.ST_FRAME] ^= 1
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations with HIP events on the launch stream (separate short run, same workload)
+    crt.profile(True)
+    for k in range(min(args.steps, 5)):
+        step(k)
+    prof = crt.profile_read()
+    crt.profile(False)
+    kern_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+    dom = max(kern_ms, key=lambda k: kern_ms[k])
+
+    if rank == 0:
+        total_frames = world * n * args.steps
+        fps = total_frames / elapsed
+        abytes = algorithmic_bytes(w, h, 4, w, h, 4, args.scanlines, 0)
+        achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_" + dom + "_bytes_per_field")
+                traffic = traffic * n if traffic else None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec at 640x480 interlaced, bit-exact vs CPU; % HBM roofline",
+            "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "NTSC %dx%d BGRA -> %dx%d BGRA, interlaced, full colour, noise %d, hue 0, "
+                                   "scanlines %d (BASELINE configs[1])" % (w, h, w, h, args.noise, args.scanlines),
+                       "fields_per_gpu_per_step": n, "frames_per_step": world * n,
+                       "sharding": "frames by rank, RCCL broadcast of settings only"},
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_field": abytes,
+                         "kernel_ms": kern_ms,
+                         "pipeline_achieved": abytes * n * args.steps / elapsed / 1e9,
+                         "pipeline_frac": abytes * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "note": "640x480 is integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(w, h, w, h, args.noise, args.scanlines, args.cpu_seconds)
+            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

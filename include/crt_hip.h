@@ -205,6 +205,12 @@ int  crthip_decode(crthip_ctx *ctx, const crthip_params *p, int n,
                    const signed char *d_inp, const crthip_line *d_lines,
                    void *d_out, size_t out_stride);
 
+/* The decoder and encoder normally run kernels whose multiplies are the full-rate 24-bit
+ * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,
+ * "24-bit multiply envelope"), everything else goes to the exact 32-bit instantiation.  Both
+ * give identical results; this switch forces the 32-bit kernels everywhere (tests, debugging). */
+int  crthip_set_exact(crthip_ctx *ctx, int on);
+
 /* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg).
  * While enabled every launch is bracketed by an event pair. */
 int  crthip_profile_enable(crthip_ctx *ctx, int on);

@@ -86,6 +86,7 @@ def load_library():
     L.crthip_sync.argtypes = [vp, PP, ci, vp, vp, vp]
     L.crthip_decode.argtypes = [vp, PP, ci, vp, vp, vp, sz]
     L.crthip_profile_enable.argtypes = [vp, ci]
+    L.crthip_set_exact.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
     _LIB = L
     return L
@@ -288,6 +289,10 @@ class CRT:
         s.initialized = 1
 
     # ------------------------------------------------------------------ observation
+    def set_exact(self, on=True):
+        """Force the exact 32-bit-multiply kernels (normally only used outside the proven 24-bit envelope)."""
+        self._check(self.L.crthip_set_exact(self.ctx, int(on)), "crthip_set_exact")
+
     def profile(self, on=True):
         self._check(self.L.crthip_profile_enable(self.ctx, int(on)), "crthip_profile_enable")
 

@@ -105,6 +105,14 @@ __device__ __forceinline__ void store4u(void *p, int v) { ((unaligned4 *) p)->v 
 __device__ __forceinline__ int posmod(int x, int n) { return ((x % n) + n) % n; }  /* crt_core.c:17 */
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* full-rate 24-bit multiply when FAST (operands proven inside [-2^23, 2^23)), else the
+ * quarter-rate exact 32-bit one -- see the comment above k_decode */
+template <bool FAST> __device__ __forceinline__ int mulq(int a, int b)
+{
+    if (FAST) return __mul24(a, b);
+    return a * b;
+}
+
 /* noise LCG, crt_core.c:359-364 */
 __device__ __forceinline__ unsigned lcg_step(unsigned rn) { return LCG_MUL * rn + LCG_ADD; }
 __device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)
@@ -164,14 +172,12 @@ skeleton(const crthip_params &P, int n, int t, int field, int inv_phase, int aux
     }
 }
 
-/* One lane per 16 consecutive samples.  FULL=false: write exactly the reference's
- * write-set into analog[] (drop-in semantics, other samples keep their contents).
- * FULL=true: every sample outside the active rectangle gets skeleton-or-zero plus
- * channel noise, i.e. dst is inp[] of a field that started from a clean analog[]. */
-template <class S, bool FULL>
+/* Drop-in (stage-level) path: write exactly the reference's write-set into analog[]; all other
+ * samples keep their contents.  One lane per 16 consecutive samples. */
+template <class S>
 __global__ void __launch_bounds__(256)
 k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
-           const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16, int nes_setup)
+           const crthip_state *__restrict__ state, int nes_setup)
 {
     constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -187,29 +193,15 @@ k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, s
     signed char *out = dst + (size_t) f * fstride;
 
     /* chunks entirely inside the active rectangle belong to k_active */
-    {
-        int t1 = t + 15;   /* may spill into the next line; then not "entirely inside" */
-        if (t >= P.xo && t1 < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth) return;
-    }
-    unsigned rn = 0;
-    if (FULL) {
-        uint2 j = jump16[q];
-        rn = j.x * (unsigned) st.rn + j.y;
-    }
+    if (t >= P.xo && t + 15 < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth) return;
     int vals[16];
     unsigned wmask = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         int v = 0;
-        bool in_field = idx0 + k < S::INPUT_SIZE;
-        bool active = t >= P.xo && t < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth;
-        bool wr = skeleton<S>(P, line, t, field, inv_phase, st.aux, nes_setup != 0, v);
-        if (FULL) {
-            rn = lcg_step(rn);
-            if (!wr) v = 0;
-            v = noisy(v, rn, P.noise);
-            wr = true;
-        }
+        const bool in_field = idx0 + k < S::INPUT_SIZE;
+        const bool active = t >= P.xo && t < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth;
+        const bool wr = skeleton<S>(P, line, t, field, inv_phase, st.aux, nes_setup != 0, v);
         if (wr && !active && in_field) wmask |= 1u << k;
         vals[k] = v;
         if (++t == S::HRES) { t = 0; line++; }
@@ -227,32 +219,20 @@ k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, s
             if (wmask >> k & 1u) out[idx0 + k] = (signed char) vals[k];
         }
     }
-    if (FULL && q == 0) {
-        /* mirror of the struct members behind inp[] (see CRTHIP_TAIL) */
-        signed char *tail = out + S::INPUT_SIZE;     /* INPUT_SIZE % 4 != 0 for NES pattern 2 */
-        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
-    }
 }
 
 /* ------------------------------------------------------------------------- */
 /* M5: active video, one lane per destination row                              */
 /* ------------------------------------------------------------------------- */
-/* 0x00RRGGBB from the 6 byte orders, crt_ntsc.c:278-305 */
-__device__ __forceinline__ void fetch_rgb(const unsigned char *p, int format, int bpp, int &r, int &g, int &b)
+/* v_perm_b32 selector turning a loaded pixel (bytes in memory order, 3-byte formats zero-extended)
+ * into 0x??RRGGBB for the 6 byte orders of crt_ntsc.c:278-305 */
+__device__ __forceinline__ unsigned input_selector(int format)
 {
-    unsigned w;
-    if (bpp == 4) {
-        w = (unsigned) load4u(p);
-    } else {
-        w = (unsigned) p[0] | (unsigned) p[1] << 8 | (unsigned) p[2] << 16;
-    }
-    int b0 = w & 255, b1 = (w >> 8) & 255, b2 = (w >> 16) & 255, b3 = w >> 24;
     switch (format) {
-    case CRTHIP_FMT_RGB: case CRTHIP_FMT_RGBA: r = b0; g = b1; b = b2; break;
-    case CRTHIP_FMT_BGR: case CRTHIP_FMT_BGRA: r = b2; g = b1; b = b0; break;
-    case CRTHIP_FMT_ARGB: r = b1; g = b2; b = b3; break;
-    case CRTHIP_FMT_ABGR: r = b3; g = b2; b = b1; break;
-    default: r = g = b = 0; break;
+    case CRTHIP_FMT_BGR: case CRTHIP_FMT_BGRA: return 0x03020100u;
+    case CRTHIP_FMT_RGB: case CRTHIP_FMT_RGBA: return 0x03000102u;
+    case CRTHIP_FMT_ARGB: return 0x00010203u;
+    default /* ABGR */:   return 0x00030201u;
     }
 }
 
@@ -281,7 +261,10 @@ __device__ __forceinline__ int ppu_level(int p, int phase)
     return v;
 }
 
-template <class S, bool NOISE>
+/* FAST: 24-bit multiplies (always in range for the IIRs and the carrier products: 8-bit pixels
+ * bound every state; `white` and `noise` are range-checked on the host).  IN4: 4-byte input pixels,
+ * fetched 4 at a time with one 16-byte load per lane. */
+template <class S, bool NOISE, bool FAST, bool IN4>
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
@@ -346,32 +329,59 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         const int field_offset = (field * P.h + P.desth) / P.desth / 2;
         int sy = (y * P.h) / P.desth + field_offset;
         if (sy >= P.h) sy = P.h;                             /* (sic) crt_ntsc.c:263 */
-        const unsigned char *row = img + (size_t) sy * w * P.in_bpp;
+        const unsigned char *row = img + (size_t) sy * w * (IN4 ? 4 : 3);
         /* (h * ph) * cc == h * (ph * cc) in wrapping arithmetic; xo is a multiple of 4 (crt_ntsc.c:203)
          * so the carrier phase (x + xo) % 4 is x & 3 */
         const int cI0 = ph * P.modI[0], cI1 = ph * P.modI[1], cI2 = ph * P.modI[2], cI3 = ph * P.modI[3];
         const int cQ0 = ph * P.modQ[0], cQ1 = ph * P.modQ[1], cQ2 = ph * P.modQ[2], cQ3 = ph * P.modQ[3];
         const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
+        const unsigned isel = input_selector(P.format);
+        const int white = P.white, ire_base = P.ire_base, noise = P.noise;
         int hy = 0, hi = 0, hq = 0;
+        /* IN4: the row is consumed in 16-byte chunks of 4 pixels; `have` = chunk in `cur`, `nxt` = chunk have+1 */
+        const int last_chunk = (w - 1) >> 2;
+        int have = 0;
+        v4i cur = { 0, 0, 0, 0 }, nxt = { 0, 0, 0, 0 };
+        if (IN4) {
+            cur = load16u(row);
+            nxt = load16u(row + 16 * (last_chunk > 0 ? 1 : 0));
+        }
         for (int g = 0; g < ngroups; g++) {
             unsigned pack = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = 4 * g + k;
                 if (x < destw) {
-                    int r, gg, b;
-                    fetch_rgb(row + (size_t) col * P.in_bpp, P.format, P.in_bpp, r, gg, b);
+                    unsigned pixel;
+                    if (IN4) {
+                        const int need = col >> 2;                 /* wave-uniform */
+                        if (need != have) {
+                            if (need == have + 1) cur = nxt; else cur = load16u(row + 16 * (size_t) need);
+                            have = need;
+                            nxt = load16u(row + 16 * (size_t) (need < last_chunk ? need + 1 : last_chunk));
+                        }
+                        const int sub = col & 3;
+                        pixel = (unsigned) (sub == 0 ? cur.x : sub == 1 ? cur.y : sub == 2 ? cur.z : cur.w);
+                    } else {
+                        const unsigned char *p = row + (size_t) col * 3;
+                        pixel = (unsigned) p[0] | (unsigned) p[1] << 8 | (unsigned) p[2] << 16;
+                    }
+                    const unsigned rgb = __builtin_amdgcn_perm(pixel, pixel, isel);
+                    const int r = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, b = rgb & 255;
                     const int fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
                     const int fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
                     const int fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
-                    hy += ((fy - hy) * cy_) >> 11;               /* iirf, crt_ntsc.c:117-126 */
-                    hi += ((fi - hi) * ci_) >> 11;
-                    hq += ((fq - hq) * cq_) >> 11;
-                    const int mi = hi * (k == 0 ? cI0 : k == 1 ? cI1 : k == 2 ? cI2 : cI3) >> 4;
-                    const int mq = hq * (k == 0 ? cQ0 : k == 1 ? cQ1 : k == 2 ? cQ2 : cQ3) >> 4;
-                    int ire = P.ire_base + ((hy + mi + mq) * P.white >> 10);
+                    hy += mulq<FAST>(fy - hy, cy_) >> 11;           /* iirf, crt_ntsc.c:117-126 */
+                    hi += mulq<FAST>(fi - hi, ci_) >> 11;
+                    hq += mulq<FAST>(fq - hq, cq_) >> 11;
+                    const int mi = mulq<FAST>(hi, k == 0 ? cI0 : k == 1 ? cI1 : k == 2 ? cI2 : cI3) >> 4;
+                    const int mq = mulq<FAST>(hq, k == 0 ? cQ0 : k == 1 ? cQ1 : k == 2 ? cQ2 : cQ3) >> 4;
+                    int ire = ire_base + (mulq<FAST>(hy + mi + mq, white) >> 10);
                     ire = clampi(ire, 0, 110);
-                    if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                    if (NOISE) {
+                        rn = lcg_step(rn);
+                        ire = clampi(ire + (mulq<FAST>((int) ((rn >> 16) & 0xffu) - 0x7f, noise) >> 8), -127, 127);
+                    }
                     pack |= (unsigned) (ire & 255) << (8 * k);
                     col += qstep; err += rstep;
                     if (err >= destw) { err -= destw; col++; }
@@ -383,6 +393,77 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                 for (int k = 4 * g; k < destw; k++) { out[k] = (signed char) (pack & 255); pack >>= 8; }
             }
         }
+    }
+}
+
+/* Fused path only: everything OUTSIDE the active rectangle of a field that started from a clean
+ * analog[] -- skeleton value (or 0) plus channel noise, written straight into inp[].  The complement
+ * of the rectangle in flat sample order is
+ *     head   [0, S0)                                   S0 = yo*HRES + xo
+ *     gap y  [S0 + y*HRES + destw, S0 + (y+1)*HRES)    y = 0 .. desth-2
+ *     tail   [S0 + (desth-1)*HRES + destw, INPUT_SIZE)
+ * and each lane takes one run of up to 16 samples of it. */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
+         const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16,
+         int head_chunks, int gap_chunks, int tail_chunks)
+{
+    const int per_field = head_chunks + (P.desth - 1) * gap_chunks + tail_chunks;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_fields * per_field) return;
+    const int f = gid / per_field;
+    int q = gid - f * per_field;
+    const int s0 = P.yo * S::HRES + P.xo;
+    const int gap_len = S::HRES - P.destw;
+    int idx0, len;
+    if (q < head_chunks) {
+        idx0 = q * 16;
+        len = s0 - idx0;
+    } else if (q < head_chunks + (P.desth - 1) * gap_chunks) {
+        q -= head_chunks;
+        const int yy = q / gap_chunks, c = q - yy * gap_chunks;
+        idx0 = s0 + yy * S::HRES + P.destw + c * 16;
+        len = gap_len - c * 16;
+    } else {
+        q -= head_chunks + (P.desth - 1) * gap_chunks;
+        idx0 = s0 + (P.desth - 1) * S::HRES + P.destw + q * 16;
+        len = S::INPUT_SIZE - idx0;
+    }
+    if (len > 16) len = 16;
+    const crthip_state st = state[f];
+    const int field = st.field & 1;
+    const int inv_phase = (field == (st.frame & 1));
+    int line = idx0 / S::HRES;
+    int t = idx0 - line * S::HRES;
+    signed char *out = dst + (size_t) f * fstride;
+    unsigned rn = lcg_at(jump16, (unsigned) st.rn, idx0);
+    int vals[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int v = 0;
+        if (!skeleton<S>(P, line, t, field, inv_phase, st.aux, true, v)) v = 0;
+        rn = lcg_step(rn);
+        vals[k] = noisy(v, rn, P.noise);
+        if (++t == S::HRES) { t = 0; line++; }
+    }
+    if (len == 16) {
+        v4i pk;
+        pk.x = (vals[0] & 255) | (vals[1] & 255) << 8 | (vals[2] & 255) << 16 | vals[3] << 24;
+        pk.y = (vals[4] & 255) | (vals[5] & 255) << 8 | (vals[6] & 255) << 16 | vals[7] << 24;
+        pk.z = (vals[8] & 255) | (vals[9] & 255) << 8 | (vals[10] & 255) << 16 | vals[11] << 24;
+        pk.w = (vals[12] & 255) | (vals[13] & 255) << 8 | (vals[14] & 255) << 16 | vals[15] << 24;
+        store16u(out + idx0, pk);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < len) out[idx0 + k] = (signed char) vals[k];
+        }
+    }
+    if (gid - f * per_field == 0) {
+        /* mirror of the struct members behind inp[] (see CRTHIP_TAIL) */
+        signed char *tail = out + S::INPUT_SIZE;
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
     }
 }
 
@@ -557,7 +638,10 @@ k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp,
             lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
             lp.beg = beg;
             int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
-            lp.nrows = nrows < 1 ? 1 : nrows;
+            nrows = nrows < 1 ? 1 : nrows;
+            /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
+            if (lp.wave0 > 524288 || lp.wave0 < -524288 || lp.wave1 > 524288 || lp.wave1 < -524288) nrows |= 0x40000000;
+            lp.nrows = nrows;
             lp.hsync = hsync;
             lines[(size_t) f * S::LINES + (line - S::TOP)] = lp;
         }
@@ -577,55 +661,63 @@ k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp,
 /* ------------------------------------------------------------------------- */
 /* D8-D10: equalisers + resample + YIQ->RGB, one lane per CRT line              */
 /* ------------------------------------------------------------------------- */
+/*
+ * Multiplies.  The reference multiplies 32x32->32 with wrap-around.  gfx950's
+ * v_mul_lo_u32 does exactly that but runs at quarter rate; v_mul_i32_i24 /
+ * v_mad_i32_i24 run at full rate and return the low 32 bits of the 48-bit product
+ * of the operands' low 24 bits (sign-extended) -- identical to the wrapped 32-bit
+ * product WHENEVER both operands are within [-2^23, 2^23).  FAST=true uses them and
+ * is only dispatched when that range is proven (see fast_path_ok() below and
+ * DESIGN.md "24-bit multiply envelope"); lines outside the envelope are flagged by
+ * k_sync (CRTHIP_LINE_EXACT) and re-run by the FAST=false instantiation.
+ */
+#define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows */
+#define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast path, 2^19 */
+#define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast path        */
+
 struct Eq3 { int lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3, h0, h1, h2; };
 
-/* eqf, crt_core.c:206-233; G0 is always 65536 (crt_core.c:278-280) */
-template <int G1, int G2>
+/* eqf, crt_core.c:206-233.  Band gains are the compile-time constants of crt_core.c:278-280
+ * (G0 is always 65536: (x * 65536) >> 16 wraps to the sign-extended low half of x). */
+template <bool FAST, int G1, int G2>
 __device__ __forceinline__ int eq_step(Eq3 &f, const int lf, const int hf, const int s)
 {
-    f.lo0 += (lf * (s - f.lo0) + 32768) >> 16;
-    f.hi0 += (hf * (s - f.hi0) + 32768) >> 16;
-    f.lo1 += (lf * (f.lo0 - f.lo1) + 32768) >> 16;
-    f.hi1 += (hf * (f.hi0 - f.hi1) + 32768) >> 16;
-    f.lo2 += (lf * (f.lo1 - f.lo2) + 32768) >> 16;
-    f.hi2 += (hf * (f.hi1 - f.hi2) + 32768) >> 16;
-    f.lo3 += (lf * (f.lo2 - f.lo3) + 32768) >> 16;
-    f.hi3 += (hf * (f.hi2 - f.hi3) + 32768) >> 16;
+    f.lo0 += (mulq<FAST>(lf, s - f.lo0) + 32768) >> 16;
+    f.hi0 += (mulq<FAST>(hf, s - f.hi0) + 32768) >> 16;
+    f.lo1 += (mulq<FAST>(lf, f.lo0 - f.lo1) + 32768) >> 16;
+    f.hi1 += (mulq<FAST>(hf, f.hi0 - f.hi1) + 32768) >> 16;
+    f.lo2 += (mulq<FAST>(lf, f.lo1 - f.lo2) + 32768) >> 16;
+    f.hi2 += (mulq<FAST>(hf, f.hi1 - f.hi2) + 32768) >> 16;
+    f.lo3 += (mulq<FAST>(lf, f.lo2 - f.lo3) + 32768) >> 16;
+    f.hi3 += (mulq<FAST>(hf, f.hi2 - f.hi3) + 32768) >> 16;
     int r = (f.lo3 * 65536) >> 16;
-    r += ((f.hi3 - f.lo3) * G1) >> 16;
+    if (G1 == 65536 || G1 == 8192) r += ((f.hi3 - f.lo3) * G1) >> 16;      /* shifts / bit-field extract */
+    else r += mulq<FAST>(f.hi3 - f.lo3, G1) >> 16;
     if (G2 != 0) {
-        r += ((f.h2 - f.hi3) * G2) >> 16;
+        r += mulq<FAST>(f.h2 - f.hi3, G2) >> 16;
         f.h2 = f.h1; f.h1 = f.h0; f.h0 = s;
     }
     return r;
 }
 
-/* pack 0x00RRGGBB into the little-endian dword of a 4-byte output format, crt_core.c:613-656 */
-__device__ __forceinline__ unsigned pack_px4(int rgb, int format)
+/* byte selectors for v_perm_b32: 0xffRRGGBB (bytes B,G,R,ff) <-> the four 4-byte output formats,
+ * crt_core.c:587-656 */
+__device__ __forceinline__ unsigned pack_selector(int format)
 {
-    const unsigned u = (unsigned) rgb;
-    switch (format) {
-    case CRTHIP_FMT_BGRA: return 0xff000000u | u;
-    case CRTHIP_FMT_RGBA: return 0xff000000u | (u & 0xff00u) | (u >> 16 & 0xffu) | (u & 0xffu) << 16;
-    case CRTHIP_FMT_ARGB: return 0xffu | (u >> 16 & 0xffu) << 8 | (u >> 8 & 0xffu) << 16 | (u & 0xffu) << 24;
-    default /* ABGR */:   return 0xffu | u << 8;
-    }
+    return format == CRTHIP_FMT_BGRA ? 0x03020100u : format == CRTHIP_FMT_RGBA ? 0x03000102u
+         : format == CRTHIP_FMT_ARGB ? 0x00010203u : 0x02010003u /* ABGR */;
 }
-/* inverse, for blend (crt_core.c:587-605) */
-__device__ __forceinline__ int unpack_px4(unsigned d, int format)
+__device__ __forceinline__ unsigned unpack_selector(int format)
 {
-    switch (format) {
-    case CRTHIP_FMT_BGRA: return (int) (d & 0xffffffu);
-    case CRTHIP_FMT_RGBA: return (int) ((d & 0xffu) << 16 | (d & 0xff00u) | (d >> 16 & 0xffu));
-    case CRTHIP_FMT_ARGB: return (int) ((d >> 8 & 0xffu) << 16 | (d >> 16 & 0xffu) << 8 | d >> 24);
-    default /* ABGR */:   return (int) (d >> 8);
-    }
+    return format == CRTHIP_FMT_BGRA ? 0x03020100u : format == CRTHIP_FMT_RGBA ? 0x03000102u
+         : format == CRTHIP_FMT_ARGB ? 0x00010203u : 0x00030201u /* ABGR */;
 }
 
-template <class S>
+/* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line */
+template <class S, bool FAST, bool BPP3>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride)
+         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int want_exact)
 {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const bool live = gid < n_fields * S::LINES;
@@ -633,16 +725,22 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
     const int f = live ? gid / S::LINES : 0;
     if (live) lp = lines[gid];
-    const bool act = live && lp.nrows > 0;
-    const signed char *sig = inp + (size_t) f * fstride + lp.pos;
-    const int bpp = P.out_bpp;
+    const int exact = (lp.nrows & CRTHIP_LINE_EXACT) ? 1 : 0;
+    int nrows = lp.nrows & ~CRTHIP_LINE_EXACT;
+    if (!live || (want_exact >= 0 && exact != want_exact)) nrows = 0;
+    if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
+    const bool act = nrows > 0;
+    const signed char *sig = inp + (size_t) f * fstride + (act ? lp.pos : 0);
+    constexpr int bpp = BPP3 ? 3 : 4;
     const size_t pitch = (size_t) P.outw * bpp;
     unsigned char *orow = outp + (size_t) f * ostride + (size_t) lp.beg * pitch;
-    const int nrows = act ? lp.nrows : 0;
 
     const int w0 = lp.wave0, w1 = lp.wave1, nw0 = -lp.wave0, nw1 = -lp.wave1;
     const int bright = P.bright, contrast = P.contrast;
     const int ylf = P.eq_lf[0], yhf = P.eq_hf[0], ilf = P.eq_lf[1], ihf = P.eq_hf[1], qlf = P.eq_lf[2], qhf = P.eq_hf[2];
+    const unsigned psel = pack_selector(P.out_format), usel = unpack_selector(P.out_format);
+    const bool rgb_order = P.out_format == CRTHIP_FMT_RGB;
+    const bool blend = P.blend != 0;
     Eq3 ey = {}, ei = {}, eq = {};
     int py = 0, pi = 0, pq = 0;                    /* yiq of the previous sample */
 
@@ -654,11 +752,17 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const int outw = P.outw;
     unsigned pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;   /* finished pixels awaiting a 16-byte store */
 
-    constexpr int NQ = (S::AV_LEN + 3) / 4;        /* dwords per line window (last one partly beyond AV_LEN:
-                                                      the filters are causal, the extra samples feed nothing) */
-    int word = load4u(sig);
+    /* the line window is consumed 16 bytes per load, 4 samples per loop trip; the last trips run
+     * past AV_LEN: the filters are causal, the extra samples feed nothing */
+    constexpr int NQ = (S::AV_LEN + 3) / 4;
+    v4i cur = load16u(sig), nxt = cur;
     for (int xq = 0; xq < NQ; xq++) {
-        const int nextword = load4u(sig + 4 * (xq + 1 < NQ ? xq + 1 : xq));
+        const int sub = xq & 3;                    /* wave-uniform */
+        if (sub == 0) {
+            if (xq) cur = nxt;
+            nxt = load16u(sig + 4 * (xq + 4));     /* prefetch; stays inside the per-field slack */
+        }
+        const int word = sub == 0 ? cur.x : sub == 1 ? cur.y : sub == 2 ? cur.z : cur.w;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = xq * 4 + k;
@@ -666,27 +770,29 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
             /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
             const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
             const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
-            const int cy = eq_step<8192, 9175>(ey, ylf, yhf, s + bright) << 4;
-            const int ci = eq_step<65536, 1311>(ei, ilf, ihf, s * wi >> 9) >> 3;
-            const int cq = eq_step<65536, 0>(eq, qlf, qhf, s * wq >> 9) >> 3;
+            const int cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
+            const int ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
+            const int cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
             /* D9: every output pixel whose left tap is sample x-1 is now computable */
             while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
                 const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
-                const int yy = ((py * L) >> 2) + ((cy * R) >> 2);
-                const int ii = ((pi * L) >> 14) + ((ci * R) >> 14);
-                const int qq = ((pq * L) >> 14) + ((cq * R) >> 14);
-                int r = (((yy + 3879 * ii + 2556 * qq) >> 12) * contrast) >> 8;
-                int g = (((yy - 1126 * ii - 2605 * qq) >> 12) * contrast) >> 8;
-                int b = (((yy - 4530 * ii + 7021 * qq) >> 12) * contrast) >> 8;
+                const int yy = (mulq<FAST>(py, L) >> 2) + (mulq<FAST>(cy, R) >> 2);
+                const int ii = (mulq<FAST>(pi, L) >> 14) + (mulq<FAST>(ci, R) >> 14);
+                const int qq = (mulq<FAST>(pq, L) >> 14) + (mulq<FAST>(cq, R) >> 14);
+                int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
+                int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
+                int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
                 r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
                 int rgb = r << 16 | g << 8 | b;
-                if (bpp == 4) {
-                    if (P.blend && act) {
-                        const int old = unpack_px4(*(const unsigned *) (orow + (size_t) px * 4), P.out_format);
+                if (!BPP3) {
+                    if (blend && act) {
+                        const unsigned oldw = *(const unsigned *) (orow + (size_t) px * 4);
+                        const int old = (int) __builtin_amdgcn_perm(oldw, oldw, usel);
                         rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
                     }
                     {
-                        const unsigned pk = pack_px4(rgb, P.out_format);
+                        const unsigned full = 0xff000000u | (unsigned) rgb;
+                        const unsigned pk = __builtin_amdgcn_perm(full, full, psel);
                         const int slot = px & 3;                      /* wave-uniform */
                         if (slot == 0) pend0 = pk; else if (slot == 1) pend1 = pk; else if (slot == 2) pend2 = pk; else pend3 = pk;
                     }
@@ -707,13 +813,12 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     }
                 } else {
                     unsigned char *d0 = orow + (size_t) px * 3;
-                    if (P.blend && act) {
-                        const int old = P.out_format == CRTHIP_FMT_RGB ? (d0[0] << 16 | d0[1] << 8 | d0[2])
-                                                                       : (d0[2] << 16 | d0[1] << 8 | d0[0]);
+                    if (blend && act) {
+                        const int old = rgb_order ? (d0[0] << 16 | d0[1] << 8 | d0[2]) : (d0[2] << 16 | d0[1] << 8 | d0[0]);
                         rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
                     }
-                    const unsigned char c0 = (unsigned char) (P.out_format == CRTHIP_FMT_RGB ? rgb >> 16 : rgb);
-                    const unsigned char c2 = (unsigned char) (P.out_format == CRTHIP_FMT_RGB ? rgb : rgb >> 16);
+                    const unsigned char c0 = (unsigned char) (rgb_order ? rgb >> 16 : rgb);
+                    const unsigned char c2 = (unsigned char) (rgb_order ? rgb : rgb >> 16);
                     for (int rr = 0; rr < nrows; rr++) {
                         unsigned char *d = d0 + (size_t) rr * pitch;
                         d[0] = c0; d[1] = (unsigned char) (rgb >> 8); d[2] = c2;
@@ -724,7 +829,6 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
             }
             py = cy; pi = ci; pq = cq;
         }
-        word = nextword;
     }
 }
 
@@ -745,6 +849,7 @@ struct crthip_ctx {
     signed char *d_analog, *d_inp;
     crthip_line *d_lines;
     /* profiling */
+    bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
     bool prof;
     double prof_ms[CRTHIP_K_COUNT];
     int prof_n[CRTHIP_K_COUNT];
@@ -819,23 +924,51 @@ struct ProfScope {
     }
 };
 
+static bool encoder_fast_ok(const crthip_params *p)
+{
+    const int wh = p->white < 0 ? -p->white : p->white;
+    const int nz = p->noise < 0 ? -p->noise : p->noise;
+    return wh < (1 << 23) && nz < (1 << 23);
+}
+
+template <class S, bool FULL, bool FAST>
+static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                          signed char *dst, const crthip_state *d_state)
+{
+    ProfScope ps(c, CRTHIP_K_ACTIVE);
+    const int total = n * p->desth;
+    const dim3 grid((total + 63) / 64), block(64);
+    const unsigned char *img = (const unsigned char *) d_images;
+    if (S::IS_NES || p->in_bpp == 4)
+        hipLaunchKernelGGL((k_active<S, FULL, FAST, true>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16);
+    else
+        hipLaunchKernelGGL((k_active<S, FULL, FAST, false>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16);
+}
+
 template <class S, bool FULL>
 static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                           signed char *dst, const crthip_state *d_state, int nes_setup)
 {
-    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
-    {
+    if (FULL) {
+        /* fused path: skeleton + noise for everything outside the active rectangle */
+        ProfScope ps(c, CRTHIP_K_TEMPLATE);
+        const int s0 = p->yo * S::HRES + p->xo;
+        const int head = (s0 + 15) / 16;
+        const int gap = (S::HRES - p->destw + 15) / 16;
+        const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
+        const int tail = (tail_len + 15) / 16;
+        const int total = n * (head + (p->desth - 1) * gap + tail);
+        hipLaunchKernelGGL((k_margin<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, c->d_jump16, head, gap, tail);
+    } else {
+        constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
         ProfScope ps(c, CRTHIP_K_TEMPLATE);
         const int total = n * CHUNKS;
-        hipLaunchKernelGGL((k_template<S, FULL>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                           *p, n, dst, c->fstride, d_state, c->d_jump16, nes_setup);
+        hipLaunchKernelGGL((k_template<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, nes_setup);
     }
-    {
-        ProfScope ps(c, CRTHIP_K_ACTIVE);
-        const int total = n * p->desth;
-        hipLaunchKernelGGL((k_active<S, FULL>), dim3((total + 63) / 64), dim3(64), 0, c->stream,
-                           *p, n, (const unsigned char *) d_images, istride, dst, c->fstride, d_state, c->d_jump16);
-    }
+    if (encoder_fast_ok(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
+    else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state);
     return CRTHIP_OK;
 }
 
@@ -1069,15 +1202,43 @@ int crthip_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char 
     return rc;
 }
 
+/* host half of the 24-bit-multiply envelope: with |s+bright| <= 2^17 and |wave| <= 2^19
+ * every multiply operand of the decoder stays inside [-2^23, 2^23) */
+static bool fast_path_ok(const crthip_params *p)
+{
+    const int b = p->bright < 0 ? -p->bright : p->bright;
+    const int c = p->contrast < 0 ? -p->contrast : p->contrast;
+    return b <= FAST_BRIGHT_MAX && c < (1 << 23);
+}
+
 static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                          const crthip_line *d_lines, void *d_out, size_t ostride)
 {
+    const bool fast = fast_path_ok(p) && !c->force_exact;
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
-        ProfScope ps(c, CRTHIP_K_DECODE);
         const int total = n * S::LINES;
-        hipLaunchKernelGGL((k_decode<S>), dim3((total + 63) / 64), dim3(64), 0, c->stream,
-                           *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride);
+        const dim3 grid((total + 63) / 64), block(64);
+        unsigned char *o = (unsigned char *) d_out;
+        if (p->out_bpp == 3) {
+            if (fast) {
+                { ProfScope ps(c, CRTHIP_K_DECODE);
+                  hipLaunchKernelGGL((k_decode<S, true, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 0); }
+                hipLaunchKernelGGL((k_decode<S, false, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 1);
+            } else {
+                ProfScope ps(c, CRTHIP_K_DECODE);
+                hipLaunchKernelGGL((k_decode<S, false, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, -1);
+            }
+        } else {
+            if (fast) {
+                { ProfScope ps(c, CRTHIP_K_DECODE);
+                  hipLaunchKernelGGL((k_decode<S, true, false>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 0); }
+                hipLaunchKernelGGL((k_decode<S, false, false>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 1);
+            } else {
+                ProfScope ps(c, CRTHIP_K_DECODE);
+                hipLaunchKernelGGL((k_decode<S, false, false>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, -1);
+            }
+        }
         return CRTHIP_OK;
     });
 }
@@ -1134,6 +1295,13 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         if (rc) return rc;
     }
     HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_exact(crthip_ctx *c, int on)
+{
+    if (!c) return CRTHIP_E_ARG;
+    c->force_exact = on != 0;
     return CRTHIP_OK;
 }
 

@@ -59,16 +59,22 @@ CASES = [
     ("ntsc", 500, 300, R.FMT_BGR, 200, 100, R.FMT_ARGB, 60, dict(as_color=1, raw=1), dict(black_point=3, white_point=90)),
     ("ntsc", 333, 481, R.FMT_RGB, 100, 300, R.FMT_RGB, 100, dict(as_color=1, raw=1, xoffset=8, yoffset=2), dict(v_fac=10)),
     ("ntsc", 257, 243, R.FMT_BGRA, 800, 600, R.FMT_BGRA, 24, dict(as_color=1, hue=180), dict(scanlines=1, blend=1)),
+    # outside the 24-bit multiply envelope: huge saturation (lines flagged CRTHIP_LINE_EXACT by k_sync) ...
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1), dict(saturation=900, contrast=300)),
+    # ... and huge brightness / contrast / white point (host-side check picks the exact kernels)
+    ("ntsc", 640, 480, R.FMT_RGBA, 640, 480, R.FMT_RGBA, 10, dict(as_color=1), dict(brightness=200000, contrast=9000000, white_point=9000000)),
+    ("ntsc", 320, 240, R.FMT_BGRA, 320, 240, R.FMT_BGRA, 50000000, dict(as_color=1), dict(saturation=-70)),
 ]
 
 
-def _run_case(crtlib, case, fused, steps=4, n=3):
+def _run_case(crtlib, case, fused, steps=4, n=3, exact=False):
     name, outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = case
     bpp = R.bpp4fmt(ifmt)
     imgs = np.stack([R.synth_image(w, h, bpp, 777 + 13 * k, "random" if k % 2 == 0 else "bars") for k in range(n)])
     dimgs = _padded(imgs)
     orc, ocrts = _oracle_batch(name, n, outw, outh, ofmt, knobs)
     g = crtlib.CRT(n, outw, outh, ofmt, name, device=0)
+    g.set_exact(exact)
     for k, v in knobs.items():
         setattr(g, k, v)
     fields = [k & 1 for k in range(n)]
@@ -129,6 +135,12 @@ def test_stagewise_parity(crtlib, case):
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_fused_fieldpass_parity(crtlib, case):
     _run_case(crtlib, CASES[case], fused=True)
+
+
+@pytest.mark.parametrize("case", [1, 2, 3, 5])
+def test_exact_kernels_parity(crtlib, case):
+    """the 32-bit-multiply instantiations on ordinary inputs (normally only the fast ones run there)"""
+    _run_case(crtlib, CASES[case], fused=True, exact=True, steps=2)
 
 
 def test_smoke_entry():
