@@ -97,6 +97,19 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) unaligned16 { v4i v; };
 struct __attribute__((packed)) unaligned4 { int v; };
 
+/* The same through an explicit global (address space 1) pointer: addresses that went through LDS
+ * as integers would otherwise be treated as generic ("flat") and unaligned 16-byte accesses to them
+ * get split into dwords, because flat could mean LDS, where misaligned wide accesses are illegal. */
+typedef __attribute__((address_space(1))) unaligned16 g_unaligned16;
+typedef __attribute__((address_space(1))) unsigned g_u32;
+typedef __attribute__((address_space(1))) unsigned char g_u8;
+__device__ __forceinline__ v4i gload16u(unsigned long long a) { return ((const g_unaligned16 *) a)->v; }
+__device__ __forceinline__ void gstore16u(unsigned long long a, v4i v) { ((g_unaligned16 *) a)->v = v; }
+__device__ __forceinline__ unsigned gload32(unsigned long long a) { return *(const g_u32 *) a; }
+__device__ __forceinline__ void gstore32(unsigned long long a, unsigned v) { *(g_u32 *) a = v; }
+__device__ __forceinline__ unsigned gload8(unsigned long long a) { return *(const g_u8 *) a; }
+__device__ __forceinline__ void gstore8(unsigned long long a, unsigned v) { *(g_u8 *) a = (unsigned char) v; }
+
 __device__ __forceinline__ v4i load16u(const void *p) { return ((const unaligned16 *) p)->v; }
 __device__ __forceinline__ void store16u(void *p, v4i v) { ((unaligned16 *) p)->v = v; }
 __device__ __forceinline__ int load4u(const void *p) { return ((const unaligned4 *) p)->v; }
@@ -262,23 +275,32 @@ __device__ __forceinline__ int ppu_level(int p, int phase)
 }
 
 /* FAST: 24-bit multiplies (always in range for the IIRs and the carrier products: 8-bit pixels
- * bound every state; `white` and `noise` are range-checked on the host).  IN4: 4-byte input pixels,
- * fetched 4 at a time with one 16-byte load per lane. */
+ * bound every state; `white` and `noise` are range-checked on the host).
+ * IN4: 4-byte input pixels moved through a cooperative LDS tile (see the comment above k_decode);
+ * otherwise (3-byte formats, tiny images) each lane reads its own pixels bytewise.
+ * The produced samples always leave through a cooperative LDS tile. */
+#define AC_TILE    32                     /* dwords per row and tile: 32 pixels in, 128 samples out */
+#define AC_STRIDE  (AC_TILE + 1)
+
 template <class S, bool NOISE, bool FAST, bool IN4>
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
          const uint2 *__restrict__ jump16)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    __shared__ unsigned s_pix[64 * AC_STRIDE];
+    __shared__ unsigned s_out[64 * AC_STRIDE];
+    __shared__ unsigned long long s_src[64], s_dst[64];
+
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
     const int rows = P.desth;
-    if (gid >= n_fields * rows) return;
-    const int f = gid / rows;
-    const int y = gid - f * rows;
+    const bool live = gid < n_fields * rows;
+    const int f = live ? gid / rows : 0;
+    const int y = live ? gid - f * rows : 0;
     const crthip_state st = state[f];
     const unsigned char *img = images + (size_t) f * istride;
     const int start = (y + P.yo) * S::HRES + P.xo;
-    signed char *out = dst + (size_t) f * fstride + start;
     unsigned rn = 0;
     if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, start);
 
@@ -287,12 +309,54 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     int col = 0, err = 0;                                     /* wave-uniform */
     const int ngroups = (destw + 3) >> 2;
 
+    /* per-row source / destination, published to the whole wave */
+    int sy;
     if constexpr (S::IS_NES) {
-        /* crt_nes.c:162-193 */
-        int sy = (y * P.h) / S::LINES;
+        sy = (y * P.h) / S::LINES;                            /* crt_nes.c:165-168 */
         if (sy >= P.h) sy = P.h;
         if (sy < 0) sy = 0;
-        const unsigned short *row = (const unsigned short *) img + (size_t) sy * w;
+    } else {
+        const int field = st.field & 1;
+        const int field_offset = (field * P.h + P.desth) / P.desth / 2;
+        sy = (y * P.h) / P.desth + field_offset;              /* crt_ntsc.c:258-263 */
+        if (sy >= P.h) sy = P.h;                              /* (sic) */
+    }
+    const int in_bpp = S::IS_NES ? 2 : P.in_bpp;
+    const unsigned char *row = img + (size_t) sy * w * in_bpp;
+    s_src[lane] = (unsigned long long) row;
+    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
+    __syncthreads();
+
+    /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
+    auto drain = [&](int g0, int ng) {
+        __syncthreads();
+        const int orow = lane >> 3, piece = lane & 7;         /* 16 bytes per piece, 8 pieces per row */
+        const int first = (g0 + piece * 4) * 4;               /* first sample of my piece */
+        const int nbytes = destw - first < 16 ? destw - first : 16;
+#pragma unroll 2
+        for (int i = 0; i < 8; i++) {
+            const int r = i * 8 + orow;
+            const unsigned long long d = s_dst[r];
+            if (d != 0 && piece * 4 < ng && nbytes > 0) {
+                const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
+                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+                if (nbytes == 16) {
+                    gstore16u(d + first, o);
+                } else {
+                    const int wds[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    if constexpr (S::IS_NES) {
+        /* crt_nes.c:162-193 */
+        const unsigned short *prow = (const unsigned short *) row;
         int phase = 4 * ((y + P.yo + st.aux) % 3);           /* phasetab {0,4,8} */
         for (int g = 0; g < ngroups; g++) {
             unsigned pack = 0;
@@ -300,7 +364,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
             for (int k = 0; k < 4; k++) {
                 const int x = 4 * g + k;
                 if (x < destw) {
-                    int p = row[col];
+                    int p = prow[col];
                     int ire = S::BLACK + P.black_point;
                     ire += ppu_level(p, phase + 0);
                     ire += ppu_level(p, phase + 1);
@@ -315,21 +379,14 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     if (err >= destw) { err -= destw; col++; }
                 }
             }
-            if (4 * g + 3 < destw) {
-                store4u(out + 4 * g, (int) pack);
-            } else {
-                for (int k = 4 * g; k < destw; k++) { out[k] = (signed char) (pack & 255); pack >>= 8; }
-            }
+            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
+            if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
         }
     } else {
         /* crt_ntsc.c:254-324 */
         const int field = st.field & 1;
         const int inv_phase = (field == (st.frame & 1));
         const int ph = (S::PATTERN == 1 && (inv_phase & 1)) ? -1 : 1;
-        const int field_offset = (field * P.h + P.desth) / P.desth / 2;
-        int sy = (y * P.h) / P.desth + field_offset;
-        if (sy >= P.h) sy = P.h;                             /* (sic) crt_ntsc.c:263 */
-        const unsigned char *row = img + (size_t) sy * w * (IN4 ? 4 : 3);
         /* (h * ph) * cc == h * (ph * cc) in wrapping arithmetic; xo is a multiple of 4 (crt_ntsc.c:203)
          * so the carrier phase (x + xo) % 4 is x & 3 */
         const int cI0 = ph * P.modI[0], cI1 = ph * P.modI[1], cI2 = ph * P.modI[2], cI3 = ph * P.modI[3];
@@ -338,13 +395,44 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         const unsigned isel = input_selector(P.format);
         const int white = P.white, ire_base = P.ire_base, noise = P.noise;
         int hy = 0, hi = 0, hq = 0;
-        /* IN4: the row is consumed in 16-byte chunks of 4 pixels; `have` = chunk in `cur`, `nxt` = chunk have+1 */
-        const int last_chunk = (w - 1) >> 2;
+
+        /* IN4 pixel tiles: 32 pixels (128 bytes) per row; pieces of 16 bytes, 8 per row, 8 rows per
+         * load instruction.  `have` = tile in LDS, `stage[]` = tile have+1 in flight / in registers.
+         * A piece that would run past the row end is moved back to the row's last 16 bytes, so
+         * nothing beyond the image is touched (w >= 4). */
+        const int prow_ = lane >> 3, piece = lane & 7;
+        const int last_tile = (w - 1) >> 5;
+        const int row_bytes = w * 4;
+        v4i stage[8];
+        auto piece_offset = [&](int tile) {
+            int off = tile * 128 + piece * 16;
+            return off > row_bytes - 16 ? row_bytes - 16 : off;
+        };
+        auto fetch = [&](int tile) {
+            const int off = piece_offset(tile);
+#pragma unroll
+            for (int i = 0; i < 8; i++) stage[i] = gload16u(s_src[i * 8 + prow_] + off);
+        };
+        auto stash = [&](int tile) {
+            /* dword index inside the tile where my (possibly moved-back) piece belongs; moved-back
+             * pieces of several lanes overlap and carry identical bytes */
+            const int dw0 = (piece_offset(tile) - tile * 128) >> 2;     /* may be negative for a moved-back piece */
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                unsigned *d = s_pix + (i * 8 + prow_) * AC_STRIDE;
+                if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
+                if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
+                if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
+                if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+            }
+            __syncthreads();
+        };
         int have = 0;
-        v4i cur = { 0, 0, 0, 0 }, nxt = { 0, 0, 0, 0 };
         if (IN4) {
-            cur = load16u(row);
-            nxt = load16u(row + 16 * (last_chunk > 0 ? 1 : 0));
+            fetch(0);
+            stash(0);
+            if (last_tile > 0) fetch(1);
         }
         for (int g = 0; g < ngroups; g++) {
             unsigned pack = 0;
@@ -354,17 +442,18 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                 if (x < destw) {
                     unsigned pixel;
                     if (IN4) {
-                        const int need = col >> 2;                 /* wave-uniform */
+                        const int need = col >> 5;                 /* wave-uniform */
                         if (need != have) {
-                            if (need == have + 1) cur = nxt; else cur = load16u(row + 16 * (size_t) need);
+                            if (need != have + 1) fetch(need);      /* only when w > 32*destw */
+                            stash(need);
                             have = need;
-                            nxt = load16u(row + 16 * (size_t) (need < last_chunk ? need + 1 : last_chunk));
+                            if (need < last_tile) fetch(need + 1);
                         }
-                        const int sub = col & 3;
-                        pixel = (unsigned) (sub == 0 ? cur.x : sub == 1 ? cur.y : sub == 2 ? cur.z : cur.w);
+                        pixel = s_pix[lane * AC_STRIDE + (col & 31)];
                     } else {
-                        const unsigned char *p = row + (size_t) col * 3;
-                        pixel = (unsigned) p[0] | (unsigned) p[1] << 8 | (unsigned) p[2] << 16;
+                        const unsigned char *pp = row + (size_t) col * in_bpp;
+                        pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
+                        if (in_bpp == 4) pixel |= (unsigned) pp[3] << 24;
                     }
                     const unsigned rgb = __builtin_amdgcn_perm(pixel, pixel, isel);
                     const int r = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, b = rgb & 255;
@@ -387,11 +476,8 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     if (err >= destw) { err -= destw; col++; }
                 }
             }
-            if (4 * g + 3 < destw) {
-                store4u(out + 4 * g, (int) pack);
-            } else {
-                for (int k = 4 * g; k < destw; k++) { out[k] = (signed char) (pack & 255); pack >>= 8; }
-            }
+            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
+            if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
         }
     }
 }
@@ -713,13 +799,34 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
          : format == CRTHIP_FMT_ARGB ? 0x00010203u : 0x00030201u /* ABGR */;
 }
 
+/*
+ * Global memory traffic of the lane-per-line kernels.  A lane walks along its own scanline, so a
+ * wave's 64 lanes touch 64 different rows: per-lane loads/stores would move 16 bytes out of every
+ * 128-byte line at a time (measured: 3-8x the algorithmic HBM traffic, profiles/r01_v1_*).  Instead
+ * all global I/O goes through LDS tiles [64 rows][TILE] that the wave fills / drains COOPERATIVELY
+ * with row-contiguous 16-byte pieces (8 lanes x 16 B = one 128-byte line of one row per 8 lanes),
+ * while each lane reads / writes only its own row of the tile.  Row stride = TILE+1 dwords, all LDS
+ * accesses are 32-bit: bank = (row + column) % 32, conflict-free for both access directions.
+ * Workgroup = one wave, so __syncthreads() is only an ordering fence between the two phases.
+ */
+#define IN_TILE_DW   16                    /* decoder input tile: 64 samples per row            */
+#define IN_STRIDE    (IN_TILE_DW + 1)
+#define PX_TILE      32                    /* decoder output tile: 32 pixels per row            */
+#define PX_STRIDE    (PX_TILE + 1)
+
 /* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line */
 template <class S, bool FAST, bool BPP3>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int want_exact)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    __shared__ unsigned s_in[64 * IN_STRIDE];
+    __shared__ unsigned s_px[64 * PX_STRIDE];
+    __shared__ unsigned long long s_src[64], s_dst[64];
+    __shared__ int s_nrows[64];
+
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
     const bool live = gid < n_fields * S::LINES;
     crthip_line lp;
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
@@ -730,10 +837,12 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     if (!live || (want_exact >= 0 && exact != want_exact)) nrows = 0;
     if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
     const bool act = nrows > 0;
-    const signed char *sig = inp + (size_t) f * fstride + (act ? lp.pos : 0);
     constexpr int bpp = BPP3 ? 3 : 4;
     const size_t pitch = (size_t) P.outw * bpp;
-    unsigned char *orow = outp + (size_t) f * ostride + (size_t) lp.beg * pitch;
+    s_src[lane] = (unsigned long long) (inp + (size_t) f * fstride + (act ? lp.pos : 0));
+    s_dst[lane] = (unsigned long long) (outp + (size_t) f * ostride + (size_t) (act ? lp.beg : 0) * pitch);
+    s_nrows[lane] = nrows;
+    __syncthreads();
 
     const int w0 = lp.wave0, w1 = lp.wave1, nw0 = -lp.wave0, nw1 = -lp.wave1;
     const int bright = P.bright, contrast = P.contrast;
@@ -750,84 +859,130 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     unsigned ppos = 0;
     int px = 0;
     const int outw = P.outw;
-    unsigned pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;   /* finished pixels awaiting a 16-byte store */
 
-    /* the line window is consumed 16 bytes per load, 4 samples per loop trip; the last trips run
-     * past AV_LEN: the filters are causal, the extra samples feed nothing */
-    constexpr int NQ = (S::AV_LEN + 3) / 4;
-    v4i cur = load16u(sig), nxt = cur;
-    for (int xq = 0; xq < NQ; xq++) {
-        const int sub = xq & 3;                    /* wave-uniform */
-        if (sub == 0) {
-            if (xq) cur = nxt;
-            nxt = load16u(sig + 4 * (xq + 4));     /* prefetch; stays inside the per-field slack */
-        }
-        const int word = sub == 0 ? cur.x : sub == 1 ? cur.y : sub == 2 ? cur.z : cur.w;
+    /* cooperative input tile: piece = 16 bytes, 4 pieces per row, 16 rows per load instruction */
+    const int in_row = lane >> 2, in_piece = lane & 3;
+    v4i stage[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = xq * 4 + k;
-            const int s = (word << (24 - 8 * k)) >> 24;
-            /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
-            const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
-            const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
-            const int cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
-            const int ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
-            const int cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
-            /* D9: every output pixel whose left tap is sample x-1 is now computable */
-            while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
-                const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
-                const int yy = (mulq<FAST>(py, L) >> 2) + (mulq<FAST>(cy, R) >> 2);
-                const int ii = (mulq<FAST>(pi, L) >> 14) + (mulq<FAST>(ci, R) >> 14);
-                const int qq = (mulq<FAST>(pq, L) >> 14) + (mulq<FAST>(cq, R) >> 14);
-                int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
-                int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
-                int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
-                r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
-                int rgb = r << 16 | g << 8 | b;
-                if (!BPP3) {
-                    if (blend && act) {
-                        const unsigned oldw = *(const unsigned *) (orow + (size_t) px * 4);
-                        const int old = (int) __builtin_amdgcn_perm(oldw, oldw, usel);
-                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
-                    }
-                    {
-                        const unsigned full = 0xff000000u | (unsigned) rgb;
-                        const unsigned pk = __builtin_amdgcn_perm(full, full, psel);
-                        const int slot = px & 3;                      /* wave-uniform */
-                        if (slot == 0) pend0 = pk; else if (slot == 1) pend1 = pk; else if (slot == 2) pend2 = pk; else pend3 = pk;
-                    }
-                    if ((px & 3) == 3 || px == outw - 1) {
-                        const int base = px & ~3;
-                        const int cnt = px - base + 1;
-                        for (int rr = 0; rr < nrows; rr++) {          /* row `beg` + D10 duplicates, :661-664 */
-                            unsigned char *d = orow + (size_t) rr * pitch + (size_t) base * 4;
-                            if (cnt == 4) {
-                                v4i v; v.x = (int) pend0; v.y = (int) pend1; v.z = (int) pend2; v.w = (int) pend3;
-                                store16u(d, v);
-                            } else {
-                                ((unsigned *) d)[0] = pend0;
-                                if (cnt > 1) ((unsigned *) d)[1] = pend1;
-                                if (cnt > 2) ((unsigned *) d)[2] = pend2;
+    for (int i = 0; i < 4; i++) {
+        stage[i] = gload16u(s_src[i * 16 + in_row] + in_piece * 16);
+    }
+    constexpr int NQ = (S::AV_LEN + 3) / 4;        /* dwords per line window; the last one may run past
+                                                      AV_LEN: the filters are causal, the extra samples feed nothing */
+    constexpr int NT = (NQ + IN_TILE_DW - 1) / IN_TILE_DW;
+    for (int t = 0; t < NT; t++) {
+        /* stash tile t (already in registers), then start fetching tile t+1 */
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned *d = s_in + (i * 16 + in_row) * IN_STRIDE + in_piece * 4;
+            d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
+        }
+        __syncthreads();
+        if (t + 1 < NT) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                stage[i] = gload16u(s_src[i * 16 + in_row] + (t + 1) * (IN_TILE_DW * 4) + in_piece * 16);
+            }
+        }
+        const int xq_end = (t + 1) * IN_TILE_DW < NQ ? (t + 1) * IN_TILE_DW : NQ;
+        for (int xq = t * IN_TILE_DW; xq < xq_end; xq++) {
+            const int word = (int) s_in[lane * IN_STRIDE + (xq - t * IN_TILE_DW)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = xq * 4 + k;
+                const int s = (word << (24 - 8 * k)) >> 24;
+                /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
+                const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
+                const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
+                const int cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
+                const int ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
+                const int cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
+                /* D9: every output pixel whose left tap is sample x-1 is now computable */
+                while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
+                    const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
+                    const int yy = (mulq<FAST>(py, L) >> 2) + (mulq<FAST>(cy, R) >> 2);
+                    const int ii = (mulq<FAST>(pi, L) >> 14) + (mulq<FAST>(ci, R) >> 14);
+                    const int qq = (mulq<FAST>(pq, L) >> 14) + (mulq<FAST>(cq, R) >> 14);
+                    int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
+                    int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
+                    int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
+                    r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
+                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = (unsigned) (r << 16 | g << 8 | b);
+                    if ((px & (PX_TILE - 1)) == PX_TILE - 1 || px == outw - 1) {
+                        /* drain the pixel tile: pixels [px0, px0+cnt) of every row, + D10 duplicates (:661-664) */
+                        const int px0 = px & ~(PX_TILE - 1);
+                        const int cnt = px - px0 + 1;
+                        __syncthreads();
+                        if (!BPP3) {
+                            const int orow_ = lane >> 3, piece = lane & 7;          /* 4 pixels = 16 bytes per piece */
+                            const int have = cnt - piece * 4;                      /* pixels of this piece that exist */
+#pragma unroll 2
+                            for (int i = 0; i < 8; i++) {
+                                const int rr_ = i * 8 + orow_;
+                                const int nr = s_nrows[rr_];
+                                if (nr > 0 && have > 0) {
+                                    const unsigned long long d = s_dst[rr_] + (size_t) (px0 + piece * 4) * 4;
+                                    const unsigned *sp = s_px + rr_ * PX_STRIDE + piece * 4;
+                                    unsigned v[4] = { sp[0], sp[1], sp[2], sp[3] };
+                                    if (blend) {
+#pragma unroll
+                                        for (int c = 0; c < 4; c++) {
+                                            if (c < have) {
+                                                const unsigned oldw = gload32(d + 4 * c);
+                                                const unsigned old = __builtin_amdgcn_perm(oldw, oldw, usel);
+                                                v[c] = ((v[c] & 0xfefeffu) >> 1) + ((old & 0xfefeffu) >> 1);
+                                            }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int c = 0; c < 4; c++) {
+                                        const unsigned full = 0xff000000u | v[c];
+                                        v[c] = __builtin_amdgcn_perm(full, full, psel);
+                                    }
+                                    for (int dup = 0; dup < nr; dup++) {
+                                        const unsigned long long dd = d + (size_t) dup * pitch;
+                                        if (have >= 4) {
+                                            v4i o; o.x = (int) v[0]; o.y = (int) v[1]; o.z = (int) v[2]; o.w = (int) v[3];
+                                            gstore16u(dd, o);
+                                        } else {
+                                            gstore32(dd, v[0]);
+                                            if (have > 1) gstore32(dd + 4, v[1]);
+                                            if (have > 2) gstore32(dd + 8, v[2]);
+                                        }
+                                    }
+                                }
+                            }
+                        } else {
+                            /* 3-byte formats: one pixel per lane, 32 pixels of 2 rows per pass */
+                            const int half = lane >> 5, c = lane & 31;
+                            for (int i = 0; i < 32; i++) {
+                                const int rr_ = i * 2 + half;
+                                const int nr = s_nrows[rr_];
+                                if (nr > 0 && c < cnt) {
+                                    const unsigned long long d = s_dst[rr_] + (size_t) (px0 + c) * 3;
+                                    int rgb = (int) s_px[rr_ * PX_STRIDE + c];
+                                    if (blend) {
+                                        const int o0 = (int) gload8(d), o1 = (int) gload8(d + 1), o2 = (int) gload8(d + 2);
+                                        const int old = rgb_order ? (o0 << 16 | o1 << 8 | o2) : (o2 << 16 | o1 << 8 | o0);
+                                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
+                                    }
+                                    const unsigned char c0 = (unsigned char) (rgb_order ? rgb >> 16 : rgb);
+                                    const unsigned char c2 = (unsigned char) (rgb_order ? rgb : rgb >> 16);
+                                    for (int dup = 0; dup < nr; dup++) {
+                                        const unsigned long long dd = d + (size_t) dup * pitch;
+                                        gstore8(dd, c0); gstore8(dd + 1, (unsigned) (rgb >> 8)); gstore8(dd + 2, c2);
+                                    }
+                                }
                             }
                         }
+                        __syncthreads();
                     }
-                } else {
-                    unsigned char *d0 = orow + (size_t) px * 3;
-                    if (blend && act) {
-                        const int old = rgb_order ? (d0[0] << 16 | d0[1] << 8 | d0[2]) : (d0[2] << 16 | d0[1] << 8 | d0[0]);
-                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
-                    }
-                    const unsigned char c0 = (unsigned char) (rgb_order ? rgb >> 16 : rgb);
-                    const unsigned char c2 = (unsigned char) (rgb_order ? rgb : rgb >> 16);
-                    for (int rr = 0; rr < nrows; rr++) {
-                        unsigned char *d = d0 + (size_t) rr * pitch;
-                        d[0] = c0; d[1] = (unsigned char) (rgb >> 8); d[2] = c2;
-                    }
+                    ppos += dx;
+                    px++;
                 }
-                ppos += dx;
-                px++;
+                py = cy; pi = ci; pq = cq;
             }
-            py = cy; pi = ci; pq = cq;
         }
     }
 }
@@ -939,7 +1094,7 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const int total = n * p->desth;
     const dim3 grid((total + 63) / 64), block(64);
     const unsigned char *img = (const unsigned char *) d_images;
-    if (S::IS_NES || p->in_bpp == 4)
+    if (S::IS_NES || (p->in_bpp == 4 && p->w >= 4))
         hipLaunchKernelGGL((k_active<S, FULL, FAST, true>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16);
     else
         hipLaunchKernelGGL((k_active<S, FULL, FAST, false>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16);

@@ -1,10 +1,28 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the default bench workload; summaries land in gpurun_out/prof_*
+# usage: tools/prof_bench.sh <tag> [bench args...]
+# rocprofv3 kernel trace (+ separate PMC passes for HBM bytes) of the bench workload.
+# Summaries land in gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
+tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$1 -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu > gpurun_out/prof_$1.log 2>&1
-tail -2 gpurun_out/prof_$1.log
-find gpurun_out/prof_$1 -name "*kernel_stats*" | head -3
-f=$(find gpurun_out/prof_$1 -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -12 "$f"
+out=gpurun_out/prof_$tag
+mkdir -p $out
+args="--steps 5 --warmup 2 --no-cpu $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py $args > $out/trace.log 2>&1
+tail -1 $out/trace.log | cut -c1-400
+f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $out/kernel_stats.csv && head -12 $out/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu $* > $out/pmc_$c.log 2>&1
+  g=$(find $out/pmc_$c -name "*counter_collection.csv" | head -1)
+  [ -n "$g" ] && python3 - "$g" $c <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: [0.0, 0])
+for r in rows:
+    k = r.get("Kernel_Name", "?").split("(")[0][:60]
+    agg[k][0] += float(r.get("Counter_Value", 0)); agg[k][1] += 1
+for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]:
+    print("%-12s %-60s launches %4d  avg/launch %.1f (counter units; KB for *_SIZE)" % (sys.argv[2], k, n, v / n))
+PY
+done
