@@ -282,7 +282,9 @@ __device__ __forceinline__ int ppu_level(int p, int phase)
 #define AC_TILE    32                     /* dwords per row and tile: 32 pixels in, 128 samples out */
 #define AC_STRIDE  (AC_TILE + 1)
 
-template <class S, bool NOISE, bool FAST, bool IN4>
+/* CLAMP: output is inp[] (fused path), i.e. the +-127 clamp of crt_core.c:363-364 applies even when
+ * no noise is added (only matters for NES, whose samples can be -128) */
+template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP>
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
@@ -373,6 +375,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     ire = (ire * P.white_point / 100) >> 12;
                     ire = (int) (signed char) ire;
                     if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                    else if (CLAMP) ire = clampi(ire, -127, 127);
                     pack |= (unsigned) (ire & 255) << (8 * k);
                     phase += 3;
                     col += qstep; err += rstep;
@@ -489,7 +492,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
  *     gap y  [S0 + y*HRES + destw, S0 + (y+1)*HRES)    y = 0 .. desth-2
  *     tail   [S0 + (desth-1)*HRES + destw, INPUT_SIZE)
  * and each lane takes one run of up to 16 samples of it. */
-template <class S>
+template <class S, bool NOISE>
 __global__ void __launch_bounds__(256)
 k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
          const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16,
@@ -523,14 +526,16 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     int line = idx0 / S::HRES;
     int t = idx0 - line * S::HRES;
     signed char *out = dst + (size_t) f * fstride;
-    unsigned rn = lcg_at(jump16, (unsigned) st.rn, idx0);
+    unsigned rn = 0;
+    if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, idx0);
     int vals[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         int v = 0;
         if (!skeleton<S>(P, line, t, field, inv_phase, st.aux, true, v)) v = 0;
-        rn = lcg_step(rn);
-        vals[k] = noisy(v, rn, P.noise);
+        if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
+        else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
+        vals[k] = v;
         if (++t == S::HRES) { t = 0; line++; }
     }
     if (len == 16) {
@@ -811,7 +816,8 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  */
 #define IN_TILE_DW   16                    /* decoder input tile: 64 samples per row            */
 #define IN_STRIDE    (IN_TILE_DW + 1)
-#define PX_TILE      32                    /* decoder output tile: 32 pixels per row            */
+#define PX_TILE      16                    /* decoder output tile: pixels per row (16 or 32)    */
+#define PX_PIECES    (PX_TILE / 4)         /* 16-byte pieces per tile row                       */
 #define PX_STRIDE    (PX_TILE + 1)
 
 /* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line */
@@ -915,11 +921,11 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                         const int cnt = px - px0 + 1;
                         __syncthreads();
                         if (!BPP3) {
-                            const int orow_ = lane >> 3, piece = lane & 7;          /* 4 pixels = 16 bytes per piece */
+                            const int orow_ = lane / PX_PIECES, piece = lane % PX_PIECES;  /* 4 pixels = 16 bytes per piece */
                             const int have = cnt - piece * 4;                      /* pixels of this piece that exist */
 #pragma unroll 2
-                            for (int i = 0; i < 8; i++) {
-                                const int rr_ = i * 8 + orow_;
+                            for (int i = 0; i < PX_PIECES; i++) {
+                                const int rr_ = i * (64 / PX_PIECES) + orow_;
                                 const int nr = s_nrows[rr_];
                                 if (nr > 0 && have > 0) {
                                     const unsigned long long d = s_dst[rr_] + (size_t) (px0 + piece * 4) * 4;
@@ -954,10 +960,10 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                 }
                             }
                         } else {
-                            /* 3-byte formats: one pixel per lane, 32 pixels of 2 rows per pass */
-                            const int half = lane >> 5, c = lane & 31;
-                            for (int i = 0; i < 32; i++) {
-                                const int rr_ = i * 2 + half;
+                            /* 3-byte formats: one pixel per lane, PX_TILE pixels of 64/PX_TILE rows per pass */
+                            const int half = lane / PX_TILE, c = lane % PX_TILE;
+                            for (int i = 0; i < PX_TILE; i++) {
+                                const int rr_ = i * (64 / PX_TILE) + half;
                                 const int nr = s_nrows[rr_];
                                 if (nr > 0 && c < cnt) {
                                     const unsigned long long d = s_dst[rr_] + (size_t) (px0 + c) * 3;
@@ -1094,10 +1100,13 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const int total = n * p->desth;
     const dim3 grid((total + 63) / 64), block(64);
     const unsigned char *img = (const unsigned char *) d_images;
-    if (S::IS_NES || (p->in_bpp == 4 && p->w >= 4))
-        hipLaunchKernelGGL((k_active<S, FULL, FAST, true>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16);
-    else
-        hipLaunchKernelGGL((k_active<S, FULL, FAST, false>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16);
+    const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
+    const bool noise = FULL && p->noise != 0;
+#define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
+    hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16)
+    if (noise) { if (in4) CRTHIP_LAUNCH_ACTIVE(true, true); else CRTHIP_LAUNCH_ACTIVE(true, false); }
+    else       { if (in4) CRTHIP_LAUNCH_ACTIVE(false, true); else CRTHIP_LAUNCH_ACTIVE(false, false); }
+#undef CRTHIP_LAUNCH_ACTIVE
 }
 
 template <class S, bool FULL>
@@ -1113,8 +1122,12 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
         const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
         const int tail = (tail_len + 15) / 16;
         const int total = n * (head + (p->desth - 1) * gap + tail);
-        hipLaunchKernelGGL((k_margin<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                           *p, n, dst, c->fstride, d_state, c->d_jump16, head, gap, tail);
+        if (p->noise != 0)
+            hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, dst, c->fstride, d_state, c->d_jump16, head, gap, tail);
+        else
+            hipLaunchKernelGGL((k_margin<S, false>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, dst, c->fstride, d_state, c->d_jump16, head, gap, tail);
     } else {
         constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
         ProfScope ps(c, CRTHIP_K_TEMPLATE);
