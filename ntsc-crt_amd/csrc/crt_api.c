@@ -1,0 +1,329 @@
+/*
+ * crt_api.c -- the reference's public API (crt_core.h:100-139 of LMP88959/NTSC-CRT) as a thin
+ * C89 client of the crthip_* C ABI.  One library per CRT_SYSTEM (-DCRT_SYSTEM=0|1|5), exactly
+ * like the reference is one build per CRT_SYSTEM.
+ *
+ * The caller owns `struct CRT`, the input image and the output image and may read or write any
+ * member between calls (crt_main.c:235-236, :262-264, :317-391, :430).  This layer therefore
+ * keeps NO authoritative state on the device: every call uploads what the kernels read
+ * (analog[], the output image, hsync/vsync/rn/ccf, the knobs) and downloads what the reference
+ * would have written (analog[] and ccf after crt_modulate; inp[], the output image, ccf, hsync,
+ * vsync, rn after crt_demodulate).  Device buffers are cached per `struct CRT *`.
+ *
+ * Errors: the reference API is all-void and has no error channel.  A HIP failure or a missing
+ * gfx950 device is reported on stderr and the process aborts -- there is no CPU fallback.
+ */
+#include "crt_core.h"
+#include "crt_hip.h"
+#include "crt_setup.h"
+
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- layout pins (C89 static assertions) ----------------------------------------------- */
+#define PIN(name, cond) typedef char crt_pin_##name[(cond) ? 1 : -1]
+PIN(analog_first, offsetof(struct CRT, analog) == 0);
+PIN(inp_follows_analog, offsetof(struct CRT, inp) == CRT_INPUT_SIZE);
+PIN(outw_follows_inp, offsetof(struct CRT, outw) == ((2 * CRT_INPUT_SIZE + 3) & ~3));
+PIN(out_is_pointer_aligned, offsetof(struct CRT, out) % sizeof(void *) == 0);
+PIN(ccf_shape, sizeof(((struct CRT *) 0)->ccf) == CRT_CC_VPER * CRT_CC_SAMPLES * sizeof(int));
+PIN(rn_last, offsetof(struct CRT, rn) + sizeof(int) <= sizeof(struct CRT));
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSC)
+PIN(ntsc_sizeof_crt, sizeof(void *) != 8 || sizeof(struct CRT) == 476928);    /* SURVEY.md section 8b */
+PIN(ntsc_sizeof_settings, sizeof(void *) != 8 || sizeof(struct NTSC_SETTINGS) == 56);
+PIN(ntsc_hres, CRT_HRES == 910 && AV_LEN == 753 && AV_BEG == 156);
+#endif
+
+#if (CRT_SYSTEM == CRT_SYSTEM_NES)
+#define SYS_ID CRTHIP_SYSTEM_NES
+#elif (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+#define SYS_ID CRTHIP_SYSTEM_NTSCVHS
+#else
+#define SYS_ID CRTHIP_SYSTEM_NTSC
+#endif
+
+/* ---- device-side cache, one slot per struct CRT ------------------------------------------- */
+#define MAX_SLOTS 32
+
+struct slot {
+    struct CRT *host;
+    signed char *d_analog, *d_inp;
+    crthip_state *d_state;
+    crthip_line *d_lines;
+    unsigned char *d_img, *d_out;
+    size_t img_cap, out_cap;
+};
+
+static crthip_ctx *g_ctx;
+static struct slot g_slots[MAX_SLOTS];
+static size_t g_fstride;
+
+static void
+fatal(const char *what, int rc)
+{
+    fprintf(stderr, "ntsc-crt (HIP/gfx950): %s failed (%d): %s\n", what, rc,
+            g_ctx ? crthip_error_string(g_ctx) : "no context");
+    fprintf(stderr, "ntsc-crt (HIP/gfx950): this library has no CPU fallback -- aborting\n");
+    abort();
+}
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ != CRTHIP_OK) fatal(#call, rc_); } while (0)
+
+static void *
+dev_alloc(size_t bytes)
+{
+    void *p = crthip_malloc(g_ctx, bytes);
+    if (p == 0) {
+        fatal("crthip_malloc", CRTHIP_E_NOMEM);
+    }
+    CHECK(crthip_memset(g_ctx, p, 0, bytes));
+    return p;
+}
+
+static struct slot *
+get_slot(struct CRT *v)
+{
+    int i;
+    struct slot *free_slot = 0;
+
+    if (g_ctx == 0) {
+        const char *dev = getenv("CRTHIP_DEVICE");
+        int rc = crthip_create(&g_ctx, dev ? atoi(dev) : 0, SYS_ID, CRT_CHROMA_PATTERN);
+        if (rc != CRTHIP_OK) {
+            g_ctx = 0;
+            fatal("crthip_create (is an MI355X / gfx950 visible?)", rc);
+        }
+        g_fstride = crthip_field_stride(SYS_ID, CRT_CHROMA_PATTERN);
+    }
+    for (i = 0; i < MAX_SLOTS; i++) {
+        if (g_slots[i].host == v) {
+            return &g_slots[i];
+        }
+        if (g_slots[i].host == 0 && free_slot == 0) {
+            free_slot = &g_slots[i];
+        }
+    }
+    if (free_slot == 0) {
+        /* recycle slot 0: its buffers stay allocated and are simply re-filled on the next call */
+        free_slot = &g_slots[0];
+    }
+    free_slot->host = v;
+    if (free_slot->d_analog == 0) {
+        free_slot->d_analog = (signed char *) dev_alloc(g_fstride + 4096);
+        free_slot->d_inp = (signed char *) dev_alloc(g_fstride + 4096);
+        free_slot->d_state = (crthip_state *) dev_alloc(sizeof(crthip_state));
+        free_slot->d_lines = (crthip_line *) dev_alloc(sizeof(crthip_line) * CRT_LINES);
+    }
+    return free_slot;
+}
+
+static void
+ensure(unsigned char **buf, size_t *cap, size_t need)
+{
+    if (*cap < need) {
+        if (*buf) {
+            crthip_free(g_ctx, *buf);
+        }
+        *buf = (unsigned char *) dev_alloc(need);
+        *cap = need;
+    }
+}
+
+static void
+state_to_device(struct slot *sl, const struct CRT *v, int field, int frame, int aux)
+{
+    crthip_state st;
+    int r, k;
+
+    memset(&st, 0, sizeof(st));
+    st.field = field;
+    st.frame = frame;
+    st.aux = aux;
+    st.hsync = v->hsync;
+    st.vsync = v->vsync;
+    st.rn = v->rn;
+    for (r = 0; r < CRT_CC_VPER; r++) {
+        for (k = 0; k < CRT_CC_SAMPLES; k++) {
+            st.ccf[r][k] = v->ccf[r][k];
+        }
+    }
+    CHECK(crthip_upload(g_ctx, sl->d_state, &st, sizeof(st)));
+}
+
+static void
+state_from_device(struct slot *sl, struct CRT *v, int sync_too)
+{
+    crthip_state st;
+    int r, k;
+
+    CHECK(crthip_download(g_ctx, &st, sl->d_state, sizeof(st)));
+    for (r = 0; r < CRT_CC_VPER; r++) {
+        for (k = 0; k < CRT_CC_SAMPLES; k++) {
+            v->ccf[r][k] = st.ccf[r][k];
+        }
+    }
+    v->hsync = st.hsync;
+    if (sync_too) {
+        v->vsync = st.vsync;
+        v->rn = st.rn;
+    }
+}
+
+/* the knobs the kernels need, from the caller's struct */
+static void
+monitor_params(crthip_params *p, const struct CRT *v)
+{
+    CHECK(crthip_params_default(p, SYS_ID, CRT_CHROMA_PATTERN));
+    p->outw = v->outw > 0 ? v->outw : 1;
+    p->outh = v->outh > 0 ? v->outh : 1;
+    p->out_format = v->out_format;
+    p->mon_hue = v->hue;
+    p->brightness = v->brightness;
+    p->contrast = v->contrast;
+    p->saturation = v->saturation;
+    p->black_point = v->black_point;
+    p->white_point = v->white_point;
+    p->scanlines = v->scanlines;
+    p->blend = v->blend;
+    p->v_fac = v->v_fac;
+    p->w = 1;
+    p->h = 1;
+}
+
+/* ---- public API ---------------------------------------------------------------------------- */
+
+extern int
+crt_bpp4fmt(int format)
+{
+    return crt_setup_bpp4fmt(format);
+}
+
+extern void
+crt_sincos14(int *s, int *c, int n)
+{
+    crt_setup_sincos14(s, c, n);
+}
+
+extern void
+crt_resize(struct CRT *v, int w, int h, int f, unsigned char *out)
+{
+    v->outw = w;
+    v->outh = h;
+    v->out_format = f;
+    v->out = out;
+}
+
+extern void
+crt_reset(struct CRT *v)
+{
+    v->hue = 0;
+    v->saturation = 10;
+    v->brightness = 0;
+    v->contrast = 180;
+    v->black_point = 0;
+    v->white_point = 100;
+    v->hsync = 0;
+    v->vsync = 0;
+}
+
+extern void
+crt_init(struct CRT *v, int w, int h, int f, unsigned char *out)
+{
+    memset(v, 0, sizeof(struct CRT));
+    crt_resize(v, w, h, f, out);
+    crt_reset(v);
+    v->rn = 194;
+    /* the equaliser coefficients the reference sets up here are derived per call on the host
+     * (crthip_params_finalize); nothing else to do until the first modulate / demodulate */
+}
+
+extern void
+crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
+{
+    struct slot *sl;
+    crthip_params p;
+    size_t img_bytes;
+    int field = 0, frame = 0, aux = 0;
+
+    monitor_params(&p, v);
+    p.w = s->w;
+    p.h = s->h;
+    p.hue = s->hue;
+    p.xoffset = s->xoffset;
+    p.yoffset = s->yoffset;
+#if (CRT_SYSTEM == CRT_SYSTEM_NES)
+    if (!s->field_initialized) {
+        p.flags |= CRTHIP_F_NES_SETUP;
+    }
+    s->field_initialized = 1;
+    aux = s->dot_crawl_offset;
+    img_bytes = (size_t) s->w * (size_t) s->h * 2;
+#else
+    p.format = s->format;
+    p.raw = s->raw;
+    p.as_color = s->as_color;
+    s->iirs_initialized = 1;
+    if (crt_setup_bpp4fmt(s->format) == 0) {
+        return;     /* like the reference: nothing else happens for an unknown pixel format */
+    }
+    s->field &= 1;
+    s->frame &= 1;
+    field = s->field;
+    frame = s->frame;
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+    if (s->do_aberration) {
+        aux = ((rand() % 12) - 8) + 14;     /* same libc stream as the reference consumes */
+    }
+#endif
+    img_bytes = (size_t) s->w * (size_t) s->h * (size_t) crt_setup_bpp4fmt(s->format);
+#endif
+    if (s->w <= 0 || s->h <= 0 || s->data == 0) {
+        return;
+    }
+    CHECK(crthip_params_finalize(&p));
+
+    sl = get_slot(v);
+    /* one spare row + slack: the encoder may address row h (reference quirk) */
+    ensure(&sl->d_img, &sl->img_cap, img_bytes + img_bytes / (size_t) s->h + 256);
+    CHECK(crthip_upload(g_ctx, sl->d_img, s->data, img_bytes));
+    CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
+    state_to_device(sl, v, field, frame, aux);
+    CHECK(crthip_modulate(g_ctx, &p, 1, sl->d_img, 0, sl->d_analog, sl->d_state));
+    CHECK(crthip_download(g_ctx, v->analog, sl->d_analog, CRT_INPUT_SIZE));
+    state_from_device(sl, v, 0);
+}
+
+extern void
+crt_demodulate(struct CRT *v, int noise)
+{
+    struct slot *sl;
+    crthip_params p;
+    size_t out_bytes;
+    int bpp;
+
+    bpp = crt_setup_bpp4fmt(v->out_format);
+    if (bpp == 0) {
+        return;
+    }
+    if (v->outw <= 0 || v->outh <= 0 || v->out == 0) {
+        return;
+    }
+    monitor_params(&p, v);
+    p.noise = noise;
+    CHECK(crthip_params_finalize(&p));
+
+    sl = get_slot(v);
+    out_bytes = (size_t) v->outw * (size_t) v->outh * (size_t) bpp;
+    ensure(&sl->d_out, &sl->out_cap, out_bytes + 256);
+    CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
+    CHECK(crthip_upload(g_ctx, sl->d_out, v->out, out_bytes));
+    state_to_device(sl, v, 0, 0, 0);
+    CHECK(crthip_noise(g_ctx, &p, 1, sl->d_analog, sl->d_inp, sl->d_state));
+    CHECK(crthip_sync(g_ctx, &p, 1, sl->d_inp, sl->d_state, sl->d_lines));
+    CHECK(crthip_decode(g_ctx, &p, 1, sl->d_inp, sl->d_lines, sl->d_out, out_bytes));
+    CHECK(crthip_download(g_ctx, v->inp, sl->d_inp, CRT_INPUT_SIZE));
+    CHECK(crthip_download(g_ctx, v->out, sl->d_out, out_bytes));
+    state_from_device(sl, v, 1);
+}

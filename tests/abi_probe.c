@@ -1,10 +1,13 @@
 /*
- * ref_probe.c -- TEST INFRASTRUCTURE ONLY.
+ * abi_probe.c -- TEST INFRASTRUCTURE ONLY.
  *
- * Compiled *together with* the untouched reference sources (found through
- * -I$(REF), never copied) into oracle/_ref/libref_<sys>.so.  It adds a few
- * helper entry points next to the reference's own crt_* symbols so the Python
- * tests / bench can
+ * A tiny shim over "crt_core.h" -- WHICHEVER crt_core.h the include path provides:
+ *   (a) compiled together with the untouched reference sources (found through -I$(REF), never
+ *       copied) into oracle/_ref/libref_<sys>.so, and
+ *   (b) compiled against this repo's own include/crt_core.h and linked to the drop-in
+ *       libntsccrt_hip_<sys>.so (tests/crtref.py: build_dropin_probe), so both can be driven
+ *       and compared through the same Python wrapper.
+ * It adds a few helper entry points next to the crt_* symbols so the tests / bench can
  *   - learn sizeof/offsetof of the reference's struct CRT / NTSC_SETTINGS
  *     (they depend on CRT_SYSTEM, crt_core.h:43-59),
  *   - time the reference's crt_modulate + crt_demodulate on the host cores

@@ -43,6 +43,25 @@ def build_ref():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
 
 
+PKG_LIB = os.path.join(ROOT, "ntsc-crt_amd", "lib")
+DROPIN = {"ntsc": ("libntsccrt_hip_ntsc.so", ["-DCRT_SYSTEM=0"]),
+          "vhs": ("libntsccrt_hip_vhs.so", ["-DCRT_SYSTEM=5"]),
+          "nes": ("libntsccrt_hip_nes.so", ["-DCRT_SYSTEM=1"]),
+          "nesp0": ("libntsccrt_hip_nesp0.so", ["-DCRT_SYSTEM=1", "-DCRT_CHROMA_PATTERN=0"])}
+
+
+def build_dropin_probe(name):
+    """tests/abi_probe.c compiled against THIS repo's include/crt_core.h and linked to the drop-in
+    library: the same refp_* helper surface as oracle/_ref, but over the HIP implementation."""
+    lib, defs = DROPIN[name]
+    out = os.path.join(PKG_LIB, "libdropin_probe_%s.so" % name)
+    src = os.path.join(ROOT, "tests", "abi_probe.c")
+    if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(PKG_LIB, lib))):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include")] + defs +
+                       ["-o", out, src, "-L" + PKG_LIB, "-l" + lib[3:-3], "-Wl,-rpath," + PKG_LIB], check=True)
+    return out
+
+
 def have_ref(name="ntsc"):
     return os.path.exists(os.path.join(REF_DIR, SYSTEMS[name][2]))
 
@@ -114,10 +133,15 @@ class RefLib:
                   "contrast", "saturation", "black_point", "white_point", "scanlines", "blend",
                   "v_fac", "ccf", "hsync", "vsync", "rn"]
 
-    def __init__(self, name="ntsc"):
+    def __init__(self, name="ntsc", dropin=False):
+        """dropin=False: the real reference (oracle/_ref).  dropin=True: this repo's drop-in library
+        (ntsc-crt_amd/lib/libntsccrt_hip_<sys>.so) behind the same probe surface."""
         self.name = name
         self.system, self.pattern, libname = SYSTEMS[name]
-        self.lib = C.CDLL(os.path.join(REF_DIR, libname), mode=os.RTLD_LOCAL)
+        if dropin:
+            self.lib = C.CDLL(build_dropin_probe(name), mode=os.RTLD_LOCAL)
+        else:
+            self.lib = C.CDLL(os.path.join(REF_DIR, libname), mode=os.RTLD_LOCAL)
         L = self.lib
         for f in ("sizeof_crt", "sizeof_settings"):
             getattr(L, "refp_" + f).restype = C.c_long
