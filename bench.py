@@ -81,6 +81,7 @@ def main():
 
     import torch
     import crtlib
+    import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,15 +106,15 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
     images = torch.randint(0, 256, (n, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)[:, :h]
+    # this rank's contiguous block of the global batch: frames [rank*n, (rank+1)*n)
+    parity = [shard.field_parity(rank * n + k) for k in range(n)]
     s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
-                        field=[k & 1 for k in range(n)], frame=[(k >> 1) & 1 for k in range(n)])
+                        field=[a for a, _ in parity], frame=[b for _, b in parity])
 
     # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
     p = crt.params(s, args.noise)
     if dist is not None:
-        blob = torch.frombuffer(bytearray(bytes(p)), dtype=torch.uint8).to(dev)
-        dist.broadcast(blob, src=0)
-        C.memmove(C.byref(p), bytes(blob.cpu().numpy().tobytes()), C.sizeof(p))
+        shard.broadcast_params(p, dist, dev)
     crt._load_field_state(s)
 
     def step(k):
@@ -138,9 +139,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
     # per-kernel durations with HIP events on the launch stream (separate short run, same workload)
     crt.profile(True)
