@@ -89,6 +89,9 @@ static_assert(SysNTSC::HRES == 910 && SysNTSC::AV_BEG == 156 && SysNTSC::AV_LEN 
 static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES == 912 &&
               SysNES0::AV_LEN == 684, "NES timing (SURVEY.md section 8)");
 
+#define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
+#define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
+#define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
 #define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
 #define LCG_MUL 214019u          /* crt_core.c:359 */
 #define LCG_ADD 140327895u
@@ -124,6 +127,19 @@ template <bool FAST> __device__ __forceinline__ int mulq(int a, int b)
 {
     if (FAST) return __mul24(a, b);
     return a * b;
+}
+
+/* vgpr * sgpr.  __mul24's sign-extension of a LOOP-CARRIED operand gets hoisted to its definition in
+ * another basic block, after which instruction selection (per block) no longer knows the value fits
+ * 24 bits and falls back to the quarter-rate v_mul_lo_u32; pinning the instruction avoids that. */
+template <bool FAST> __device__ __forceinline__ int mulq_vs(int v, int s_uniform)
+{
+    if (FAST) {
+        int r;
+        asm("v_mul_i32_i24 %0, %2, %1" : "=v"(r) : "v"(v), "s"(s_uniform));
+        return r;
+    }
+    return v * s_uniform;
 }
 
 /* noise LCG, crt_core.c:359-364 */
@@ -610,42 +626,68 @@ __global__ void k_advance_rn(int n_fields, crthip_state *state, uint2 whole_fiel
 }
 
 /* ------------------------------------------------------------------------- */
-/* D2-D7: the serial sync chain, one wavefront per field                       */
+/* D2-D7: the serial sync chain                                                */
 /* ------------------------------------------------------------------------- */
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+/* The chain is serial in the line index (hsync and the burst integrators carry over,
+ * crt_core.c:447,456-467).  Two kernels:
+ *   k_vsync  D2      one wave per field: all 2*VWIN candidate lines are fetched up front, then
+ *                    scanned with a wave-wide prefix sum; runs once per field.
+ *   k_hsync  D4-D7   ONE DPP ROW (16 lanes) PER FIELD, four fields per wave: the hsync window is
+ *                    16 samples (= one row, prefix sum by DPP row shifts), the burst integrators
+ *                    are 4 chains (= one quad).  Row-uniform values live redundantly in the 16 lanes.
+ * Latency: the bytes a line needs lie in [ln+hsync+SYNC_BEG-HWIN, ln+(hsync'&~3)+CB_BEG+40) with
+ * |hsync'-hsync| <= HWIN; a 256-byte window [ln+hsync-40, ln+hsync+216) of line L+2 is fetched
+ * while line L is processed (speculating that hsync moves by at most 3*HWIN until then) and parked
+ * in a 3-slot LDS ring one iteration later, so a fetch has a whole iteration to land.  Whenever the bytes actually needed are not inside the parked window (hsync
+ * wrapped around, ...) they are loaded directly -- same result, only slower. */
+#define DPP_ROW_SHR(n)   (0x110 + (n))
+#define DPP_ROW_BCAST15  0x142
+#define DPP_ROW_BCAST31  0x143
+#define DPP_QUAD_BCAST(k) ((k) * 0x55)            /* quad_perm:[k,k,k,k] */
+
+/* inclusive prefix sum inside each row of 16 lanes */
+__device__ __forceinline__ int row_incl_scan(int v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, true);
+    return v;
+}
+/* inclusive prefix sum over the 64 lanes of the wave */
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v = row_incl_scan(v);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xa, 0xf, false);   /* rows 1,3 += last of rows 0,2 */
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);   /* rows 2,3 += lane 31 */
     return v;
 }
 
+/* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR */
 template <class S>
 __global__ void __launch_bounds__(64)
-k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-       crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn)
+k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
+        uint2 whole_field, int advance_rn)
 {
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     if (f >= n_fields) return;
     const signed char *in = inp + (size_t) f * fstride;
     crthip_state *st = state + f;
-    int hsync = st->hsync, vsync = st->vsync;
-    int ccr[S::VPER];                                   /* lane holds ccf[r][lane & 3] */
-#pragma unroll
-    for (int r = 0; r < S::VPER; r++) ccr[r] = st->ccf[r][lane & 3];
-
-    /* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR */
+    const int vsync = st->vsync;
     int vline = 0, vj = S::HRES;
-    {
-        bool found = false;
-        for (int i = -S::VWIN; i < S::VWIN && !found; i++) {
-            vline = posmod(vsync + i, S::VRES);
-            const signed char *sig = in + vline * S::HRES + lane * 16;
-            const v4i raw = load16u(sig);
-            const int wds[4] = { raw.x, raw.y, raw.z, raw.w };
+    v4i cand[2 * S::VWIN];
+#pragma unroll
+    for (int i = 0; i < 2 * S::VWIN; i++) {
+        const int l = posmod(vsync + i - S::VWIN, S::VRES);
+        cand[i] = load16u(in + l * S::HRES + lane * 16);
+    }
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 2 * S::VWIN; i++) {
+        if (!found) {
+            vline = posmod(vsync + i - S::VWIN, S::VRES);
+            const int wds[4] = { cand[i].x, cand[i].y, cand[i].z, cand[i].w };
             int pre[16];
             int run = 0;
 #pragma unroll
@@ -655,7 +697,7 @@ k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp,
                 run += s;
                 pre[k] = run;
             }
-            const int excl = wave_incl_scan(run, lane) - run;
+            const int excl = wave_incl_scan(run) - run;
             int first = 16;
 #pragma unroll
             for (int k = 15; k >= 0; k--) {
@@ -664,89 +706,182 @@ k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp,
             const unsigned long long m = __ballot(first < 16);
             if (m) {
                 const int L = __ffsll((long long) m) - 1;
-                vj = L * 16 + __shfl(first, L);
+                vj = L * 16 + __builtin_amdgcn_readlane(first, L);
                 found = true;
             }
         }
-        if (!found) vj = S::HRES;
     }
-    vsync = vline;
-    const int odd = vj > S::HRES / 2;
-    const int field_rows = odd * (P.ratio / 2);                       /* crt_core.c:407 */
+    if (!found) vj = S::HRES;
+    if (lane == 0) {
+        st->vsync = vline;
+        st->odd_field = vj > S::HRES / 2;
+        if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
+    }
+}
 
+#define SYNC_WIN      256      /* bytes of a line's parked sync/burst window (16 lanes x 16 bytes) */
+#define SYNC_WIN_BACK 40       /* window starts this far before ln + hsync                         */
+
+/* D4-D7, crt_core.c:428-479.  Needs state.vsync / state.odd_field from k_vsync. */
+template <class S>
+__global__ void __launch_bounds__(64)
+k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+        crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
+{
+    __shared__ int s_win[4][3][SYNC_WIN / 4];
+    const int lane = threadIdx.x;
+    const int row = lane >> 4, j = lane & 15;            /* field slot in the wave, lane in the row */
+    const int f = blockIdx.x * 4 + row;
+    const bool live = f < n_fields;
+    const int fc = live ? f : n_fields - 1;              /* dead rows shadow the last field, never store */
+    const signed char *in = inp + (size_t) fc * fstride;
+    crthip_state *st = state + fc;
+    int hsync = st->hsync;
+    const int vsync = st->vsync;
+    const int field_rows = st->odd_field * (P.ratio / 2);             /* crt_core.c:407 */
+    int ccr[S::VPER];                                    /* lane holds ccf[r][j & 3] */
+#pragma unroll
+    for (int r = 0; r < S::VPER; r++) ccr[r] = st->ccf[r][j & 3];
+    crthip_line *out_lines = lines + (size_t) fc * S::LINES;
+
+    /* flat base of the window of line `line` assuming hsync h (row-uniform) */
+    auto window_base = [&](int line, int h) {
+        int l = line + vsync;                          /* < 2*VRES: BOT + 1 + VRES - 1 */
+        if (l >= S::VRES) l -= S::VRES;
+        const int b = l * S::HRES + h - SYNC_WIN_BACK;
+        return b < 0 ? 0 : b;
+    };
+    /* each of the 16 lanes of a row moves 16 bytes of its field's window */
+    int base_cur = window_base(S::TOP, hsync);           /* window parked for the current line */
+    {
+        const v4i w = load16u(in + base_cur + j * 16);
+        int *d = s_win[row][S::TOP % 3] + j * 4;
+        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+    }
+    int base_p = window_base(S::TOP + 1, hsync);         /* window in flight for line + 1 */
+    v4i wp = load16u(in + base_p + j * 16);
+    __syncthreads();
+
+    const unsigned span = (unsigned) P.outh + P.v_fac;
     for (int line = S::TOP; line < S::BOT; line++) {
-        crthip_line lp;
+        /* speculative fetch of the window of line + 2 (see the comment above) */
+        const int base_n = window_base(line + 2, hsync);
+        v4i wn = wp;
+        if (line + 2 < S::BOT) wn = load16u(in + base_n + j * 16);
+        const signed char *win = (const signed char *) s_win[row][line % 3];
+
         /* D4, crt_core.c:428-432 (unsigned arithmetic: v_fac is unsigned) */
-        int beg = (int) ((unsigned) (line - S::TOP + 0) * ((unsigned) P.outh + P.v_fac) / (unsigned) S::LINES + (unsigned) field_rows);
-        int end = (int) ((unsigned) (line - S::TOP + 1) * ((unsigned) P.outh + P.v_fac) / (unsigned) S::LINES + (unsigned) field_rows);
-        if (beg >= P.outh) {
-            if (lane == 0) {
-                lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = hsync;
-                lines[(size_t) f * S::LINES + (line - S::TOP)] = lp;
-            }
-            continue;
-        }
+        int beg = (int) ((unsigned) (line - S::TOP + 0) * span / (unsigned) S::LINES + (unsigned) field_rows);
+        int end = (int) ((unsigned) (line - S::TOP + 1) * span / (unsigned) S::LINES + (unsigned) field_rows);
+        const bool skip = beg >= P.outh;                               /* :431, row-uniform */
         if (end > P.outh) end = P.outh;
 
-        /* D5 hsync, crt_core.c:437-450 */
-        const int ln = posmod(line + vsync, S::VRES) * S::HRES;
+        /* D5 hsync, crt_core.c:437-450.  0 <= vsync < VRES (k_vsync), so one conditional subtract wraps */
+        int lidx = line + vsync;
+        if (lidx >= S::VRES) lidx -= S::VRES;
+        const int ln = lidx * S::HRES;
+        const int a_off = ln + hsync + S::SYNC_BEG - S::HWIN - base_cur;          /* window-relative */
         int sv = 0;
-        if (lane < 2 * S::HWIN) sv = in[ln + hsync + S::SYNC_BEG - S::HWIN + lane];
-        const int pref = wave_incl_scan(sv, lane);
-        const unsigned long long hm = __ballot(lane < 2 * S::HWIN && pref <= S::HTHR);
-        const int hi = hm ? (__ffsll((long long) hm) - 1 - S::HWIN) : S::HWIN;
-        hsync = posmod(hi + hsync, S::HRES);
+        if (j < 2 * S::HWIN) {
+            if (a_off >= 0 && a_off + 2 * S::HWIN <= SYNC_WIN) sv = win[a_off + j];
+            else sv = in[ln + hsync + S::SYNC_BEG - S::HWIN + j];
+        }
+        const int pref = row_incl_scan(sv);
+        const unsigned long long hm = __ballot(j < 2 * S::HWIN && pref <= S::HTHR);
+        const unsigned m16 = (unsigned) (hm >> (row * 16)) & 0xffffu;
+        const int hi = m16 ? (__ffs((int) m16) - 1 - S::HWIN) : S::HWIN;
+        int hsync_new = hi + hsync;                                      /* POSMOD(i + hsync, HRES), :447 */
+        if (hsync >= 0 && hsync < S::HRES) {                             /* |hi| <= HWIN: one wrap either way */
+            if (hsync_new < 0) hsync_new += S::HRES;
+            if (hsync_new >= S::HRES) hsync_new -= S::HRES;
+        } else {
+            hsync_new = posmod(hsync_new, S::HRES);                      /* caller-supplied out-of-range hsync */
+        }
+        if (!skip) hsync = hsync_new;
 
-        const int xpos = posmod(S::AV_BEG + hsync - 3, S::HRES);       /* :452-454 */
-        const int ypos = posmod(line + vsync + 3, S::VRES);
+        int xpos, ypos;                                                  /* :452-454 */
+        if (hsync >= 0 && hsync < S::HRES) {
+            xpos = S::AV_BEG + hsync - 3;
+            if (xpos >= S::HRES) xpos -= S::HRES;
+        } else {
+            xpos = posmod(S::AV_BEG + hsync - 3, S::HRES);
+        }
+        ypos = lidx + 3;
+        if (ypos >= S::VRES) ypos -= S::VRES;
         const int pos = xpos + ypos * S::HRES;
 
-        /* D6 burst lock, crt_core.c:456-467.  Lane l integrates phase (l & 3). */
-        int bs = 0;
-        if (lane < CB_SAMPLES) bs = in[ln + (hsync & ~3) + S::CB_BEG + lane];
+        /* D6 burst lock, crt_core.c:456-467.  Lane j integrates phase (j & 3): its samples are burst
+         * bytes k0, k0+4, ... with (CB_BEG + k0) & 3 == (j & 3) */
+        const int b_off = ln + (hsync & ~3) + S::CB_BEG - base_cur;
+        const bool b_in = b_off >= 0 && b_off + CB_SAMPLES <= SYNC_WIN;
+        const int k0 = ((j & 3) - S::CB_BEG) & 3;
+        int smp[CB_SAMPLES / 4];
+        if (b_in) {
+#pragma unroll
+            for (int q = 0; q < CB_SAMPLES / 4; q++) smp[q] = win[b_off + k0 + 4 * q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < CB_SAMPLES / 4; q++) smp[q] = in[ln + (hsync & ~3) + S::CB_BEG + k0 + 4 * q];
+        }
         const int r = S::VPER == 1 ? 0 : ypos % S::VPER;
         int acc = ccr[0];
 #pragma unroll
         for (int k = 1; k < S::VPER; k++) if (r == k) acc = ccr[k];
-        const int k0 = ((lane & 3) - S::CB_BEG) & 3;                    /* first burst sample of my phase */
 #pragma unroll
-        for (int j = 0; j < CB_SAMPLES / 4; j++) {
-            const int nsmp = __shfl(bs, k0 + 4 * j);
-            const int t127 = acc * 127;
-            acc = ((t127 + ((t127 >> 31) & 127)) >> 7) + nsmp;          /* C's truncating /128 */
+        for (int q = 0; q < CB_SAMPLES / 4; q++) {
+            const int t127 = (int) (((unsigned) acc << 7) - (unsigned) acc);   /* acc * 127 with wrap, no slow multiply */
+            acc = ((t127 + ((t127 >> 31) & 127)) >> 7) + smp[q];          /* C's truncating /128 */
         }
+        if (!skip) {
 #pragma unroll
-        for (int k = 0; k < S::VPER; k++) if (r == k) ccr[k] = acc;
+            for (int k = 0; k < S::VPER; k++) if (r == k) ccr[k] = acc;
+        }
 
-        /* D7 carrier table, crt_core.c:469-479 */
+        /* D7 carrier table, crt_core.c:469-479: quad lanes 0..3 hold ccr[0..3] */
+        const int q0 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(0), 0xf, 0xf, false);
+        const int q1 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(1), 0xf, 0xf, false);
+        const int q2 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(2), 0xf, 0xf, false);
+        const int q3 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(3), 0xf, 0xf, false);
         const int pa = hsync & 3;
-        const int c1 = __shfl(acc, (pa + 1) & 3), c3 = __shfl(acc, (pa + 3) & 3);
-        const int c2 = __shfl(acc, (pa + 2) & 3), c0 = __shfl(acc, pa);
+        const int c0 = pa == 0 ? q0 : pa == 1 ? q1 : pa == 2 ? q2 : q3;
+        const int c1 = pa == 0 ? q1 : pa == 1 ? q2 : pa == 2 ? q3 : q0;
+        const int c2 = pa == 0 ? q2 : pa == 1 ? q3 : pa == 2 ? q0 : q1;
+        const int c3 = pa == 0 ? q3 : pa == 1 ? q0 : pa == 2 ? q1 : q2;
         const int dci = c1 - c3, dcq = c2 - c0;
-        if (lane == 0) {
-            lp.pos = pos;
-            lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
-            lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
-            lp.beg = beg;
-            int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
-            nrows = nrows < 1 ? 1 : nrows;
-            /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
-            if (lp.wave0 > 524288 || lp.wave0 < -524288 || lp.wave1 > 524288 || lp.wave1 < -524288) nrows |= 0x40000000;
-            lp.nrows = nrows;
-            lp.hsync = hsync;
-            lines[(size_t) f * S::LINES + (line - S::TOP)] = lp;
+        if (j == 0 && live) {
+            crthip_line lp;
+            if (skip) {
+                lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = hsync;
+            } else {
+                lp.pos = pos;
+                lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
+                lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
+                lp.beg = beg;
+                int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
+                nrows = nrows < 1 ? 1 : nrows;
+                /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
+                if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
+                    nrows |= CRTHIP_LINE_EXACT;
+                lp.nrows = nrows;
+                lp.hsync = hsync;
+            }
+            out_lines[line - S::TOP] = lp;
         }
+        /* park the window of line + 1 (fetched one iteration ago), keep line + 2's in flight */
+        if (line + 1 < S::BOT) {
+            int *d = s_win[row][(line + 1) % 3] + j * 4;
+            d[0] = wp.x; d[1] = wp.y; d[2] = wp.z; d[3] = wp.w;
+        }
+        base_cur = base_p;
+        base_p = base_n;
+        wp = wn;
+        __syncthreads();
     }
-    if (lane < 4) {
+    if (j < 4 && live) {
 #pragma unroll
-        for (int r = 0; r < S::VPER; r++) st->ccf[r][lane] = ccr[r];
+        for (int r = 0; r < S::VPER; r++) st->ccf[r][j] = ccr[r];
     }
-    if (lane == 0) {
-        st->hsync = hsync;
-        st->vsync = vsync;
-        st->odd_field = odd;
-        if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
-    }
+    if (j == 0 && live) st->hsync = hsync;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -762,9 +897,6 @@ k_sync(const crthip_params P, int n_fields, const signed char *__restrict__ inp,
  * DESIGN.md "24-bit multiply envelope"); lines outside the envelope are flagged by
  * k_sync (CRTHIP_LINE_EXACT) and re-run by the FAST=false instantiation.
  */
-#define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows */
-#define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast path, 2^19 */
-#define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast path        */
 
 struct Eq3 { int lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3, h0, h1, h2; };
 
@@ -907,9 +1039,9 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 /* D9: every output pixel whose left tap is sample x-1 is now computable */
                 while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
                     const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
-                    const int yy = (mulq<FAST>(py, L) >> 2) + (mulq<FAST>(cy, R) >> 2);
-                    const int ii = (mulq<FAST>(pi, L) >> 14) + (mulq<FAST>(ci, R) >> 14);
-                    const int qq = (mulq<FAST>(pq, L) >> 14) + (mulq<FAST>(cq, R) >> 14);
+                    const int yy = (mulq_vs<FAST>(py, L) >> 2) + (mulq<FAST>(cy, R) >> 2);
+                    const int ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq<FAST>(ci, R) >> 14);
+                    const int qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq<FAST>(cq, R) >> 14);
                     int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
                     int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
                     int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
@@ -1351,8 +1483,8 @@ static int launch_sync(crthip_ctx *c, const crthip_params *p, int n, const signe
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
-        hipLaunchKernelGGL((k_sync<S>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                           c->whole_field, advance_rn);
+        hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
+        hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         return CRTHIP_OK;
     });
 }
