@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--scanlines", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--overlap", type=int, default=1, help="chunks alternating between two streams")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +102,7 @@ def main():
     crt = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=local)
     crt.scanlines = args.scanlines
     crt.reserve(n)
+    crt.set_overlap(args.overlap)
 
     # synthetic input, generated on the device: uniform random BGRA bytes per frame
     gen = torch.Generator(device=dev)

@@ -205,6 +205,11 @@ int  crthip_decode(crthip_ctx *ctx, const crthip_params *p, int n,
                    const signed char *d_inp, const crthip_line *d_lines,
                    void *d_out, size_t out_stride);
 
+/* crthip_fieldpass may cut a batch into `chunks` pieces that alternate between the caller's
+ * stream and an internal stream (fenced by events on both sides), so that the latency-bound
+ * kernels of one piece overlap the ALU-bound kernels of the next.  1 = off (default). */
+int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
+
 /* The decoder and encoder normally run kernels whose multiplies are the full-rate 24-bit
  * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,
  * "24-bit multiply envelope"), everything else goes to the exact 32-bit instantiation.  Both

@@ -87,6 +87,7 @@ def load_library():
     L.crthip_decode.argtypes = [vp, PP, ci, vp, vp, vp, sz]
     L.crthip_profile_enable.argtypes = [vp, ci]
     L.crthip_set_exact.argtypes = [vp, ci]
+    L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
     _LIB = L
     return L
@@ -292,6 +293,10 @@ class CRT:
     def set_exact(self, on=True):
         """Force the exact 32-bit-multiply kernels (normally only used outside the proven 24-bit envelope)."""
         self._check(self.L.crthip_set_exact(self.ctx, int(on)), "crthip_set_exact")
+
+    def set_overlap(self, chunks):
+        """fieldpass(): split the batch into `chunks` pieces alternating between two streams."""
+        self._check(self.L.crthip_set_overlap(self.ctx, int(chunks)), "crthip_set_overlap")
 
     def profile(self, on=True):
         self._check(self.L.crthip_profile_enable(self.ctx, int(on)), "crthip_profile_enable")

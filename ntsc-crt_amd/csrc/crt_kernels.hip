@@ -1143,6 +1143,9 @@ struct crthip_ctx {
     crthip_line *d_lines;
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
+    int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
+    hipStream_t aux_stream;
+    hipEvent_t ev_fork, ev_join;
     bool prof;
     double prof_ms[CRTHIP_K_COUNT];
     int prof_n[CRTHIP_K_COUNT];
@@ -1341,6 +1344,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         return CRTHIP_E_HIP;
     }
     c->stream = 0;              /* the device's default stream until crthip_set_stream() */
+    c->overlap_chunks = 1;
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;
@@ -1369,6 +1373,7 @@ void crthip_destroy(crthip_ctx *c)
     hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->npend; i++) { hipEventDestroy(c->pend[i].a); hipEventDestroy(c->pend[i].b); }
     free(c->pend);
+    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->d_jump16) hipFree(c->d_jump16);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
@@ -1557,6 +1562,41 @@ int crthip_decode(crthip_ctx *c, const crthip_params *p, int n, const signed cha
     return rc;
 }
 
+/* one chunk of a batch: fields [first, first+n) on the context's current stream */
+static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n,
+                           const void *d_images, size_t istride, void *d_out, size_t ostride, crthip_state *d_state)
+{
+    const unsigned char *img = (const unsigned char *) d_images + (size_t) first * istride;
+    unsigned char *out = (unsigned char *) d_out + (size_t) first * ostride;
+    crthip_state *st = d_state + first;
+    signed char *inp = c->d_inp + (size_t) first * c->fstride;
+    signed char *analog = c->d_analog + (size_t) first * c->fstride;
+    crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
+    int rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        if (enc == 0) {
+            /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
+            launch_encoder<S, true>(c, p, n, img, istride, inp, st, 1);
+            hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, st);
+        } else {
+            /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise */
+            hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
+            constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+            hipLaunchKernelGGL((k_noise<S>), dim3((n * CHUNKS + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, analog, inp, c->fstride, st, c->d_jump16);
+        }
+        return CRTHIP_OK;
+    });
+    if (rc) return rc;
+    if (p->out_bpp != 0) {
+        rc = launch_sync(c, p, n, inp, st, ln, 1);
+        if (rc) return rc;
+        rc = launch_decode(c, p, n, inp, ln, out, ostride);
+        if (rc) return rc;
+    }
+    return CRTHIP_OK;
+}
+
 int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                      void *d_out, size_t ostride, crthip_state *d_state)
 {
@@ -1572,29 +1612,41 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         rc = crthip_reserve(c, n);
         if (rc) return rc;
     }
-    rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
-        using S = decltype(tag);
-        if (enc == 0) {
-            /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
-            launch_encoder<S, true>(c, p, n, d_images, istride, c->d_inp, d_state, 1);
-            hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
-        } else {
-            /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise */
-            hipMemsetAsync(c->d_analog, 0, c->fstride * (size_t) n, c->stream);
-            constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
-            hipLaunchKernelGGL((k_noise<S>), dim3((n * CHUNKS + 255) / 256), dim3(256), 0, c->stream,
-                               *p, n, c->d_analog, c->d_inp, c->fstride, d_state, c->d_jump16);
+    /* Fields are independent, so a large batch is cut into chunks that alternate between the
+     * caller's stream and an internal one: the latency-bound kernels of one chunk (sync chain,
+     * margins, launch gaps) then overlap the VALU-bound kernels of the other.  The internal stream
+     * is fenced by events on both sides, so to the caller everything is still ordered on ITS stream. */
+    const int nchunks = (c->overlap_chunks > 1 && n >= 256 * c->overlap_chunks && !c->prof) ? c->overlap_chunks : 1;
+    if (nchunks == 1) {
+        rc = fieldpass_chunk(c, p, enc, 0, n, d_images, istride, d_out, ostride, d_state);
+    } else {
+        if (!c->aux_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
-        return CRTHIP_OK;
-    });
-    if (rc) return rc;
-    if (p->out_bpp != 0) {
-        rc = launch_sync(c, p, n, c->d_inp, d_state, c->d_lines, 1);
-        if (rc) return rc;
-        rc = launch_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
-        if (rc) return rc;
+        hipStream_t main_stream = c->stream;
+        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        const int per = ((n + nchunks - 1) / nchunks + 3) & ~3;
+        for (int k = 0, first = 0; first < n && rc == CRTHIP_OK; k++, first += per) {
+            const int cnt = n - first < per ? n - first : per;
+            c->stream = (k & 1) ? c->aux_stream : main_stream;
+            rc = fieldpass_chunk(c, p, enc, first, cnt, d_images, istride, d_out, ostride, d_state);
+        }
+        c->stream = main_stream;
+        HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
     }
+    if (rc) return rc;
     HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_overlap(crthip_ctx *c, int chunks)
+{
+    if (!c || chunks < 1 || chunks > 64) return CRTHIP_E_ARG;
+    c->overlap_chunks = chunks;
     return CRTHIP_OK;
 }
 
