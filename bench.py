@@ -165,6 +165,22 @@ def main():
                 traffic = traffic * n if traffic else None
             except Exception:
                 traffic = None
+        # integer-VALU roofline of the dominant kernel (the bound that actually binds at 640x480): its VALU
+        # instruction count per field comes from the committed SQ counter profile, an integer VALU
+        # instruction occupies a SIMD for 4 cycles (16 lanes/clk), 1024 SIMDs
+        valu = None
+        spath = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
+        if os.path.exists(spath) and dom == "decode" and (w, h) == (640, 480):
+            try:
+                kd = json.load(open(spath))["kernels"]["void k_decode<SysNTSC, true, false>"]
+                per_field = kd["SQ_INSTS_VALU"] / 4096.0
+                clk = kd["GRBM_GUI_ACTIVE"] / 8.0 / (kern_ms_profiled := 2.61e-3)   # Hz during the counter run
+                need_s = per_field * n * 4.0 / 1024.0 / clk
+                valu = {"bound": "int-valu", "insts_per_field": per_field, "clock_hz": clk,
+                        "min_kernel_ms": need_s * 1e3, "frac": need_s * 1e3 / kern_ms[dom],
+                        "source": "profiles/r01_sq_counters.json"}
+            except Exception:
+                valu = None
         out = {
             "metric": "frames/sec at 640x480 interlaced, bit-exact vs CPU; % HBM roofline",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,6 +197,7 @@ def main():
                          "kernel_ms": kern_ms,
                          "pipeline_achieved": abytes * n * args.steps / elapsed / 1e9,
                          "pipeline_frac": abytes * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "valu_roofline": valu,
                          "note": "640x480 is integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu:
