@@ -156,6 +156,13 @@ int  crthip_lines(int system);                               /* CRT_LINES      *
 size_t crthip_field_stride(int system, int chroma_pattern);  /* bytes between consecutive
                                    fields in analog[] / inp[] device buffers (>= INPUT_SIZE+CRTHIP_TAIL) */
 
+/* VHS only.  The reference's VHS noise is the C library's rand() stream (crt_core.c:344-351); on
+ * glibc that is y[n] = y[n-31] + y[n-3], rand() = y[n] >> 1.  The kernels take the generator state
+ * of every field as its 31-word history (the values preceding the next output), in/out, device
+ * resident, 32 words apart.  crthip_vhs_history_from_seed gives the history right after srand(seed). */
+int  crthip_vhs_history_from_seed(unsigned seed, unsigned hist[31]);
+int  crthip_vhs_bind_history(crthip_ctx *ctx, unsigned *d_hist);     /* n x 32 words, device */
+
 /* Context = one device + one stream + the jump tables of the noise LCG. */
 int  crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern);
 void crthip_destroy(crthip_ctx *ctx);

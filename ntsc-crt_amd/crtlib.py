@@ -87,6 +87,8 @@ def load_library():
     L.crthip_decode.argtypes = [vp, PP, ci, vp, vp, vp, sz]
     L.crthip_profile_enable.argtypes = [vp, ci]
     L.crthip_set_exact.argtypes = [vp, ci]
+    L.crthip_vhs_history_from_seed.argtypes = [C.c_uint, C.POINTER(C.c_uint)]
+    L.crthip_vhs_bind_history.argtypes = [vp, vp]
     L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
     _LIB = L
@@ -164,6 +166,12 @@ class CRT:
         self._lines = None
         self._settings = None
         self.use_stream(None)
+        self.vhs_hist = None
+        if self.sysid == SYSTEM_VHS:
+            # per-field rand() generator state (31-word history), see crthip_vhs_history_from_seed
+            self.vhs_hist = torch.zeros((n, 32), dtype=torch.int32, device=self.dev)
+            self._check(self.L.crthip_vhs_bind_history(self.ctx, C.c_void_p(self.vhs_hist.data_ptr())), "crthip_vhs_bind_history")
+            self.srand([1] * n)
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -290,6 +298,16 @@ class CRT:
         s.initialized = 1
 
     # ------------------------------------------------------------------ observation
+    def srand(self, seeds):
+        """VHS: put field k's rand() generator into the state right after srand(seeds[k])."""
+        import numpy as np
+        h = np.zeros((self.n, 32), dtype=np.uint32)
+        buf = (C.c_uint * 31)()
+        for k, sd in enumerate(seeds):
+            self._check(self.L.crthip_vhs_history_from_seed(C.c_uint(sd & 0xffffffff), buf), "crthip_vhs_history_from_seed")
+            h[k, :31] = np.frombuffer(buf, dtype=np.uint32)
+        self.vhs_hist.copy_(self.torch.from_numpy(h.view(np.int32)).to(self.dev))
+
     def set_exact(self, on=True):
         """Force the exact 32-bit-multiply kernels (normally only used outside the proven 24-bit envelope)."""
         self._check(self.L.crthip_set_exact(self.ctx, int(on)), "crthip_set_exact")

@@ -192,6 +192,56 @@ monitor_params(crthip_params *p, const struct CRT *v)
     p->h = 1;
 }
 
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+/*
+ * The VHS decoder consumes the process's rand() stream (crt_core.c:344-351).  To stay in step with
+ * the host program (video_convert.c seeds it, crt_modulate draws from it) the generator state is
+ * borrowed from the C library, advanced on the GPU, and put back:
+ *   setstate(scratch) returns the library's own state array; word 0 is the info word
+ *   (5 * rear_index + type, refreshed by that very setstate call), words 1..31 the ring.  The ring is
+ *   rewritten with the advanced history and re-installed with setstate(), which re-reads the info
+ *   word.  glibc's default TYPE_3 generator only (the reference's platform); anything else aborts.
+ */
+extern char *setstate(char *state);        /* POSIX (stdlib.h hides it under -std=c89) */
+
+static unsigned *d_hist_buf;
+
+static int *
+borrow_libc_rand(unsigned hist[31])
+{
+    static int scratch[34];
+    int *lib, info, rear, j;
+
+    scratch[0] = 3;                                 /* TYPE_3, rear index 0 */
+    lib = (int *) setstate((char *) scratch);
+    if (lib == 0) {
+        fatal("setstate", CRTHIP_E_ARG);
+    }
+    info = lib[0];
+    if (info % 5 != 3) {
+        setstate((char *) lib);
+        fatal("rand() is not glibc's TYPE_3 generator", CRTHIP_E_ARG);
+    }
+    rear = info / 5;
+    for (j = 0; j < 31; j++) {
+        hist[j] = (unsigned) lib[1 + (rear + 3 + j) % 31];
+    }
+    return lib;
+}
+
+static void
+return_libc_rand(int *lib, const unsigned hist[31])
+{
+    int j;
+
+    for (j = 0; j < 31; j++) {
+        lib[1 + (3 + j) % 31] = (int) hist[j];
+    }
+    lib[0] = 3;                                     /* rear index 0, TYPE_3 */
+    setstate((char *) lib);
+}
+#endif
+
 /* ---- public API ---------------------------------------------------------------------------- */
 
 extern int
@@ -320,7 +370,22 @@ crt_demodulate(struct CRT *v, int noise)
     CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
     CHECK(crthip_upload(g_ctx, sl->d_out, v->out, out_bytes));
     state_to_device(sl, v, 0, 0, 0);
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+    {
+        unsigned hist[32];
+        int *lib = borrow_libc_rand(hist);
+        if (d_hist_buf == 0) {
+            d_hist_buf = (unsigned *) dev_alloc(32 * sizeof(unsigned));
+        }
+        CHECK(crthip_upload(g_ctx, d_hist_buf, hist, 31 * sizeof(unsigned)));
+        CHECK(crthip_vhs_bind_history(g_ctx, d_hist_buf));
+        CHECK(crthip_noise(g_ctx, &p, 1, sl->d_analog, sl->d_inp, sl->d_state));
+        CHECK(crthip_download(g_ctx, hist, d_hist_buf, 31 * sizeof(unsigned)));
+        return_libc_rand(lib, hist);
+    }
+#else
     CHECK(crthip_noise(g_ctx, &p, 1, sl->d_analog, sl->d_inp, sl->d_state));
+#endif
     CHECK(crthip_sync(g_ctx, &p, 1, sl->d_inp, sl->d_state, sl->d_lines));
     CHECK(crthip_decode(g_ctx, &p, 1, sl->d_inp, sl->d_lines, sl->d_out, out_bytes));
     CHECK(crthip_download(g_ctx, v->inp, sl->d_inp, CRT_INPUT_SIZE));

@@ -618,6 +618,177 @@ k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ ana
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* D1, VHS flavour: noise from the C library's rand() stream                   */
+/* ------------------------------------------------------------------------- */
+/*
+ * crt_core.c:343-357.  rand() is modelled as glibc's y[n] = y[n-31] + y[n-3] (crt_setup.c).  Calls:
+ * #0 picks the band's phase (`line`); sample i then makes call A_i (its noise value) and call B_i
+ * (always), plus call C_i only when the first half of the && is true.  That can only happen for
+ * i > I0 = INPUT_SIZE - 25*HRES, so
+ *   - samples [0, I0] use calls 1+2i, 2+2i: PARALLEL, one lane per VHS_CHUNK samples; the lane's
+ *     31-value history at its first call K is obtained from the field's base history by the jump
+ *     y[K+j] = sum_m c_K[m] * y[m+j]  (c_K = x^K mod x^31-x^28-1, host-made table `rows`);
+ *   - samples (I0, INPUT_SIZE) have a data-dependent call count: ONE LANE PER FIELD walks them
+ *     serially with the generator's ring buffer in LDS ([index][lane], conflict-free), and hands
+ *     back the final history and rn.
+ * Both roles run in the same launch (blockIdx < blocks_a: role A).
+ */
+#define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 */
+
+__device__ __forceinline__ int dev_sine_q1(int a)
+{
+    /* crt_core.c:19-39 */
+    const int knots[18] = { 0, 3208, 6392, 9512, 12536, 15440, 18200, 20784, 23168,
+                            25328, 27240, 28896, 30272, 31352, 32136, 32608, 32768, 32608 };
+    const int k = (a >> 8) & 255, t = a & 255;
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < 17; q++) {
+        if (k == q) { lo = knots[q]; hi = knots[q + 1]; }
+    }
+    return lo + (((hi - lo) * t) >> 8);
+}
+/* cosine only (crt_core.c:42-61), 14-bit angle */
+__device__ __forceinline__ int dev_cos14(int n)
+{
+    n &= 16383;
+    const int a = n & 8191;
+    int cs = a < 4096 ? dev_sine_q1(4096 - a) : -dev_sine_q1(a - 4096);
+    if (n & 8192) cs = -cs;
+    return cs;
+}
+
+template <class S>
+__global__ void __launch_bounds__(64)
+k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+            signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
+            unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a, int blocks_a)
+{
+    constexpr int I0 = S::INPUT_SIZE - 25 * S::HRES;          /* last sample of the parallel region */
+    const int lane = threadIdx.x;
+    if ((int) blockIdx.x < blocks_a) {
+        /* ---- role A: parallel region ---------------------------------------------------- */
+        const int gid = blockIdx.x * 64 + lane;
+        if (gid >= n_fields * chunks_a) return;
+        const int f = gid / chunks_a;
+        const int q = gid - f * chunks_a;
+        const unsigned *h = hist + (size_t) f * 32;
+        /* base sequence z[0..60]: the history and the next 30 values */
+        unsigned z[61];
+#pragma unroll
+        for (int j = 0; j < 31; j++) z[j] = h[j];
+#pragma unroll
+        for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
+        /* history of call K = 1 + 248 q */
+        const unsigned *c = rows + (size_t) q * 31;
+        unsigned w[31];
+#pragma unroll
+        for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+        for (int m = 0; m < 31; m++) {
+            const unsigned cm = c[m];
+#pragma unroll
+            for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
+        }
+        const int i0 = q * VHS_CHUNK;
+        const signed char *src = analog + (size_t) f * fstride + i0;
+        signed char *dst = inp + (size_t) f * fstride + i0;
+        const int noise = P.noise;
+        /* 4 rounds of 62 calls = 31 samples each; ring index = call % 31 is static */
+        for (int r = 0; r < 4; r++) {
+            unsigned char outb[32];
+#pragma unroll
+            for (int t = 0; t < 62; t++) {
+                const unsigned v = w[t % 31] + w[(t + 28) % 31];
+                w[t % 31] = v;
+                if ((t & 1) == 0) {                                  /* call A of sample r*31 + t/2 */
+                    const int k = r * 31 + t / 2;
+                    const int rn = (int) (v >> 1);
+                    int s = 0;
+                    if (i0 + k <= I0) s = src[k];
+                    s = s + ((((rn >> 16) & 0xff) - 0x7f) * noise >> 8);
+                    outb[t / 2] = (unsigned char) clampi(s, -127, 127);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 31; k++) {
+                if (i0 + r * 31 + k <= I0) dst[r * 31 + k] = (signed char) outb[k];
+            }
+        }
+        return;
+    }
+    /* ---- role T: the last 25 lines, one lane per field ------------------------------------ */
+    __shared__ unsigned s_ring[31 * 64];
+    const int f = ((int) blockIdx.x - blocks_a) * 64 + lane;
+    const bool live = f < n_fields;
+    const int fc = live ? f : n_fields - 1;
+    unsigned *h = hist + (size_t) fc * 32;
+    unsigned z[61];
+#pragma unroll
+    for (int j = 0; j < 31; j++) z[j] = h[j];
+#pragma unroll
+    for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
+    const int vhs_line = (int) (((z[31] >> 1) & 7u)) - 4 + 14;        /* call #0, crt_core.c:344 */
+    {
+        const unsigned *c = rows + (size_t) chunks_a * 31;            /* x^(2*I0+3): first call of sample I0+1 */
+        unsigned w[31];
+#pragma unroll
+        for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+        for (int m = 0; m < 31; m++) {
+            const unsigned cm = c[m];
+#pragma unroll
+            for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 31; j++) s_ring[j * 64 + lane] = w[j];
+    }
+    int p = 0;                                                       /* ring slot of y[n-31] */
+    auto next = [&]() -> unsigned {
+        int p28 = p + 28;
+        if (p28 >= 31) p28 -= 31;
+        const unsigned v = s_ring[p * 64 + lane] + s_ring[p28 * 64 + lane];
+        s_ring[p * 64 + lane] = v;
+        if (++p == 31) p = 0;
+        return v >> 1;
+    };
+    const signed char *src = analog + (size_t) fc * fstride;
+    signed char *dst = inp + (size_t) fc * fstride;
+    const int noise = P.noise;
+    unsigned rn = 0;
+    unsigned pack = 0;
+    for (int i = I0 + 1; i < S::INPUT_SIZE; i++) {
+        int nn = noise;
+        rn = next();                                                  /* :349 */
+        const unsigned r2 = next();                                   /* :350 */
+        if (i > S::INPUT_SIZE - S::HRES * (16 + ((int) (r2 % 20u) - 10))) {
+            const unsigned r3 = next();                               /* :351 */
+            if (i < S::INPUT_SIZE - S::HRES * (5 + ((int) (r3 & 7u) - 4))) {
+                const int ln = (i * vhs_line) / S::HRES;              /* :354-356 */
+                nn = dev_cos14(ln * 8192 / 180) >> 8;
+            }
+        }
+        int s = src[i] + (((int) ((rn >> 16) & 0xffu) - 0x7f) * nn >> 8);
+        s = clampi(s, -127, 127);
+        /* INPUT_SIZE and I0+1 are even multiples of ... not necessarily of 4: plain byte stores */
+        if (live) dst[i] = (signed char) s;
+    }
+    (void) pack;
+    if (live) {
+        /* final history in logical order, rn, and the struct tail mirror */
+#pragma unroll
+        for (int j = 0; j < 31; j++) {
+            int q = p + j;
+            if (q >= 31) q -= 31;
+            h[j] = s_ring[q * 64 + lane];
+        }
+        state[f].rn = (int) rn;                                       /* crt_core.c:367 */
+        signed char *tail = dst + S::INPUT_SIZE;
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+    }
+}
+
 /* rn <- rn after INPUT_SIZE steps (crt_core.c:367) */
 __global__ void k_advance_rn(int n_fields, crthip_state *state, uint2 whole_field)
 {
@@ -1143,6 +1314,9 @@ struct crthip_ctx {
     crthip_line *d_lines;
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
+    unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words */
+    int vhs_chunks;
+    unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join;
@@ -1362,6 +1536,23 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         return CRTHIP_E_HIP;
     }
     free(h);
+    if (system == CRTHIP_SYSTEM_NTSCVHS) {
+        /* jump coefficients of the rand() recurrence: one row per parallel chunk + one for the tail */
+        const int i0 = sd.input_size - 25 * sd.hres;
+        const int chunks = (i0 + 1 + 124 - 1) / 124;
+        unsigned *rows = (unsigned *) malloc(sizeof(unsigned) * 31 * (size_t) (chunks + 1));
+        if (!rows) { crthip_destroy(c); return CRTHIP_E_NOMEM; }
+        crt_setup_vhs_power_table(1ul, 248ul, chunks, rows);
+        crt_setup_vhs_power(2ul * (unsigned long) i0 + 3ul, rows + 31 * (size_t) chunks);
+        c->vhs_chunks = chunks;
+        if (hipMalloc((void **) &c->d_vhs_rows, sizeof(unsigned) * 31 * (size_t) (chunks + 1)) != hipSuccess ||
+            hipMemcpy(c->d_vhs_rows, rows, sizeof(unsigned) * 31 * (size_t) (chunks + 1), hipMemcpyHostToDevice) != hipSuccess) {
+            free(rows);
+            crthip_destroy(c);
+            return CRTHIP_E_HIP;
+        }
+        free(rows);
+    }
     *out = c;
     return CRTHIP_OK;
 }
@@ -1375,6 +1566,7 @@ void crthip_destroy(crthip_ctx *c)
     free(c->pend);
     if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->d_jump16) hipFree(c->d_jump16);
+    if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
@@ -1464,9 +1656,21 @@ int crthip_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char
     int rc = check_params(c, p, n);
     if (rc) return rc;
     if (p->out_bpp == 0) return CRTHIP_OK;                       /* crt_core.c:312-315 */
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS) return set_err(c, CRTHIP_E_ARG, "VHS rand() noise not implemented yet", hipSuccess);
     if (!d_analog || !d_inp || !d_state) return CRTHIP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+        if (!c->d_vhs_hist) return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
+        rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+            using S = decltype(tag);
+            ProfScope ps(c, CRTHIP_K_NOISE);
+            const int blocks_a = (n * c->vhs_chunks + 63) / 64, blocks_t = (n + 63) / 64;
+            hipLaunchKernelGGL((k_vhs_noise<S>), dim3(blocks_a + blocks_t), dim3(64), 0, c->stream,
+                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks, blocks_a);
+            return CRTHIP_OK;
+        });
+        HIPCHK(c, hipGetLastError());
+        return rc;
+    }
     rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
@@ -1572,6 +1776,30 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     signed char *inp = c->d_inp + (size_t) first * c->fstride;
     signed char *analog = c->d_analog + (size_t) first * c->fstride;
     crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+        /* VHS noise follows the C library's rand() stream, not the LCG: encode into a clean analog[],
+         * then the dedicated noise kernel (which also produces rn) */
+        hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
+        int r = CRTHIP_OK;
+        if (enc == 0) {
+            r = dispatch_system(c->system, c->pattern, [&](auto tag) {
+                using S = decltype(tag);
+                launch_encoder<S, false>(c, p, n, img, istride, analog, st, 0);
+                hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, st);
+                return CRTHIP_OK;
+            });
+        }
+        if (r) return r;
+        if (p->out_bpp == 0) return CRTHIP_OK;
+        unsigned *saved = c->d_vhs_hist;
+        c->d_vhs_hist = saved + (size_t) first * 32;
+        r = crthip_noise(c, p, n, analog, inp, st);
+        c->d_vhs_hist = saved;
+        if (r) return r;
+        r = launch_sync(c, p, n, inp, st, ln, 0);
+        if (r) return r;
+        return launch_decode(c, p, n, inp, ln, out, ostride);
+    }
     int rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         if (enc == 0) {
@@ -1603,7 +1831,8 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     int rc = check_params(c, p, n);
     if (rc) return rc;
     if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS) return set_err(c, CRTHIP_E_ARG, "VHS rand() noise not implemented yet", hipSuccess);
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !c->d_vhs_hist)
+        return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
     if (p->out_bpp != 0 && p->outh < c->sd.lines) return set_err(c, CRTHIP_E_ARG, "outh < CRT_LINES not supported", hipSuccess);
     int enc = check_encoder(c, p);
     if (enc < 0) return enc;
@@ -1647,6 +1876,13 @@ int crthip_set_overlap(crthip_ctx *c, int chunks)
 {
     if (!c || chunks < 1 || chunks > 64) return CRTHIP_E_ARG;
     c->overlap_chunks = chunks;
+    return CRTHIP_OK;
+}
+
+int crthip_vhs_bind_history(crthip_ctx *c, unsigned *d_hist)
+{
+    if (!c || c->system != CRTHIP_SYSTEM_NTSCVHS) return CRTHIP_E_ARG;
+    c->d_vhs_hist = d_hist;
     return CRTHIP_OK;
 }
 

@@ -364,3 +364,117 @@ crthip_params_finalize(crthip_params *p)
     p->finalized = CRTHIP_PARAMS_MAGIC;
     return CRTHIP_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* VHS: the C library's rand() (crt_core.c:344,349-351; crt_ntscvhs.c:206)    */
+/* ------------------------------------------------------------------------- */
+/*
+ * The reference's VHS noise is whatever the process's rand() returns; on the platform the reference
+ * is built for (glibc) that is random()'s TYPE_3 additive feedback generator:
+ *     y[n] = y[n-31] + y[n-3]  (mod 2^32),   rand() = y[n] >> 1
+ * seeded by srand(seed): y[0] = seed, y[i] = 16807*y[i-1] mod (2^31-1) for i < 31, y[31..33] =
+ * y[0..2], and the first 310 outputs discarded.  A generator state is handed to the kernels as its
+ * "history": the 31 values y[n-31 .. n-1] that precede the next output.
+ */
+int
+crthip_vhs_history_from_seed(unsigned seed, unsigned hist[31])
+{
+    unsigned y[34 + 310 + 31];
+    int i;
+    long word;
+
+    if (hist == 0) {
+        return CRTHIP_E_ARG;
+    }
+    if (seed == 0) {
+        seed = 1;
+    }
+    y[0] = seed;
+    word = (long) (int) seed;
+    for (i = 1; i < 31; i++) {
+        /* Schrage: 16807 * word mod 2147483647 without overflow (glibc srandom_r) */
+        long hi = word / 127773;
+        long lo = word % 127773;
+        word = 16807 * lo - 2836 * hi;
+        if (word < 0) {
+            word += 2147483647;
+        }
+        y[i] = (unsigned) word;
+    }
+    for (i = 31; i < 34; i++) {
+        y[i] = y[i - 31];
+    }
+    for (i = 34; i < 34 + 310; i++) {
+        y[i] = y[i - 31] + y[i - 3];
+    }
+    /* the next output is y[344]; its history is y[313 .. 343] */
+    for (i = 0; i < 31; i++) {
+        hist[i] = y[313 + i];
+    }
+    return CRTHIP_OK;
+}
+
+/* coefficients of x^k modulo x^31 - x^28 - 1 over Z/2^32: y[a+k] = sum_m c[m] * y[a+m] */
+static void
+poly_mul_mod(const unsigned *a, const unsigned *b, unsigned *out)
+{
+    unsigned t[61];
+    int i, j;
+
+    for (i = 0; i < 61; i++) {
+        t[i] = 0;
+    }
+    for (i = 0; i < 31; i++) {
+        if (a[i] == 0) {
+            continue;
+        }
+        for (j = 0; j < 31; j++) {
+            t[i + j] += a[i] * b[j];
+        }
+    }
+    for (i = 60; i >= 31; i--) {       /* x^i = x^(i-3) + x^(i-31) */
+        t[i - 3] += t[i];
+        t[i - 31] += t[i];
+    }
+    for (i = 0; i < 31; i++) {
+        out[i] = t[i];
+    }
+}
+
+void
+crt_setup_vhs_power(unsigned long k, unsigned c[31])
+{
+    unsigned base[31], acc[31], tmp[31];
+    int i;
+
+    for (i = 0; i < 31; i++) {
+        base[i] = 0;
+        acc[i] = 0;
+    }
+    base[1] = 1;    /* x   */
+    acc[0] = 1;     /* 1   */
+    while (k) {
+        if (k & 1ul) {
+            poly_mul_mod(acc, base, tmp);
+            memcpy(acc, tmp, sizeof(acc));
+        }
+        poly_mul_mod(base, base, tmp);
+        memcpy(base, tmp, sizeof(base));
+        k >>= 1;
+    }
+    memcpy(c, acc, sizeof(acc));
+}
+
+/* rows[q] = coefficients of x^(first + q*step), q = 0 .. count-1 */
+void
+crt_setup_vhs_power_table(unsigned long first, unsigned long step, int count, unsigned *rows)
+{
+    unsigned stepc[31];
+    int q;
+
+    crt_setup_vhs_power(step, stepc);
+    crt_setup_vhs_power(first, rows);
+    for (q = 1; q < count; q++) {
+        poly_mul_mod(rows + 31 * (q - 1), stepc, rows + 31 * q);
+    }
+}

@@ -93,6 +93,39 @@ def test_nes_dropin(name, outsz):
         R.compare_state(a, b, "%s step %d" % (name, step))
 
 
+@pytest.mark.parametrize("aberration", [0, 1])
+def test_vhs_dropin_shares_the_libc_rand_stream(aberration):
+    """video_convert.c semantics: the program seeds rand(), crt_modulate draws the aberration height
+    from it, crt_demodulate consumes ~500k values per field.  The HIP library borrows the generator
+    from libc, advances it on the GPU and puts it back: after every call the NEXT rand() of the
+    process must be what it would have been with the reference."""
+    import ctypes as C
+    libc = C.CDLL(None)
+    hip = R.RefLib("vhs", dropin=True)
+    chk = _checker("vhs")
+    img = R.synth_image(832, 624, 4, 9)
+    a, b = hip.new_crt(832, 624, R.FMT_BGRA), chk.new_crt(832, 624, R.FMT_BGRA)
+    for c in (a, b):
+        c.settings(img, format=R.FMT_BGRA, w=832, h=624, as_color=1, do_aberration=aberration)
+    probes = []
+    for c in (a, b):
+        libc.srand(4242)
+        seq = []
+        for step in range(3):
+            c.modulate()
+            c.demodulate(12)
+            seq.append(libc.rand())                       # the process's own next draw
+            c.sset("field", c.sget("field") ^ 1)
+        probes.append(seq)
+    assert probes[0] == probes[1]
+    np.testing.assert_array_equal(a.analog, b.analog)
+    np.testing.assert_array_equal(a.inp, b.inp)
+    for f in R.STATE_FIELDS:
+        assert a.get(f) == b.get(f), f
+    if not aberration:
+        np.testing.assert_array_equal(a.out, b.out)
+
+
 def _write_ppm(path, w, h, seed):
     img = R.synth_image(w, h, 3, seed, "bars")
     with open(path, "wb") as f:

@@ -234,8 +234,62 @@ def test_vhs_encoder_parity(crtlib, aberration):
         np.testing.assert_array_equal(an[k, :orc.input_size], c.analog, err_msg="vhs analog %d" % k)
         np.testing.assert_array_equal(g.ccf[k, :1], c.ccf)
         assert g.get("hsync")[k] == c.get("hsync") == 0
-    with pytest.raises(RuntimeError):
-        g.demodulate(0)
+    g.close()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("noise", [0, 12, 40])
+def test_vhs_fieldpass_parity(crtlib, fused, noise):
+    """BASELINE configs[3]: CRT_SYSTEM_NTSCVHS, 832x624.  The decoder's noise is the C library's rand()
+    stream (crt_core.c:344-351): field k's generator starts at srand(seed_k) and carries over from
+    step to step, so the oracle processes each field's whole sequence under its own libc stream.
+    (The aberration band draws from the same stream in crt_modulate; that interplay is covered by the
+    drop-in test, where the host draws it exactly like the reference.)"""
+    import ctypes as C
+    libc = C.CDLL(None)
+    n, w, h, steps = 3, 832, 624, 3
+    seeds = [1, 77, 20260924]
+    imgs = np.stack([R.synth_image(w, h, 4, 60 + k, "random" if k != 1 else "bars") for k in range(n)])
+    orc = R.Oracle("vhs")
+    want = []
+    for k in range(n):
+        c = orc.new_crt(w, h, R.FMT_BGRA)
+        c.set("scanlines", 1)
+        c.settings(np.concatenate([imgs[k], imgs[k][-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1, field=k & 1, frame=0,
+                   do_aberration=0)
+        libc.srand(seeds[k])
+        per = []
+        for step in range(steps):
+            if fused:
+                c.analog[:] = 0                        # batch semantics: clean analog[] per field-pass
+            c.modulate()
+            c.demodulate(noise)
+            per.append((c.inp.copy(), c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn"), c.ccf.copy()))
+            c.sset("field", c.sget("field") ^ 1)
+        want.append(per)
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "vhs", device=0)
+    g.scanlines = 1
+    g.srand(seeds)
+    fields = [k & 1 for k in range(n)]
+    s = crtlib.Settings(_padded(imgs), format=crtlib.FMT_BGRA, field=list(fields), frame=0)
+    for step in range(steps):
+        if fused:
+            g.fieldpass(s, noise)
+        else:
+            g.modulate(s)
+            g.demodulate(noise)
+        g.synchronize()
+        gout = g.out.cpu().numpy()
+        for k in range(n):
+            inp, out, hs, vs, rn, ccf = want[k][step]
+            what = "vhs fused=%s noise %d step %d field %d" % (fused, noise, step, k)
+            if not fused:
+                np.testing.assert_array_equal(g.inp[k, :orc.input_size].cpu().numpy(), inp, err_msg=what + " inp")
+            assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), what
+            np.testing.assert_array_equal(g.ccf[k, :1], ccf, err_msg=what + " ccf")
+            np.testing.assert_array_equal(gout[k].reshape(-1), out, err_msg=what + " out")
+        fields = [f ^ 1 for f in fields]
+        s.field = list(fields)
     g.close()
 
 
