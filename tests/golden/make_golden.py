@@ -36,6 +36,9 @@ CASES = [
     dict(id="ntsc_rgb24_raw_mono_832x624", sys="ntsc", w=320, h=200, ifmt=R.FMT_RGB, outw=832, outh=624,
          ofmt=R.FMT_RGB, noise=40, knobs=dict(hue=17, saturation=14, brightness=3), settings=dict(as_color=0, raw=1),
          steps=3, interlaced=True, image=("bars", 5)),
+    dict(id="cfg4_vhs_832x624_srand_per_step", sys="vhs", w=832, h=624, ifmt=R.FMT_BGRA, outw=832, outh=624,
+         ofmt=R.FMT_BGRA, noise=12, knobs=dict(scanlines=1), settings=dict(as_color=1, do_aberration=0), steps=3,
+         interlaced=True, image=("random", 4), srand=1000),        # glibc rand(): srand(1000 + step) before each pass
     dict(id="cfg5_nes_pattern0_256x240_to_640x480", sys="nesp0", w=256, h=240, outw=640, outh=480, ofmt=R.FMT_BGRA,
          noise=12, knobs=dict(), settings=dict(hue=0), steps=3, image=("ppu", 99)),
     dict(id="nes_pattern2_256x240_to_640x480", sys="nes", w=256, h=240, outw=640, outh=480, ofmt=R.FMT_BGRA,
@@ -67,6 +70,8 @@ def run_case(lib, case, on_step):
             c.settings(img, w=case["w"], h=case["h"], dot_crawl_offset=step % 3, **case["settings"])
         elif step == 0:
             c.settings(img, format=case["ifmt"], w=case["w"], h=case["h"], field=0, frame=0, **case["settings"])
+        if "srand" in case:
+            lib.srand(case["srand"] + step)
         c.modulate()
         analog = c.analog.copy()
         c.demodulate(case["noise"])

@@ -45,7 +45,11 @@ class _HipLib:
         self.crtlib, self.name = crtlib, name
 
     def new_crt(self, outw, outh, fmt):
-        return _HipCRT(self, outw, outh, fmt)
+        self.last = _HipCRT(self, outw, outh, fmt)
+        return self.last
+
+    def srand(self, seed):
+        self.last.g.srand([seed])
 
 
 class _HipCRT:
@@ -79,6 +83,7 @@ class _HipCRT:
         else:
             self.s = self.L.Settings(full[:, :h], format=k["format"], raw=k.get("raw", 0), as_color=k.get("as_color", 0),
                                      field=k.get("field", 0), frame=k.get("frame", 0), hue=k.get("hue", 0))
+            assert not k.get("do_aberration", 0)
         self.s.initialized = init
 
     def sget(self, k):
