@@ -25,7 +25,8 @@ LINE_INTS = 6        # sizeof(crthip_line) / 4
 # columns of the state tensor
 ST_FIELD, ST_FRAME, ST_AUX, ST_HSYNC, ST_VSYNC, ST_RN, ST_CCF, ST_ODD = 0, 1, 2, 3, 4, 5, 6, 18
 
-SYSTEMS = {"ntsc": (SYSTEM_NTSC, 1), "vhs": (SYSTEM_VHS, 1), "nes": (SYSTEM_NES, 2), "nesp0": (SYSTEM_NES, 0)}
+SYSTEMS = {"ntsc": (SYSTEM_NTSC, 1), "vhs": (SYSTEM_VHS, 1), "nes": (SYSTEM_NES, 2), "nesp0": (SYSTEM_NES, 0),
+           "ntscp0": (SYSTEM_NTSC, 0)}
 
 
 class Params(C.Structure):

@@ -30,7 +30,7 @@ PIN(outw_follows_inp, offsetof(struct CRT, outw) == ((2 * CRT_INPUT_SIZE + 3) & 
 PIN(out_is_pointer_aligned, offsetof(struct CRT, out) % sizeof(void *) == 0);
 PIN(ccf_shape, sizeof(((struct CRT *) 0)->ccf) == CRT_CC_VPER * CRT_CC_SAMPLES * sizeof(int));
 PIN(rn_last, offsetof(struct CRT, rn) + sizeof(int) <= sizeof(struct CRT));
-#if (CRT_SYSTEM == CRT_SYSTEM_NTSC)
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSC) && (CRT_CHROMA_PATTERN == 1)
 PIN(ntsc_sizeof_crt, sizeof(void *) != 8 || sizeof(struct CRT) == 476928);    /* SURVEY.md section 8b */
 PIN(ntsc_sizeof_settings, sizeof(void *) != 8 || sizeof(struct NTSC_SETTINGS) == 56);
 PIN(ntsc_hres, CRT_HRES == 910 && AV_LEN == 753 && AV_BEG == 156);

@@ -90,6 +90,9 @@ static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES ==
               SysNES0::AV_LEN == 684, "NES timing (SURVEY.md section 8)");
 
 #define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
+#define CRTHIP_LINE_NROWS_MASK 0xffff     /* crthip_line.nrows bits 0-15: rows written              */
+#define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-29: rank among lines starting on the same row   */
+#define CRTHIP_LINE_RANK_MASK  0x3fff
 #define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
 #define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
 #define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
@@ -934,6 +937,7 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
     __syncthreads();
 
     const unsigned span = (unsigned) P.outh + P.v_fac;
+    int prev_beg = -1, rank = 0;                          /* row collisions when outh + v_fac < LINES */
     for (int line = S::TOP; line < S::BOT; line++) {
         /* speculative fetch of the window of line + 2 (see the comment above) */
         const int base_n = window_base(line + 2, hsync);
@@ -946,6 +950,12 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         int end = (int) ((unsigned) (line - S::TOP + 1) * span / (unsigned) S::LINES + (unsigned) field_rows);
         const bool skip = beg >= P.outh;                               /* :431, row-uniform */
         if (end > P.outh) end = P.outh;
+        if (!skip) {
+            /* several lines can start on the same output row (outh + v_fac < LINES); the reference
+             * handles them one after the other, so they are decoded in rank order by separate passes */
+            rank = beg == prev_beg ? rank + 1 : 0;
+            prev_beg = beg;
+        }
 
         /* D5 hsync, crt_core.c:437-450.  0 <= vsync < VRES (k_vsync), so one conditional subtract wraps */
         int lidx = line + vsync;
@@ -1031,6 +1041,8 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
                 int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
                 nrows = nrows < 1 ? 1 : nrows;
                 /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
+                if (nrows > CRTHIP_LINE_NROWS_MASK) nrows = CRTHIP_LINE_NROWS_MASK;
+                nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
                 if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
                     nrows |= CRTHIP_LINE_EXACT;
                 lp.nrows = nrows;
@@ -1123,11 +1135,13 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
 #define PX_PIECES    (PX_TILE / 4)         /* 16-byte pieces per tile row                       */
 #define PX_STRIDE    (PX_TILE + 1)
 
-/* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line */
+/* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line;
+ * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
 template <class S, bool FAST, bool BPP3>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int want_exact)
+         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int want_exact,
+         int want_rank)
 {
     __shared__ unsigned s_in[64 * IN_STRIDE];
     __shared__ unsigned s_px[64 * PX_STRIDE];
@@ -1142,8 +1156,9 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const int f = live ? gid / S::LINES : 0;
     if (live) lp = lines[gid];
     const int exact = (lp.nrows & CRTHIP_LINE_EXACT) ? 1 : 0;
-    int nrows = lp.nrows & ~CRTHIP_LINE_EXACT;
-    if (!live || (want_exact >= 0 && exact != want_exact)) nrows = 0;
+    int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
+    if (!live || (want_exact >= 0 && exact != want_exact) || rank != want_rank) nrows = 0;
     if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
     const bool act = nrows > 0;
     constexpr int bpp = BPP3 ? 3 : 4;
@@ -1724,29 +1739,26 @@ static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const sig
                          const crthip_line *d_lines, void *d_out, size_t ostride)
 {
     const bool fast = fast_path_ok(p) && !c->force_exact;
+    /* lines per output row when the picture is shorter than the raster: one pass per rank */
+    const unsigned span = (unsigned) p->outh + p->v_fac;
+    const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         const int total = n * S::LINES;
         const dim3 grid((total + 63) / 64), block(64);
         unsigned char *o = (unsigned char *) d_out;
-        if (p->out_bpp == 3) {
-            if (fast) {
-                { ProfScope ps(c, CRTHIP_K_DECODE);
-                  hipLaunchKernelGGL((k_decode<S, true, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 0); }
-                hipLaunchKernelGGL((k_decode<S, false, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 1);
+        ProfScope ps(c, CRTHIP_K_DECODE);
+        for (int rank = 0; rank < passes; rank++) {
+#define CRTHIP_LAUNCH_DECODE(FASTK, B3, WANT) \
+    hipLaunchKernelGGL((k_decode<S, FASTK, B3>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, WANT, rank)
+            if (p->out_bpp == 3) {
+                if (fast) { CRTHIP_LAUNCH_DECODE(true, true, 0); CRTHIP_LAUNCH_DECODE(false, true, 1); }
+                else CRTHIP_LAUNCH_DECODE(false, true, -1);
             } else {
-                ProfScope ps(c, CRTHIP_K_DECODE);
-                hipLaunchKernelGGL((k_decode<S, false, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, -1);
+                if (fast) { CRTHIP_LAUNCH_DECODE(true, false, 0); CRTHIP_LAUNCH_DECODE(false, false, 1); }
+                else CRTHIP_LAUNCH_DECODE(false, false, -1);
             }
-        } else {
-            if (fast) {
-                { ProfScope ps(c, CRTHIP_K_DECODE);
-                  hipLaunchKernelGGL((k_decode<S, true, false>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 0); }
-                hipLaunchKernelGGL((k_decode<S, false, false>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, 1);
-            } else {
-                ProfScope ps(c, CRTHIP_K_DECODE);
-                hipLaunchKernelGGL((k_decode<S, false, false>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, -1);
-            }
+#undef CRTHIP_LAUNCH_DECODE
         }
         return CRTHIP_OK;
     });
@@ -1759,7 +1771,6 @@ int crthip_decode(crthip_ctx *c, const crthip_params *p, int n, const signed cha
     if (rc) return rc;
     if (p->out_bpp == 0) return CRTHIP_OK;
     if (!d_inp || !d_lines || !d_out) return CRTHIP_E_ARG;
-    if (p->outh < c->sd.lines) return set_err(c, CRTHIP_E_ARG, "outh < CRT_LINES (row collisions) not supported by the parallel decoder", hipSuccess);
     HIPCHK(c, hipSetDevice(c->device));
     rc = launch_decode(c, p, n, d_inp, d_lines, d_out, ostride);
     HIPCHK(c, hipGetLastError());
@@ -1833,7 +1844,6 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
     if (c->system == CRTHIP_SYSTEM_NTSCVHS && !c->d_vhs_hist)
         return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
-    if (p->out_bpp != 0 && p->outh < c->sd.lines) return set_err(c, CRTHIP_E_ARG, "outh < CRT_LINES not supported", hipSuccess);
     int enc = check_encoder(c, p);
     if (enc < 0) return enc;
     HIPCHK(c, hipSetDevice(c->device));

@@ -28,6 +28,7 @@ SYSTEMS = {
     "vhs": (SYS_VHS, 1, "libref_vhs.so"),
     "nes": (SYS_NES, 2, "libref_nes.so"),
     "nesp0": (SYS_NES, 0, "libref_nesp0.so"),
+    "ntscp0": (SYS_NTSC, 0, "libref_ntscp0.so"),
 }
 
 
@@ -47,7 +48,8 @@ PKG_LIB = os.path.join(ROOT, "ntsc-crt_amd", "lib")
 DROPIN = {"ntsc": ("libntsccrt_hip_ntsc.so", ["-DCRT_SYSTEM=0"]),
           "vhs": ("libntsccrt_hip_vhs.so", ["-DCRT_SYSTEM=5"]),
           "nes": ("libntsccrt_hip_nes.so", ["-DCRT_SYSTEM=1"]),
-          "nesp0": ("libntsccrt_hip_nesp0.so", ["-DCRT_SYSTEM=1", "-DCRT_CHROMA_PATTERN=0"])}
+          "nesp0": ("libntsccrt_hip_nesp0.so", ["-DCRT_SYSTEM=1", "-DCRT_CHROMA_PATTERN=0"]),
+          "ntscp0": ("libntsccrt_hip_ntscp0.so", ["-DCRT_SYSTEM=0", "-DCRT_CHROMA_PATTERN=0"])}
 
 
 def build_dropin_probe(name):

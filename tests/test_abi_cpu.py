@@ -48,7 +48,7 @@ def test_struct_sizes_match_header(lib):
     assert c == 4 * lib.LINE_INTS
 
 
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0"])
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0", "ntscp0"])
 def test_host_setup_matches_oracle(lib, name):
     orc = R.Oracle(name)
     L = lib.load_library()
@@ -62,8 +62,9 @@ def test_host_setup_matches_oracle(lib, name):
     assert list(p.eq_lf) == list(orc.sys.eq_lf)
     assert list(p.eq_hf) == list(orc.sys.eq_hf)
     assert [list(r) for r in p.eq_g] == [list(r) for r in orc.sys.eq_g]
-    if name in ("ntsc", "vhs"):
+    if name in ("ntsc", "vhs", "ntscp0"):
         assert list(p.iir_c) == list(orc.sys.iir_c)
+    if name in ("ntsc", "vhs"):
         assert (p.destw, p.desth, p.xo, p.yo) == (753, 236, 156, 23)
     s, c = orc.sincos14(((340 % 360) + 33) * 8192 // 180)
     assert (p.huesn, p.huecs) == (s >> 11, c >> 11)

@@ -20,7 +20,7 @@ def _built():
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0"])
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0", "ntscp0"])
 def test_struct_layout_identical_to_reference(name):
     ref = R.RefLib(name)
     ours = R.RefLib(name, dropin=True)
@@ -34,7 +34,7 @@ def test_struct_layout_identical_to_reference(name):
         assert getattr(ours.lib, fn)() == getattr(ref.lib, fn)(), fn
 
 
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0"])
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0", "ntscp0"])
 def test_dropin_exports_the_reference_api(name):
     lib = os.path.join(R.PKG_LIB, R.DROPIN[name][0])
     syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout

@@ -78,6 +78,21 @@ def test_caller_edits_between_calls_are_honoured():
     R.compare_state(a, b, "after edits")
 
 
+def test_ntsc_pattern0_dropin():
+    hip = R.RefLib("ntscp0", dropin=True)
+    chk = _checker("ntscp0")
+    img = R.synth_image(640, 480, 4, 11)
+    a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+    for c in (a, b):
+        c.settings(img, format=R.FMT_BGRA, w=640, h=480, as_color=1)
+    for step in range(3):
+        for c in (a, b):
+            c.modulate()
+            c.demodulate(24)
+            c.sset("field", c.sget("field") ^ 1)
+        R.compare_state(a, b, "ntscp0 step %d" % step)
+
+
 @pytest.mark.parametrize("name,outsz", [("nes", (640, 480)), ("nesp0", (512, 480))])
 def test_nes_dropin(name, outsz):
     hip = R.RefLib(name, dropin=True)

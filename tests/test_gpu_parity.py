@@ -64,6 +64,13 @@ CASES = [
     # ... and huge brightness / contrast / white point (host-side check picks the exact kernels)
     ("ntsc", 640, 480, R.FMT_RGBA, 640, 480, R.FMT_RGBA, 10, dict(as_color=1), dict(brightness=200000, contrast=9000000, white_point=9000000)),
     ("ntsc", 320, 240, R.FMT_BGRA, 320, 240, R.FMT_BGRA, 50000000, dict(as_color=1), dict(saturation=-70)),
+    # standard NTSC built with CRT_CHROMA_PATTERN 0 (HRES 912, vertical chroma, no phase flip)
+    ("ntscp0", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1, hue=40), dict(scanlines=1)),
+    ("ntscp0", 832, 624, R.FMT_RGB, 320, 240, R.FMT_BGR, 0, dict(as_color=1, raw=1), dict(blend=1)),
+    # outh < CRT_LINES: several CRT lines land on one output row; sequential semantics incl. blend chains
+    ("ntsc", 640, 200, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(blend=1)),
+    ("ntsc", 101, 77, R.FMT_RGB, 64, 48, R.FMT_RGB, 10, dict(as_color=1), dict(scanlines=1)),
+    ("ntsc", 64, 120, R.FMT_ABGR, 64, 48, R.FMT_BGRA, 0, dict(as_color=1), dict(blend=1, v_fac=30)),
 ]
 
 

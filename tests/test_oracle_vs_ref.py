@@ -76,7 +76,7 @@ NTSC_CASES = [
 
 @needs_ref
 @pytest.mark.parametrize("case", range(len(NTSC_CASES)))
-@pytest.mark.parametrize("name", ["ntsc", "vhs"])
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "ntscp0"])
 def test_fieldpass_sequence_matches_reference(name, case):
     outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = NTSC_CASES[case]
     pair = _pair(name, outw, outh, ofmt)
