@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--scanlines", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--pixel-tile", type=int, default=0, help="decoder output tile: 0 auto, 16, 32")
     ap.add_argument("--overlap", type=int, default=1, help="chunks alternating between two streams")
     args = ap.parse_args()
 
@@ -103,11 +105,16 @@ def main():
     crt.scanlines = args.scanlines
     crt.reserve(n)
     crt.set_overlap(args.overlap)
+    crt.set_pixel_tile(args.pixel_tile)
 
     # synthetic input, generated on the device: uniform random BGRA bytes per frame
+    # (at most `--unique` distinct random frames, tiled to the batch: the kernels' work is data-independent,
+    #  and generating tens of GB of random bytes would dominate the run)
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
-    images = torch.randint(0, 256, (n, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)[:, :h]
+    uniq = min(n, args.unique)
+    base = torch.randint(0, 256, (uniq, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
+    images = base.repeat((n + uniq - 1) // uniq, 1, 1, 1)[:n][:, :h]
     # this rank's contiguous block of the global batch: frames [rank*n, (rank+1)*n)
     parity = [shard.field_parity(rank * n + k) for k in range(n)]
     s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,

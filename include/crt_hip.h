@@ -217,6 +217,9 @@ int  crthip_decode(crthip_ctx *ctx, const crthip_params *p, int n,
  * kernels of one piece overlap the ALU-bound kernels of the next.  1 = off (default). */
 int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
 
+/* Decoder output tile: 16 or 32 pixels per row and flush (0 = choose by output width, default). */
+int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
+
 /* The decoder and encoder normally run kernels whose multiplies are the full-rate 24-bit
  * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,
  * "24-bit multiply envelope"), everything else goes to the exact 32-bit instantiation.  Both

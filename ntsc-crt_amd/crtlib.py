@@ -91,6 +91,7 @@ def load_library():
     L.crthip_vhs_history_from_seed.argtypes = [C.c_uint, C.POINTER(C.c_uint)]
     L.crthip_vhs_bind_history.argtypes = [vp, vp]
     L.crthip_set_overlap.argtypes = [vp, ci]
+    L.crthip_set_pixel_tile.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
     _LIB = L
     return L
@@ -316,6 +317,9 @@ class CRT:
     def set_overlap(self, chunks):
         """fieldpass(): split the batch into `chunks` pieces alternating between two streams."""
         self._check(self.L.crthip_set_overlap(self.ctx, int(chunks)), "crthip_set_overlap")
+
+    def set_pixel_tile(self, px):
+        self._check(self.L.crthip_set_pixel_tile(self.ctx, int(px)), "crthip_set_pixel_tile")
 
     def profile(self, on=True):
         self._check(self.L.crthip_profile_enable(self.ctx, int(on)), "crthip_profile_enable")

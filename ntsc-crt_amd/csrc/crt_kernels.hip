@@ -1131,19 +1131,19 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  */
 #define IN_TILE_DW   16                    /* decoder input tile: 64 samples per row            */
 #define IN_STRIDE    (IN_TILE_DW + 1)
-#define PX_TILE      16                    /* decoder output tile: pixels per row (16 or 32)    */
-#define PX_PIECES    (PX_TILE / 4)         /* 16-byte pieces per tile row                       */
-#define PX_STRIDE    (PX_TILE + 1)
-
+/* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
+ * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
+ * pictures that lean on HBM write bandwidth) */
 /* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line;
  * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
-template <class S, bool FAST, bool BPP3>
+template <class S, bool FAST, bool BPP3, int PXT>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int want_exact,
          int want_rank)
 {
     __shared__ unsigned s_in[64 * IN_STRIDE];
+    constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
     __shared__ unsigned s_px[64 * PX_STRIDE];
     __shared__ unsigned long long s_src[64], s_dst[64];
     __shared__ int s_nrows[64];
@@ -1332,6 +1332,7 @@ struct crthip_ctx {
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words */
     int vhs_chunks;
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
+    int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join;
@@ -1739,6 +1740,7 @@ static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const sig
                          const crthip_line *d_lines, void *d_out, size_t ostride)
 {
     const bool fast = fast_path_ok(p) && !c->force_exact;
+    const bool wide = c->px_tile ? c->px_tile == 32 : p->outw >= 1280;
     /* lines per output row when the picture is shorter than the raster: one pass per rank */
     const unsigned span = (unsigned) p->outh + p->v_fac;
     const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
@@ -1750,7 +1752,8 @@ static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const sig
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_DECODE(FASTK, B3, WANT) \
-    hipLaunchKernelGGL((k_decode<S, FASTK, B3>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, WANT, rank)
+    do { if (wide) hipLaunchKernelGGL((k_decode<S, FASTK, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, WANT, rank); \
+         else hipLaunchKernelGGL((k_decode<S, FASTK, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, WANT, rank); } while (0)
             if (p->out_bpp == 3) {
                 if (fast) { CRTHIP_LAUNCH_DECODE(true, true, 0); CRTHIP_LAUNCH_DECODE(false, true, 1); }
                 else CRTHIP_LAUNCH_DECODE(false, true, -1);
@@ -1879,6 +1882,13 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     }
     if (rc) return rc;
     HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_pixel_tile(crthip_ctx *c, int px)
+{
+    if (!c || (px != 0 && px != 16 && px != 32)) return CRTHIP_E_ARG;
+    c->px_tile = px;
     return CRTHIP_OK;
 }
 
