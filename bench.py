@@ -172,22 +172,17 @@ def main():
                 traffic = traffic * n if traffic else None
             except Exception:
                 traffic = None
-        # integer-VALU roofline of the dominant kernel (the bound that actually binds at 640x480): its VALU
-        # instruction count per field comes from the committed SQ counter profile, an integer VALU
-        # instruction occupies a SIMD for 4 cycles (16 lanes/clk), 1024 SIMDs
+        # cycle-weighted VALU bound of the dominant kernel at 640x480 (the bound that actually binds there):
+        # ISA-inspected inner loops, 95 VALU ~ 310 cycles per sample and 50 VALU ~ 120 cycles per pixel with
+        # the measured issue costs (profiles/r01_valu_issue_rates.txt), 3.75 waves per field, 1024 SIMDs
         valu = None
-        spath = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
-        if os.path.exists(spath) and dom == "decode" and (w, h) == (640, 480):
-            try:
-                kd = json.load(open(spath))["kernels"]["void k_decode<SysNTSC, true, false>"]
-                per_field = kd["SQ_INSTS_VALU"] / 4096.0
-                clk = kd["GRBM_GUI_ACTIVE"] / 8.0 / (kern_ms_profiled := 2.61e-3)   # Hz during the counter run
-                need_s = per_field * n * 4.0 / 1024.0 / clk
-                valu = {"bound": "int-valu", "insts_per_field": per_field, "clock_hz": clk,
-                        "min_kernel_ms": need_s * 1e3, "frac": need_s * 1e3 / kern_ms[dom],
-                        "source": "profiles/r01_sq_counters.json"}
-            except Exception:
-                valu = None
+        if dom == "decode" and (w, h) == (640, 480):
+            cycles_per_field = 3.75 * (756 * 310 + 640 * 120)
+            clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_sq_counters.json
+            need_ms = cycles_per_field * n / 1024.0 / clk * 1e3
+            valu = {"bound": "int-valu (cycle-weighted)", "simd_cycles_per_field": cycles_per_field, "clock_hz": clk,
+                    "min_kernel_ms": need_ms, "frac": need_ms / kern_ms[dom],
+                    "source": "DESIGN.md section 5, profiles/r01_valu_issue_rates.txt, profiles/r01_sq_counters.json"}
         out = {
             "metric": "frames/sec at 640x480 interlaced, bit-exact vs CPU; % HBM roofline",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
