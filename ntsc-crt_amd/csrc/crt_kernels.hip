@@ -298,17 +298,18 @@ __device__ __forceinline__ int ppu_level(int p, int phase)
  * IN4: 4-byte input pixels moved through a cooperative LDS tile (see the comment above k_decode);
  * otherwise (3-byte formats, tiny images) each lane reads its own pixels bytewise.
  * The produced samples always leave through a cooperative LDS tile. */
-#define AC_TILE    32                     /* dwords per row and tile: 32 pixels in, 128 samples out */
-#define AC_STRIDE  (AC_TILE + 1)
-
+/* ACT = dwords per row and tile (ACT pixels in, 4*ACT samples out): 32 moves full 128-byte lines per row
+ * piece group, 16 halves the LDS footprint (more waves per SIMD) -- chosen by input width at launch */
 /* CLAMP: output is inp[] (fused path), i.e. the +-127 clamp of crt_core.c:363-364 applies even when
  * no noise is added (only matters for NES, whose samples can be -128) */
-template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP>
+template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT>
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
          const uint2 *__restrict__ jump16)
 {
+    constexpr int AC_TILE = ACT, AC_STRIDE = ACT + 1, AC_PIECES = ACT / 4;   /* 16-byte pieces per tile row */
+    constexpr int AC_ROWS = 64 / AC_PIECES, AC_SHIFT = ACT == 32 ? 5 : 4;      /* rows per load instruction */
     __shared__ unsigned s_pix[64 * AC_STRIDE];
     __shared__ unsigned s_out[64 * AC_STRIDE];
     __shared__ unsigned long long s_src[64], s_dst[64];
@@ -351,12 +352,12 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
     auto drain = [&](int g0, int ng) {
         __syncthreads();
-        const int orow = lane >> 3, piece = lane & 7;         /* 16 bytes per piece, 8 pieces per row */
+        const int orow = lane / AC_PIECES, piece = lane % AC_PIECES;   /* 16 bytes per piece */
         const int first = (g0 + piece * 4) * 4;               /* first sample of my piece */
         const int nbytes = destw - first < 16 ? destw - first : 16;
 #pragma unroll 2
-        for (int i = 0; i < 8; i++) {
-            const int r = i * 8 + orow;
+        for (int i = 0; i < AC_PIECES; i++) {
+            const int r = i * AC_ROWS + orow;
             const unsigned long long d = s_dst[r];
             if (d != 0 && piece * 4 < ng && nbytes > 0) {
                 const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
@@ -422,27 +423,27 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
          * load instruction.  `have` = tile in LDS, `stage[]` = tile have+1 in flight / in registers.
          * A piece that would run past the row end is moved back to the row's last 16 bytes, so
          * nothing beyond the image is touched (w >= 4). */
-        const int prow_ = lane >> 3, piece = lane & 7;
-        const int last_tile = (w - 1) >> 5;
+        const int prow_ = lane / AC_PIECES, piece = lane % AC_PIECES;
+        const int last_tile = (w - 1) >> AC_SHIFT;
         const int row_bytes = w * 4;
-        v4i stage[8];
+        v4i stage[AC_PIECES];
         auto piece_offset = [&](int tile) {
-            int off = tile * 128 + piece * 16;
+            int off = tile * (AC_TILE * 4) + piece * 16;
             return off > row_bytes - 16 ? row_bytes - 16 : off;
         };
         auto fetch = [&](int tile) {
             const int off = piece_offset(tile);
 #pragma unroll
-            for (int i = 0; i < 8; i++) stage[i] = gload16u(s_src[i * 8 + prow_] + off);
+            for (int i = 0; i < AC_PIECES; i++) stage[i] = gload16u(s_src[i * AC_ROWS + prow_] + off);
         };
         auto stash = [&](int tile) {
             /* dword index inside the tile where my (possibly moved-back) piece belongs; moved-back
              * pieces of several lanes overlap and carry identical bytes */
-            const int dw0 = (piece_offset(tile) - tile * 128) >> 2;     /* may be negative for a moved-back piece */
+            const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;     /* may be negative for a moved-back piece */
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                unsigned *d = s_pix + (i * 8 + prow_) * AC_STRIDE;
+            for (int i = 0; i < AC_PIECES; i++) {
+                unsigned *d = s_pix + (i * AC_ROWS + prow_) * AC_STRIDE;
                 if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
                 if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
                 if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
@@ -464,14 +465,14 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                 if (x < destw) {
                     unsigned pixel;
                     if (IN4) {
-                        const int need = col >> 5;                 /* wave-uniform */
+                        const int need = col >> AC_SHIFT;          /* wave-uniform */
                         if (need != have) {
                             if (need != have + 1) fetch(need);      /* only when w > 32*destw */
                             stash(need);
                             have = need;
                             if (need < last_tile) fetch(need + 1);
                         }
-                        pixel = s_pix[lane * AC_STRIDE + (col & 31)];
+                        pixel = s_pix[lane * AC_STRIDE + (col & (AC_TILE - 1))];
                     } else {
                         const unsigned char *pp = row + (size_t) col * in_bpp;
                         pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
@@ -1333,6 +1334,7 @@ struct crthip_ctx {
     int vhs_chunks;
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
+    int ac_tile;                /* encoder tile, same convention, by input width */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join;
@@ -1427,8 +1429,10 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const unsigned char *img = (const unsigned char *) d_images;
     const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
     const bool noise = FULL && p->noise != 0;
+    const bool wide_in = c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
-    hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16)
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
+         else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
     if (noise) { if (in4) CRTHIP_LAUNCH_ACTIVE(true, true); else CRTHIP_LAUNCH_ACTIVE(true, false); }
     else       { if (in4) CRTHIP_LAUNCH_ACTIVE(false, true); else CRTHIP_LAUNCH_ACTIVE(false, false); }
 #undef CRTHIP_LAUNCH_ACTIVE
@@ -1889,6 +1893,7 @@ int crthip_set_pixel_tile(crthip_ctx *c, int px)
 {
     if (!c || (px != 0 && px != 16 && px != 32)) return CRTHIP_E_ARG;
     c->px_tile = px;
+    c->ac_tile = px;
     return CRTHIP_OK;
 }
 
