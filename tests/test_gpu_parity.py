@@ -300,6 +300,34 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
     g.close()
 
 
+def _random_case(rng):
+    w = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 333, 640, 753, 800, 1281]))
+    h = int(rng.choice([1, 2, 7, 48, 100, 236, 237, 480, 601]))
+    outw = int(rng.choice([1, 3, 4, 5, 31, 32, 33, 250, 640, 1283]))
+    outh = int(rng.choice([1, 17, 120, 239, 240, 241, 480, 500, 777]))
+    ifmt, ofmt = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+    raw = int(rng.integers(0, 2))
+    skw = dict(as_color=int(rng.integers(0, 2)), raw=raw, hue=int(rng.integers(-400, 800)))
+    if raw and w <= 640 and h <= 200:
+        # offsets only where the active rectangle still fits the raster: beyond that crt_modulate scribbles
+        # over neighbouring lines (crt_ntsc.c:322) -- outside the contract, the library refuses it
+        skw.update(xoffset=int(rng.integers(0, 3)) * 4, yoffset=int(rng.integers(0, 3)))
+    knobs = dict(hue=int(rng.integers(-360, 720)), brightness=int(rng.integers(-40, 40)), contrast=int(rng.integers(0, 400)),
+                 saturation=int(rng.integers(-5, 40)), black_point=int(rng.integers(-10, 10)),
+                 white_point=int(rng.integers(50, 150)), scanlines=int(rng.integers(0, 2)), blend=int(rng.integers(0, 2)),
+                 v_fac=int(rng.choice([0, 0, 0, 7, 100])))
+    noise = int(rng.choice([0, 1, 24, 77, 300]))
+    return ("ntsc", outw, outh, ofmt, w, h, ifmt, noise, skw, knobs)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations(crtlib, seed):
+    """odd / tiny / large geometries, all format pairs, random knobs: stagewise AND fused, 2 steps each"""
+    rng = np.random.default_rng(1000 + seed)
+    case = _random_case(rng)
+    _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2)
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
