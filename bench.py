@@ -178,11 +178,11 @@ def main():
         valu = None
         if dom == "decode" and (w, h) == (640, 480):
             cycles_per_field = 3.75 * (756 * 310 + 640 * 120)
-            clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_sq_counters.json
+            clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_final_sq_counters.json
             need_ms = cycles_per_field * n / 1024.0 / clk * 1e3
             valu = {"bound": "int-valu (cycle-weighted)", "simd_cycles_per_field": cycles_per_field, "clock_hz": clk,
                     "min_kernel_ms": need_ms, "frac": need_ms / kern_ms[dom],
-                    "source": "DESIGN.md section 5, profiles/r01_valu_issue_rates.txt, profiles/r01_sq_counters.json"}
+                    "source": "DESIGN.md section 5, profiles/r01_valu_issue_rates.txt, profiles/r01_final_sq_counters.json"}
         out = {
             "metric": "frames/sec at 640x480 interlaced, bit-exact vs CPU; % HBM roofline",
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
