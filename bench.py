@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--scanlines", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sequence", action="store_true", help="treat the batch as ONE video (crthip_sequence) instead of independent frames")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--pixel-tile", type=int, default=0, help="decoder output tile: 0 auto, 16, 32")
     ap.add_argument("--overlap", type=int, default=1, help="chunks alternating between two streams")
@@ -127,6 +128,9 @@ def main():
     crt._load_field_state(s)
 
     def step(k):
+        if args.sequence:
+            crt.sequence(s, args.noise)
+            return
         crt.fieldpass(s, args.noise, params=p)
         # next field of the interlaced sequence (video_convert.c:261-267)
         crt.state[:, crtlib.ST_FIELD] ^= 1
@@ -191,7 +195,8 @@ def main():
             "config": {"workload": "NTSC %dx%d BGRA -> %dx%d BGRA, interlaced, full colour, noise %d, hue 0, "
                                    "scanlines %d (BASELINE configs[1])" % (w, h, w, h, args.noise, args.scanlines),
                        "fields_per_gpu_per_step": n, "frames_per_step": world * n,
-                       "sharding": "frames by rank, RCCL broadcast of settings only"},
+                       "sharding": "frames by rank, RCCL broadcast of settings only",
+                       "mode": "one video per GPU (crthip_sequence)" if args.sequence else "independent frames (crthip_fieldpass)"},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -192,6 +192,23 @@ int  crthip_fieldpass(crthip_ctx *ctx, const crthip_params *p, int n,
                       crthip_state *d_state);
 
 /*
+ * SEQUENCE mode: n consecutive fields of ONE television set -- what the reference's
+ * batch driver does (extra/video_convert.c:246-277:  for every frame: crt_modulate; crt_demodulate;
+ * write the output image), with the sync state and the output buffer carried from field to field,
+ * yet processed by parallel kernels (DESIGN.md "Sequence mode").
+ *   d_state[k].field / .frame / .aux : encoder inputs of field k;  d_state[0].hsync/.vsync/.rn : the
+ *   set's state before field 0; on return d_state[k] holds the state after field k.
+ *   d_out image k = the (single) output buffer as it stands after field k; d_out_init = its content
+ *   before field 0 (NULL = zeros, i.e. calloc as in the drivers).
+ * Requires blend == 0 (video_convert.c:239) and a non-VHS system; *passes (optional) receives the
+ * number of sync fixed-point passes that were needed.
+ */
+int  crthip_sequence(crthip_ctx *ctx, const crthip_params *p, int n,
+                     const void *d_images, size_t image_stride,
+                     void *d_out, size_t out_stride, const void *d_out_init,
+                     crthip_state *d_state, int *passes);
+
+/*
  * Stage-level entry points (used by the drop-in layer, which must keep the host's
  * struct CRT coherent between crt_modulate and crt_demodulate, and by the stage
  * parity tests).  d_analog / d_inp hold n fields at crthip_field_stride() spacing.

@@ -91,6 +91,7 @@ def load_library():
     L.crthip_vhs_history_from_seed.argtypes = [C.c_uint, C.POINTER(C.c_uint)]
     L.crthip_vhs_bind_history.argtypes = [vp, vp]
     L.crthip_set_overlap.argtypes = [vp, ci]
+    L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
     L.crthip_set_pixel_tile.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
     _LIB = L
@@ -298,6 +299,21 @@ class CRT:
                                      self.out.stride(0), C.c_void_p(self.state.data_ptr()))
         self._check(rc, "crthip_fieldpass")
         s.initialized = 1
+
+    def sequence(self, s, noise, out_init=None):
+        """The n images of ``s.data`` as n CONSECUTIVE fields of one television set (state and output
+        buffer carried over, like extra/video_convert.c), processed in parallel.  ``self.state[0]`` holds
+        the set's state before field 0; returns the number of sync fixed-point passes."""
+        p = self.params(s, noise)
+        self._load_field_state(s)
+        passes = C.c_int(0)
+        rc = self.L.crthip_sequence(self.ctx, C.byref(p), self.n, C.c_void_p(s.data.data_ptr()), self._image_stride(s),
+                                    C.c_void_p(self.out.data_ptr()), self.out.stride(0),
+                                    C.c_void_p(out_init.data_ptr()) if out_init is not None else None,
+                                    C.c_void_p(self.state.data_ptr()), C.byref(passes))
+        self._check(rc, "crthip_sequence")
+        s.initialized = 1
+        return passes.value
 
     # ------------------------------------------------------------------ observation
     def srand(self, seeds):

@@ -1313,6 +1313,108 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
 }
 
 /* ------------------------------------------------------------------------- */
+/* Sequence mode: n consecutive fields of ONE television set  */
+/* ------------------------------------------------------------------------- */
+/* Sequential semantics of   for k: crt_modulate(field k); crt_demodulate(); save(out)   (the loop of
+ * extra/video_convert.c:246-277) reproduced with parallel kernels:
+ *   rn      : closed form, rn_k = J^k(rn_0), J = INPUT_SIZE steps of the LCG;
+ *   encoder : independent per field (fused, writes the noisy field);
+ *   sync    : field k starts from field k-1's final (hsync, vsync).  Solved as a fixed point: every
+ *             pass runs k_vsync/k_hsync for ALL fields in parallel with init_k = final_{k-1} of the
+ *             previous pass; after pass j fields 0..j-1 are final for good, and because a field's final
+ *             state hardly ever depends on its initial one the iteration normally stops after 2-3 passes;
+ *   decoder : independent per field given its line table (blend must be 0: with blend the output is a
+ *             recurrence over fields);
+ *   weave   : output image k = the single output buffer after field k: rows field k does not write come
+ *             from the latest earlier field that wrote them (or the initial buffer). */
+__global__ void k_seq_rn(int n_fields, crthip_state *state, uint2 whole_field)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fields) return;
+    /* (m, a) = J^k by square and multiply */
+    unsigned pm = whole_field.x, pa = whole_field.y, m = 1u, a = 0u;
+    for (unsigned e = (unsigned) k; e; e >>= 1) {
+        if (e & 1u) { m = pm * m; a = pm * a + pa; }
+        pa = pm * pa + pa;
+        pm = pm * pm;
+    }
+    const unsigned rn0 = (unsigned) state[0].rn;       /* entry 0 is never written here */
+    if (k > 0) state[k].rn = (int) (m * rn0 + a);
+}
+
+/* init_k = (k ? guess[k-1] : first); also remembers nothing else */
+__global__ void k_seq_load(int n_fields, crthip_state *state, const int2 *guess, int2 first)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fields) return;
+    const int2 v = k ? guess[k - 1] : first;
+    state[k].hsync = v.x;
+    state[k].vsync = v.y;
+}
+
+/* guess <- finals; *changed |= any difference */
+__global__ void k_seq_compare(int n_fields, const crthip_state *state, int2 *guess, int *changed)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fields) return;
+    const int2 f = make_int2(state[k].hsync, state[k].vsync);
+    const int2 g = guess[k];
+    if (f.x != g.x || f.y != g.y) {
+        guess[k] = f;
+        atomicOr(changed, 1);
+    }
+}
+
+/* rows written by field k (crt_core.c:552,661-664) -> owner[k][row] = 1 */
+__global__ void k_seq_rows(int n_fields, int lines_per_field, int outh, const crthip_line *lines, unsigned char *owner)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_fields * lines_per_field) return;
+    const int k = gid / lines_per_field;
+    const crthip_line lp = lines[gid];
+    const int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    for (int r = 0; r < nrows; r++) {
+        if (lp.beg + r < outh) owner[(size_t) k * outh + lp.beg + r] = 1;
+    }
+}
+
+/* latest[k][row] = last field <= k that wrote the row, -1 = none (serial in k, one lane per row) */
+__global__ void k_seq_latest(int n_fields, int outh, const unsigned char *owner, int *latest)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= outh) return;
+    int last = -1;
+    for (int k = 0; k < n_fields; k++) {
+        if (owner[(size_t) k * outh + r]) last = k;
+        latest[(size_t) k * outh + r] = last;
+    }
+}
+
+/* rows of image k that field k did not write <- the same row of image latest[k][row] (or the initial image) */
+__global__ void __launch_bounds__(256)
+k_seq_weave(int n_fields, int outh, size_t pitch, unsigned char *out, size_t ostride, const unsigned char *init,
+            const int *latest)
+{
+    const int row = blockIdx.x % outh, k = blockIdx.x / outh;
+    if (k >= n_fields) return;
+    const int src_k = latest[(size_t) k * outh + row];
+    if (src_k == k) return;
+    unsigned char *dst = out + (size_t) k * ostride + (size_t) row * pitch;
+    const unsigned char *src = src_k >= 0 ? out + (size_t) src_k * ostride + (size_t) row * pitch
+                                          : (init ? init + (size_t) row * pitch : nullptr);
+    for (size_t b = (size_t) threadIdx.x * 16; b < pitch; b += 256 * 16) {
+        const size_t nb = pitch - b < 16 ? pitch - b : 16;
+        if (nb == 16) {
+            v4i v = { 0, 0, 0, 0 };
+            if (src) v = load16u(src + b);
+            store16u(dst + b, v);
+        } else {
+            for (size_t c = 0; c < nb; c++) dst[b + c] = src ? src[b + c] : (unsigned char) 0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* host side: context, dispatch by system, C ABI                               */
 /* ------------------------------------------------------------------------- */
 struct crthip_ctx {
@@ -1330,6 +1432,8 @@ struct crthip_ctx {
     crthip_line *d_lines;
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
+    unsigned char *d_seq;       /* crthip_sequence scratch */
+    size_t seq_cap;
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words */
     int vhs_chunks;
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
@@ -1587,6 +1691,7 @@ void crthip_destroy(crthip_ctx *c)
     if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->d_jump16) hipFree(c->d_jump16);
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
+    if (c->d_seq) hipFree(c->d_seq);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
@@ -1894,6 +1999,93 @@ int crthip_set_pixel_tile(crthip_ctx *c, int px)
     if (!c || (px != 0 && px != 16 && px != 32)) return CRTHIP_E_ARG;
     c->px_tile = px;
     c->ac_tile = px;
+    return CRTHIP_OK;
+}
+
+int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    void *d_out, size_t ostride, const void *d_out_init, crthip_state *d_state, int *passes_out)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS)
+        return set_err(c, CRTHIP_E_ARG, "sequence mode: the VHS rand() stream is a chain over fields, use crthip_fieldpass per field", hipSuccess);
+    if (p->blend) return set_err(c, CRTHIP_E_ARG, "sequence mode needs blend == 0 (blend is a recurrence over fields)", hipSuccess);
+    if (p->out_bpp == 0) return CRTHIP_OK;
+    int enc = check_encoder(c, p);
+    if (enc != 0) return enc < 0 ? enc : set_err(c, CRTHIP_E_ARG, "sequence mode: unknown input pixel format", hipSuccess);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->cap_fields) {
+        rc = crthip_reserve(c, n);
+        if (rc) return rc;
+    }
+    const int outh = p->outh;
+    const size_t pitch = (size_t) p->outw * p->out_bpp;
+    /* scratch: guess[n] (int2), changed flag, owner[n][outh] (u8), latest[n][outh] (int) */
+    const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh;
+    if (need > c->seq_cap) {
+        if (c->d_seq) hipFree(c->d_seq);
+        c->d_seq = 0; c->seq_cap = 0;
+        if (hipMalloc((void **) &c->d_seq, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sequence scratch", hipSuccess);
+        c->seq_cap = need;
+    }
+    int2 *guess = (int2 *) c->d_seq;
+    int *changed = (int *) (c->d_seq + sizeof(int2) * (size_t) n);
+    unsigned char *owner = c->d_seq + sizeof(int2) * (size_t) n + 256;
+    int *latest = (int *) (owner + (((size_t) n * outh + 255) & ~(size_t) 255));
+    const dim3 gn((n + 63) / 64), b64(64);
+
+    crthip_state first;
+    HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_seq_rn, gn, b64, 0, c->stream, n, d_state, c->whole_field);
+    /* encode every field (noise fused), ccf presets */
+    rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        launch_encoder<S, true>(c, p, n, d_images, istride, c->d_inp, d_state, 1);
+        return CRTHIP_OK;
+    });
+    if (rc) return rc;
+    /* first guess: nobody's sync state moves */
+    {
+        int2 *h = (int2 *) malloc(sizeof(int2) * (size_t) n);
+        if (!h) return CRTHIP_E_NOMEM;
+        for (int k = 0; k < n; k++) h[k] = make_int2(first.hsync, first.vsync);
+        hipError_t e = hipMemcpyAsync(guess, h, sizeof(int2) * (size_t) n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        free(h);
+        HIPCHK(c, e);
+    }
+    int passes = 0;
+    for (;;) {
+        passes++;
+        HIPCHK(c, hipMemsetAsync(changed, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_seq_load, gn, b64, 0, c->stream, n, d_state, guess, make_int2(first.hsync, first.vsync));
+        rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
+            using S = decltype(tag);
+            hipLaunchKernelGGL((k_encoder_state<S>), gn, b64, 0, c->stream, *p, n, d_state);   /* ccf preset, crt_ntsc.c:325-329 */
+            return CRTHIP_OK;
+        });
+        if (rc) return rc;
+        rc = launch_sync(c, p, n, c->d_inp, d_state, c->d_lines, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_seq_compare, gn, b64, 0, c->stream, n, d_state, guess, changed);
+        int flag = 0;
+        HIPCHK(c, hipMemcpyAsync(&flag, changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!flag || passes > n + 1) break;
+    }
+    if (passes_out) *passes_out = passes;
+    /* rn after each field, decode, weave */
+    hipLaunchKernelGGL(k_advance_rn, gn, b64, 0, c->stream, n, d_state, c->whole_field);
+    rc = launch_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(owner, 0, (size_t) n * outh, c->stream));
+    hipLaunchKernelGGL(k_seq_rows, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, owner);
+    hipLaunchKernelGGL(k_seq_latest, dim3((outh + 63) / 64), b64, 0, c->stream, n, outh, owner, latest);
+    hipLaunchKernelGGL(k_seq_weave, dim3((unsigned) n * (unsigned) outh), dim3(256), 0, c->stream, n, outh, pitch,
+                       (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, latest);
+    HIPCHK(c, hipGetLastError());
     return CRTHIP_OK;
 }
 

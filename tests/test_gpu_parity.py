@@ -300,6 +300,61 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
     g.close()
 
 
+@pytest.mark.parametrize("name,noise,scanlines,outsz", [("ntsc", 24, 1, (640, 480)), ("ntsc", 0, 0, (832, 624)),
+                                                         ("ntsc", 120, 1, (320, 240)), ("nes", 12, 1, (640, 480))])
+def test_sequence_mode_equals_sequential_processing(crtlib, name, noise, scanlines, outsz):
+    """n consecutive fields of ONE set (video_convert.c:246-277 semantics: hsync/vsync/rn and the
+    output buffer carried over) through crthip_sequence, against the oracle doing them one after the other."""
+    import torch
+    import shard
+    n = 9
+    outw, outh = outsz
+    nes = name.startswith("nes")
+    orc = R.Oracle(name)
+    c = orc.new_crt(outw, outh, R.FMT_BGRA)
+    c.set("scanlines", scanlines)
+    c.out[:] = R.lcg_bytes(c.out.size, 5)                 # the output buffer's content before field 0
+    init = c.out.copy()
+    c.set("hsync", 7)
+    c.set("vsync", 2)
+    want = []
+    if nes:
+        frames = np.stack([R.synth_ppu(256, 240, 300 + k) for k in range(n)])
+    else:
+        frames = np.stack([R.synth_image(640, 480, 4, 300 + k, "random" if k % 3 else "bars") for k in range(n)])
+    for k in range(n):
+        field, frame = shard.field_parity(k)
+        pad = np.concatenate([frames[k], frames[k][-1:]], axis=0)
+        if nes:
+            c.settings(pad, w=256, h=240, dot_crawl_offset=k % 3, hue=0)
+        else:
+            c.settings(pad, format=R.FMT_BGRA, w=640, h=480, as_color=1, field=field, frame=frame)
+        c.modulate()
+        c.demodulate(noise)
+        want.append((c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn")))
+    g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, name, device=0)
+    g.scanlines = scanlines
+    g.state[0, crtlib.ST_HSYNC] = 7
+    g.state[0, crtlib.ST_VSYNC] = 2
+    if nes:
+        full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
+        full[:, :240] = torch.from_numpy(frames.astype(np.int16)).to("cuda:0")
+        s = crtlib.Settings(full[:, :240], hue=0, dot_crawl_offset=[k % 3 for k in range(n)])
+    else:
+        par = [shard.field_parity(k) for k in range(n)]
+        s = crtlib.Settings(_padded(frames), format=crtlib.FMT_BGRA, field=[a for a, _ in par], frame=[b for _, b in par])
+    passes = g.sequence(s, noise, out_init=_to_dev(init))
+    g.synchronize()
+    assert 1 <= passes <= n + 1
+    out = g.out.cpu().numpy()
+    for k in range(n):
+        o, hs, vs, rn = want[k]
+        assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), "field %d state" % k
+        np.testing.assert_array_equal(out[k].reshape(-1), o, err_msg="sequence field %d (passes %d)" % (k, passes))
+    print("sequence %s noise %d: %d sync passes" % (name, noise, passes))
+    g.close()
+
+
 def _random_case(rng):
     w = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 333, 640, 753, 800, 1281]))
     h = int(rng.choice([1, 2, 7, 48, 100, 236, 237, 480, 601]))
