@@ -327,7 +327,8 @@ class CRT:
         self.vhs_hist.copy_(self.torch.from_numpy(h.view(np.int32)).to(self.dev))
 
     def set_exact(self, on=True):
-        """Force the exact 32-bit-multiply kernels (normally only used outside the proven 24-bit envelope)."""
+        """1/True: force the exact 32-bit-multiply kernels everywhere; 2: allow the 24-bit tier but not the
+        64-bit-mad decoder tier; 0: normal dispatch by proven operand range."""
         self._check(self.L.crthip_set_exact(self.ctx, int(on)), "crthip_set_exact")
 
     def set_overlap(self, chunks):

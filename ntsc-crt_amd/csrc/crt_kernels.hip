@@ -91,8 +91,11 @@ static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES ==
 
 #define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
 #define CRTHIP_LINE_NROWS_MASK 0xffff     /* crthip_line.nrows bits 0-15: rows written              */
-#define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-29: rank among lines starting on the same row   */
-#define CRTHIP_LINE_RANK_MASK  0x3fff
+#define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-28: rank among lines starting on the same row   */
+#define CRTHIP_LINE_RANK_MASK  0x1fff
+#define CRTHIP_LINE_NOT64 0x20000000      /* bit 29: outside the no-wrap envelope of the 64-bit-mad decoder */
+#define T0_WAVE_MAX       120000          /* |wave[k]| bound of decoder tier 0 */
+#define T0_BRIGHT_MAX     2600            /* |bright| bound of decoder tier 0  */
 #define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
 #define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
 #define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
@@ -1046,6 +1049,8 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
                 nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
                 if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
                     nrows |= CRTHIP_LINE_EXACT;
+                else if (lp.wave0 > T0_WAVE_MAX || lp.wave0 < -T0_WAVE_MAX || lp.wave1 > T0_WAVE_MAX || lp.wave1 < -T0_WAVE_MAX)
+                    nrows |= CRTHIP_LINE_NOT64;
                 lp.nrows = nrows;
                 lp.hsync = hsync;
             }
@@ -1107,6 +1112,56 @@ __device__ __forceinline__ int eq_step(Eq3 &f, const int lf, const int hf, const
     return r;
 }
 
+/*
+ * Tier 0 of the decoder: one v_mad_i64_i32 per filter stage.
+ *   x' = x + ((c*(u-x) + 2^15) >> 16)  ==  hi32( (c<<16)*(u-x) + {lo: 2^31, hi: x} )          c < 2^15
+ *   and, because x + (u-x) = u,        ==  hi32( ((c-2^16)<<16)*(u-x) + {lo: 2^31, hi: u} )   2^15 <= c < 1.5*2^16
+ * -- multiply, rounding, shift and accumulate in ONE 4-cycle instruction (measured: v_mad_i64_i32 issues
+ * like v_mad_i32_i24, profiles/r01_valu_issue_rates.txt), i.e. v_sub + v_mov(lo = 2^31) + v_mad_i64_i32
+ * = 8 cycles per stage instead of 10.  Every state lives in the HIGH half of a register pair whose low
+ * half is re-armed with 2^31 after each update, so a pair can serve as addend of its own stage (small c)
+ * or of the next stage (c near 2^16).  The 64-bit product is exact, whereas the reference's 32-bit one
+ * wraps: equal only while |c*(u-x)| + 2^15 < 2^31, which is what the tier-0 envelope guarantees
+ * (DESIGN.md): luma |s+bright| <= 2727, chroma |wave| <= 120000.  Luma coefficients are near 2^16,
+ * chroma ones below 2^15 for every system of this build (checked on the host).
+ */
+#define KROUND64 0x80000000ul
+__device__ __forceinline__ int hi32(long v) { return (int) (v >> 32); }
+__device__ __forceinline__ long pair_of(int v) { return (long) (((unsigned long) (unsigned) v << 32) | KROUND64); }
+__device__ __forceinline__ long rearm(long v) { return (long) (((unsigned long) v & 0xffffffff00000000ul) | KROUND64); }
+__device__ __forceinline__ long mad64(int d, int cc, long acc)
+{
+    long r, carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(d), "s"(cc), "v"(acc));
+    return r;
+}
+struct Eq64 { long lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3; int h0, h1, h2; };
+__device__ __forceinline__ void eq64_reset(Eq64 &f)
+{
+    f.lo0 = f.lo1 = f.lo2 = f.lo3 = f.hi0 = f.hi1 = f.hi2 = f.hi3 = (long) KROUND64;
+    f.h0 = f.h1 = f.h2 = 0;
+}
+/* lfm / hfm: pre-shifted multipliers (see above); NEAR1: coefficients are >= 2^15 */
+template <bool NEAR1, int G1, int G2>
+__device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, const long sp)
+{
+#define EQ64_STAGE(X, UPAIR, M) X = rearm(mad64(hi32(UPAIR) - hi32(X), M, NEAR1 ? UPAIR : X))
+    EQ64_STAGE(f.lo0, sp, lfm);    EQ64_STAGE(f.hi0, sp, hfm);
+    EQ64_STAGE(f.lo1, f.lo0, lfm); EQ64_STAGE(f.hi1, f.hi0, hfm);
+    EQ64_STAGE(f.lo2, f.lo1, lfm); EQ64_STAGE(f.hi2, f.hi1, hfm);
+    EQ64_STAGE(f.lo3, f.lo2, lfm); EQ64_STAGE(f.hi3, f.hi2, hfm);
+#undef EQ64_STAGE
+    const int lo3 = hi32(f.lo3), hi3 = hi32(f.hi3);
+    int r = (lo3 * 65536) >> 16;
+    if (G1 == 65536 || G1 == 8192) r += ((hi3 - lo3) * G1) >> 16;
+    else r += __mul24(hi3 - lo3, G1) >> 16;
+    if (G2 != 0) {
+        r += __mul24(f.h2 - hi3, G2) >> 16;
+        f.h2 = f.h1; f.h1 = f.h0; f.h0 = hi32(sp);
+    }
+    return r;
+}
+
 /* byte selectors for v_perm_b32: 0xffRRGGBB (bytes B,G,R,ff) <-> the four 4-byte output formats,
  * crt_core.c:587-656 */
 __device__ __forceinline__ unsigned pack_selector(int format)
@@ -1135,14 +1190,16 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
 /* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
-/* want_exact: 0 = only lines without CRTHIP_LINE_EXACT, 1 = only lines with it, -1 = every line;
+/* TIER: 0 = 64-bit-mad stages, 1 = 24-bit mads, 2 = exact 32-bit multiplies; a line is decoded by the kernel
+ * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
  * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
-template <class S, bool FAST, bool BPP3, int PXT>
+template <class S, int TIER, bool BPP3, int PXT>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int want_exact,
+         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
          int want_rank)
 {
+    constexpr bool FAST = TIER <= 1;        /* tiers 0 and 1 use 24-bit multiplies outside the filter stages */
     __shared__ unsigned s_in[64 * IN_STRIDE];
     constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
     __shared__ unsigned s_px[64 * PX_STRIDE];
@@ -1156,10 +1213,11 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
     const int f = live ? gid / S::LINES : 0;
     if (live) lp = lines[gid];
-    const int exact = (lp.nrows & CRTHIP_LINE_EXACT) ? 1 : 0;
+    int tier = (lp.nrows & CRTHIP_LINE_EXACT) ? 2 : (lp.nrows & CRTHIP_LINE_NOT64) ? 1 : 0;
+    if (tier < min_tier) tier = min_tier;          /* batch-wide floor from the host (brightness, contrast) */
     int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
     const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
-    if (!live || (want_exact >= 0 && exact != want_exact) || rank != want_rank) nrows = 0;
+    if (!live || tier != TIER || rank != want_rank) nrows = 0;
     if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
     const bool act = nrows > 0;
     constexpr int bpp = BPP3 ? 3 : 4;
@@ -1176,6 +1234,11 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const bool rgb_order = P.out_format == CRTHIP_FMT_RGB;
     const bool blend = P.blend != 0;
     Eq3 ey = {}, ei = {}, eq = {};
+    Eq64 wy, wi_, wq_;                             /* tier 0 state (register pairs) */
+    eq64_reset(wy); eq64_reset(wi_); eq64_reset(wq_);
+    /* tier 0 multipliers: luma coefficients are 2^16 + c', chroma ones < 2^15 (host-checked) */
+    const int ylfm = (ylf - 65536) << 16, yhfm = (yhf - 65536) << 16;
+    const int ilfm = ilf << 16, ihfm = ihf << 16, qlfm = qlf << 16, qhfm = qhf << 16;
     int py = 0, pi = 0, pq = 0;                    /* yiq of the previous sample */
 
     /* wave-uniform output pixel schedule, crt_core.c:528-531,555-562 */
@@ -1220,9 +1283,16 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
                 const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
                 const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
-                const int cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
-                const int ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
-                const int cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
+                int cy, ci, cq;
+                if (TIER == 0) {
+                    cy = eq_step64<true, 8192, 9175>(wy, ylfm, yhfm, pair_of(s + bright)) << 4;
+                    ci = eq_step64<false, 65536, 1311>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
+                    cq = eq_step64<false, 65536, 0>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
+                } else {
+                    cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
+                    ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
+                    cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
+                }
                 /* D9: every output pixel whose left tap is sample x-1 is now computable */
                 while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
                     const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
@@ -1432,6 +1502,7 @@ struct crthip_ctx {
     crthip_line *d_lines;
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
+    bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tier */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words */
@@ -1836,19 +1907,24 @@ int crthip_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char 
     return rc;
 }
 
-/* host half of the 24-bit-multiply envelope: with |s+bright| <= 2^17 and |wave| <= 2^19
- * every multiply operand of the decoder stays inside [-2^23, 2^23) */
-static bool fast_path_ok(const crthip_params *p)
+/* host half of the decoder envelopes: the batch-wide floor of the decoder tier.
+ * tier 0 additionally needs the luma coefficients in [2^15, 1.5*2^16) and the chroma ones below 2^15 */
+static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 {
     const int b = p->bright < 0 ? -p->bright : p->bright;
-    const int c = p->contrast < 0 ? -p->contrast : p->contrast;
-    return b <= FAST_BRIGHT_MAX && c < (1 << 23);
+    const int ct = p->contrast < 0 ? -p->contrast : p->contrast;
+    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23)) return 2;
+    const bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
+                         p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
+                         p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
+    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX) return 1;
+    return 0;
 }
 
 static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                          const crthip_line *d_lines, void *d_out, size_t ostride)
 {
-    const bool fast = fast_path_ok(p) && !c->force_exact;
+    const int min_tier = decoder_min_tier(c, p);
     const bool wide = c->px_tile ? c->px_tile == 32 : p->outw >= 1280;
     /* lines per output row when the picture is shorter than the raster: one pass per rank */
     const unsigned span = (unsigned) p->outh + p->v_fac;
@@ -1860,15 +1936,18 @@ static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const sig
         unsigned char *o = (unsigned char *) d_out;
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
-#define CRTHIP_LAUNCH_DECODE(FASTK, B3, WANT) \
-    do { if (wide) hipLaunchKernelGGL((k_decode<S, FASTK, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, WANT, rank); \
-         else hipLaunchKernelGGL((k_decode<S, FASTK, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, WANT, rank); } while (0)
+#define CRTHIP_LAUNCH_DECODE(T, B3) \
+    do { if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
+         else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); } while (0)
+            /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */
             if (p->out_bpp == 3) {
-                if (fast) { CRTHIP_LAUNCH_DECODE(true, true, 0); CRTHIP_LAUNCH_DECODE(false, true, 1); }
-                else CRTHIP_LAUNCH_DECODE(false, true, -1);
+                if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, true);
+                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, true);
+                CRTHIP_LAUNCH_DECODE(2, true);
             } else {
-                if (fast) { CRTHIP_LAUNCH_DECODE(true, false, 0); CRTHIP_LAUNCH_DECODE(false, false, 1); }
-                else CRTHIP_LAUNCH_DECODE(false, false, -1);
+                if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, false);
+                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, false);
+                CRTHIP_LAUNCH_DECODE(2, false);
             }
 #undef CRTHIP_LAUNCH_DECODE
         }
@@ -2106,7 +2185,8 @@ int crthip_vhs_bind_history(crthip_ctx *c, unsigned *d_hist)
 int crthip_set_exact(crthip_ctx *c, int on)
 {
     if (!c) return CRTHIP_E_ARG;
-    c->force_exact = on != 0;
+    c->force_exact = on == 1;
+    c->no_tier0 = on == 2;      /* 2: allow the 24-bit tier but not the 64-bit-mad one */
     return CRTHIP_OK;
 }
 

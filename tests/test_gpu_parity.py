@@ -59,6 +59,11 @@ CASES = [
     ("ntsc", 500, 300, R.FMT_BGR, 200, 100, R.FMT_ARGB, 60, dict(as_color=1, raw=1), dict(black_point=3, white_point=90)),
     ("ntsc", 333, 481, R.FMT_RGB, 100, 300, R.FMT_RGB, 100, dict(as_color=1, raw=1, xoffset=8, yoffset=2), dict(v_fac=10)),
     ("ntsc", 257, 243, R.FMT_BGRA, 800, 600, R.FMT_BGRA, 24, dict(as_color=1, hue=180), dict(scanlines=1, blend=1)),
+    # between the envelopes: saturation 40 puts the carrier above tier 0's bound (lines flagged NOT64, tier 1),
+    # brightness 5000 lifts the whole batch to tier 1
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(saturation=40)),
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(brightness=5000, contrast=20)),
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 60, dict(as_color=1), dict(brightness=-2600, saturation=24)),
     # outside the 24-bit multiply envelope: huge saturation (lines flagged CRTHIP_LINE_EXACT by k_sync) ...
     ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1), dict(saturation=900, contrast=300)),
     # ... and huge brightness / contrast / white point (host-side check picks the exact kernels)
@@ -144,10 +149,12 @@ def test_fused_fieldpass_parity(crtlib, case):
     _run_case(crtlib, CASES[case], fused=True)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("case", [1, 2, 3, 5])
-def test_exact_kernels_parity(crtlib, case):
-    """the 32-bit-multiply instantiations on ordinary inputs (normally only the fast ones run there)"""
-    _run_case(crtlib, CASES[case], fused=True, exact=True, steps=2)
+def test_slower_decoder_tiers_parity(crtlib, case, mode):
+    """ordinary inputs normally run decoder tier 0 (64-bit mads); force tier 2 (mode 1: exact 32-bit
+    multiplies everywhere) and tier 1 (mode 2: 24-bit mads) onto them"""
+    _run_case(crtlib, CASES[case], fused=True, exact=mode, steps=2)
 
 
 NES_CASES = [

@@ -35,6 +35,21 @@ DEF(mad_i32_i16, "v_mad_i32_i16 %0, %0, %1, %2")
 DEF(dot2_i32_i16, "v_dot2_i32_i16 %0, %0, %1, %2")
 DEF(pk_add_i16, "v_pk_add_i16 %0, %0, %1")
 DEF(mul_hi_i32, "v_mul_hi_i32 %0, %0, %1")
+__global__ void k_mad_i64_i32(int *out, int a, int b) {
+    long x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    int va = a + (threadIdx.x & 1), vb = b;
+    for (int i = 0; i < ITERS; i++) {
+#define M64(x) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(x) : "v"(va), "v"(vb) : "vcc")
+        M64(x0); M64(x1); M64(x2); M64(x3); M64(x4); M64(x5); M64(x6); M64(x7);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (int) (x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7);
+}
+DEF(mov, "v_mov_b32 %0, %1")
+DEF(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+DEF(and_b32, "v_and_b32 %0, %0, %1")
+DEF(lshlrev, "v_lshlrev_b32 %0, 1, %0")
+DEF(max_i32, "v_max_i32 %0, %0, %1")
+DEF(mul_i24_sdwa, "v_mul_i32_i24_sdwa %0, %1, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0")
 template <class K> void run(const char *name, K kern, int *d)
 {
     hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
@@ -54,6 +69,6 @@ int main()
     int *d; (void) hipMalloc(&d, 256 * 8 * 256 * 4);
     RUN(add_u32); RUN(sub_u32); RUN(ashr); RUN(mad_i24); RUN(mul_i24); RUN(mad_u24); RUN(mul_lo); RUN(add_sdwa); RUN(bfe_i32);
     RUN(perm); RUN(med3); RUN(add3); RUN(lshl_add); RUN(add_lshl); RUN(lshl_or); RUN(fma_f32); RUN(mad_i32_i16);
-    RUN(dot2_i32_i16); RUN(pk_add_i16); RUN(mul_hi_i32);
+    RUN(dot2_i32_i16); RUN(pk_add_i16); RUN(mul_hi_i32); RUN(mad_i64_i32); RUN(mov); RUN(cndmask); RUN(and_b32); RUN(lshlrev); RUN(max_i32); RUN(mul_i24_sdwa);
     return 0;
 }
