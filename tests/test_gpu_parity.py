@@ -362,6 +362,41 @@ def test_sequence_mode_equals_sequential_processing(crtlib, name, noise, scanlin
     g.close()
 
 
+@pytest.mark.parametrize("overlap,tile", [(2, 0), (4, 32), (3, 16)])
+def test_tuning_switches_do_not_change_results(crtlib, overlap, tile):
+    """crthip_set_overlap (two-stream chunking) and crthip_set_pixel_tile only re-arrange the work"""
+    import torch
+    n, w, h = 1030, 64, 48                       # > 256 * chunks so that chunking really happens for overlap <= 4
+    outw, outh = 96, 240
+    imgs = np.stack([R.synth_image(w, h, 4, 900 + (k % 7)) for k in range(n)])
+    fields = [k & 1 for k in range(n)]
+    outs = []
+    for ov, tl in ((1, 0), (overlap, tile)):
+        g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, "ntsc", device=0)
+        g.scanlines = 1
+        g.set_overlap(ov)
+        g.set_pixel_tile(tl)
+        s = crtlib.Settings(_padded(imgs), format=crtlib.FMT_BGRA, field=list(fields), frame=0)
+        g.fieldpass(s, 24)
+        g.fieldpass(s, 24)
+        g.synchronize()
+        outs.append((g.out.cpu().numpy(), g.state.cpu().numpy()))
+        g.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    # and the reference configuration itself is right for a few of the fields
+    orc = R.Oracle("ntsc")
+    for k in (0, 1, 513, 1029):
+        c = orc.new_crt(outw, outh, R.FMT_BGRA)
+        c.set("scanlines", 1)
+        c.settings(imgs[k], format=R.FMT_BGRA, w=w, h=h, as_color=1, field=fields[k], frame=0)
+        for _ in range(2):
+            c.analog[:] = 0
+            c.modulate()
+            c.demodulate(24)
+        np.testing.assert_array_equal(outs[1][0][k].reshape(-1), c.out, err_msg="field %d" % k)
+
+
 def _random_case(rng):
     w = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 333, 640, 753, 800, 1281]))
     h = int(rng.choice([1, 2, 7, 48, 100, 236, 237, 480, 601]))
