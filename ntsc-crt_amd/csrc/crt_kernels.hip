@@ -907,6 +907,9 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
 {
     __shared__ int s_win[4][3][SYNC_WIN / 4];
+    __shared__ int s_fb[4][16];                          /* fallback scratch: 16 hsync + 40 burst bytes per row */
+    __shared__ int s_lines[4][S::LINES * 6];              /* the rows' line tables; written to memory after the loop so
+                                                             that no store sits between the window prefetches */
     const int lane = threadIdx.x;
     const int row = lane >> 4, j = lane & 15;            /* field slot in the wave, lane in the row */
     const int f = blockIdx.x * 4 + row;
@@ -966,11 +969,16 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         if (lidx >= S::VRES) lidx -= S::VRES;
         const int ln = lidx * S::HRES;
         const int a_off = ln + hsync + S::SYNC_BEG - S::HWIN - base_cur;          /* window-relative */
-        int sv = 0;
-        if (j < 2 * S::HWIN) {
-            if (a_off >= 0 && a_off + 2 * S::HWIN <= SYNC_WIN) sv = win[a_off + j];
-            else sv = in[ln + hsync + S::SYNC_BEG - S::HWIN + j];
+        /* the fast path reads LDS only; if the bytes are not in the parked window (rare) the fallback fetches
+         * them into an LDS scratch row INSIDE its own branch, so no memory wait leaks into the common path */
+        signed char *fb = (signed char *) s_fb[row];
+        const bool a_in = a_off >= 0 && a_off + 2 * S::HWIN <= SYNC_WIN;
+        if (!a_in) {
+            if (j < 2 * S::HWIN) fb[j] = in[ln + hsync + S::SYNC_BEG - S::HWIN + j];
+            __builtin_amdgcn_s_waitcnt(0);
         }
+        int sv = 0;
+        if (j < 2 * S::HWIN) sv = a_in ? win[a_off + j] : fb[j];
         const int pref = row_incl_scan(sv);
         const unsigned long long hm = __ballot(j < 2 * S::HWIN && pref <= S::HTHR);
         const unsigned m16 = (unsigned) (hm >> (row * 16)) & 0xffffu;
@@ -1000,14 +1008,16 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         const int b_off = ln + (hsync & ~3) + S::CB_BEG - base_cur;
         const bool b_in = b_off >= 0 && b_off + CB_SAMPLES <= SYNC_WIN;
         const int k0 = ((j & 3) - S::CB_BEG) & 3;
-        int smp[CB_SAMPLES / 4];
-        if (b_in) {
-#pragma unroll
-            for (int q = 0; q < CB_SAMPLES / 4; q++) smp[q] = win[b_off + k0 + 4 * q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < CB_SAMPLES / 4; q++) smp[q] = in[ln + (hsync & ~3) + S::CB_BEG + k0 + 4 * q];
+        if (!b_in) {
+            const signed char *g = in + ln + (hsync & ~3) + S::CB_BEG;
+            if (j < 10) { fb[16 + 4 * j + 0] = g[4 * j + 0]; fb[16 + 4 * j + 1] = g[4 * j + 1];
+                          fb[16 + 4 * j + 2] = g[4 * j + 2]; fb[16 + 4 * j + 3] = g[4 * j + 3]; }
+            __builtin_amdgcn_s_waitcnt(0);
         }
+        const signed char *bsrc = b_in ? win + b_off : fb + 16;
+        int smp[CB_SAMPLES / 4];
+#pragma unroll
+        for (int q = 0; q < CB_SAMPLES / 4; q++) smp[q] = bsrc[k0 + 4 * q];
         const int r = S::VPER == 1 ? 0 : ypos % S::VPER;
         int acc = ccr[0];
 #pragma unroll
@@ -1054,7 +1064,8 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
                 lp.nrows = nrows;
                 lp.hsync = hsync;
             }
-            out_lines[line - S::TOP] = lp;
+            int *d = s_lines[row] + (line - S::TOP) * 6;
+            d[0] = lp.pos; d[1] = lp.wave0; d[2] = lp.wave1; d[3] = lp.beg; d[4] = lp.nrows; d[5] = lp.hsync;
         }
         /* park the window of line + 1 (fetched one iteration ago), keep line + 2's in flight */
         if (line + 1 < S::BOT) {
@@ -1065,6 +1076,14 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         base_p = base_n;
         wp = wn;
         __syncthreads();
+    }
+    /* line tables: LINES * 24 bytes per row, copied out 16 bytes per lane and pass */
+    if (live) {
+        int *dst = (int *) out_lines;
+        for (int i = j * 4; i < S::LINES * 6; i += 64) {
+            v4i v; v.x = s_lines[row][i]; v.y = s_lines[row][i + 1]; v.z = s_lines[row][i + 2]; v.w = s_lines[row][i + 3];
+            store16u(dst + i, v);
+        }
     }
     if (j < 4 && live) {
 #pragma unroll
