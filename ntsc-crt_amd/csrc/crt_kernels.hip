@@ -552,14 +552,53 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     unsigned rn = 0;
     if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, idx0);
     int vals[16];
+    if constexpr (S::IS_NES) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int v = 0;
-        if (!skeleton<S>(P, line, t, field, inv_phase, st.aux, true, v)) v = 0;
-        if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
-        else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
-        vals[k] = v;
-        if (++t == S::HRES) { t = 0; line++; }
+        for (int k = 0; k < 16; k++) {
+            int v = 0;
+            if (!skeleton<S>(P, line, t, field, inv_phase, st.aux, true, v)) v = 0;
+            if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
+            else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
+            vals[k] = v;
+            if (++t == S::HRES) { t = 0; line++; }
+        }
+    } else {
+        /* RGB systems (crt_ntsc.c:205-252): a line of the skeleton is SYNC on [a0,a1) and [b0,b1), carries the
+         * burst on [CB_BEG, CB_BEG+40) if it is an ordinary line, BLANK elsewhere (a clean field has 0 in the
+         * never-written active part).  The ranges are set up per line, each sample costs a few range tests. */
+        unsigned bpack = 0;                                    /* the 4 burst bytes by (t & 3) */
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cb = S::PATTERN == 1 ? P.burst[0][(q + inv_phase * 2) & 3] : P.burst[0][q];
+            bpack |= (unsigned) (((S::BLANK + cb * S::BURST) >> 5) & 255) << (8 * q);
+        }
+        unsigned a0, alen, b0, blen;
+        bool ordinary;
+        auto setup_line = [&](int n) {
+            if (n <= 3 || (n >= 7 && n <= 9)) {                /* equalising pulses */
+                a0 = 0; alen = 4 * S::HRES / 100; b0 = 50 * S::HRES / 100; blen = 54 * S::HRES / 100 - 50 * S::HRES / 100;
+                ordinary = false;
+            } else if (n >= 4 && n <= 6) {                     /* vertical sync */
+                a0 = 0; alen = (field == 1 ? 4 : 46) * S::HRES / 100;
+                b0 = 50 * S::HRES / 100; blen = 96 * S::HRES / 100 - 50 * S::HRES / 100;
+                ordinary = false;
+            } else {                                           /* ordinary line; no sync pulse inside the VHS aberration band */
+                a0 = S::SYNC_BEG; alen = n < S::VRES - st.aux ? S::BW_BEG - S::SYNC_BEG : 0; b0 = 0; blen = 0;
+                ordinary = true;
+            }
+        };
+        setup_line(line);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            int v = S::BLANK;
+            if ((unsigned) t - a0 < alen || (unsigned) t - b0 < blen) v = S::SYNC;
+            if (ordinary && (unsigned) (t - S::CB_BEG) < (unsigned) CB_SAMPLES)
+                v = (int) (signed char) (bpack >> (8 * (t & 3)));
+            if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
+            else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
+            vals[k] = v;
+            if (++t == S::HRES) { t = 0; line++; setup_line(line); }
+        }
     }
     if (len == 16) {
         v4i pk;
