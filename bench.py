@@ -77,6 +77,10 @@ def main():
     ap.add_argument("--scanlines", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--system", default="ntsc", choices=["ntsc", "ntscp0", "vhs", "nes", "nesp0"],
+                    help="non-default systems are extra measurements (BASELINE configs[3], [4]), not the headline")
+    ap.add_argument("--outw", type=int, default=0)
+    ap.add_argument("--outh", type=int, default=0)
     ap.add_argument("--sequence", action="store_true", help="treat the batch as ONE video (crthip_sequence) instead of independent frames")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--pixel-tile", type=int, default=0, help="decoder output tile: 0 auto, 16, 32")
@@ -102,7 +106,11 @@ def main():
     dev = torch.device("cuda", local)
 
     w, h, n = args.width, args.height, args.batch
-    crt = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=local)
+    nes = args.system.startswith("nes")
+    if nes:
+        w, h = 256, 240
+    outw, outh = args.outw or (640 if nes else w), args.outh or (480 if nes else h)
+    crt = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, args.system, device=local)
     crt.scanlines = args.scanlines
     crt.reserve(n)
     crt.set_overlap(args.overlap)
@@ -114,12 +122,19 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
     uniq = min(n, args.unique)
-    base = torch.randint(0, 256, (uniq, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
-    images = base.repeat((n + uniq - 1) // uniq, 1, 1, 1)[:n][:, :h]
-    # this rank's contiguous block of the global batch: frames [rank*n, (rank+1)*n)
-    parity = [shard.field_parity(rank * n + k) for k in range(n)]
-    s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
-                        field=[a for a, _ in parity], frame=[b for _, b in parity])
+    if nes:
+        base = torch.randint(0, 512, (uniq, h + 1, w), dtype=torch.int16, device=dev, generator=gen)
+        images = base.repeat((n + uniq - 1) // uniq, 1, 1)[:n][:, :h]
+        s = crtlib.Settings(images, hue=0, dot_crawl_offset=[(rank * n + k) % 3 for k in range(n)])
+    else:
+        base = torch.randint(0, 256, (uniq, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
+        images = base.repeat((n + uniq - 1) // uniq, 1, 1, 1)[:n][:, :h]
+        # this rank's contiguous block of the global batch: frames [rank*n, (rank+1)*n)
+        parity = [shard.field_parity(rank * n + k) for k in range(n)]
+        s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
+                            field=[a for a, _ in parity], frame=[b for _, b in parity])
+    if args.system == "vhs":
+        crt.srand([1 + rank * n + k for k in range(n)])
 
     # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
     p = crt.params(s, args.noise)
@@ -133,9 +148,10 @@ def main():
             return
         crt.fieldpass(s, args.noise, params=p)
         # next field of the interlaced sequence (video_convert.c:261-267)
-        crt.state[:, crtlib.ST_FIELD] ^= 1
-        if k % 2 == 0:
-            crt.state[:, crtlib.ST_FRAME] ^= 1
+        if not nes:
+            crt.state[:, crtlib.ST_FIELD] ^= 1
+            if k % 2 == 0:
+                crt.state[:, crtlib.ST_FRAME] ^= 1
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -166,7 +182,7 @@ def main():
     if rank == 0:
         total_frames = world * n * args.steps
         fps = total_frames / elapsed
-        abytes = algorithmic_bytes(w, h, 4, w, h, 4, args.scanlines, 0)
+        abytes = algorithmic_bytes(w, h, 2 if nes else 4, outw, outh, 4, args.scanlines, 0, desth=240 if nes else 236)
         achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -180,7 +196,7 @@ def main():
         # ISA-inspected inner loops, 94 VALU ~ 264 cycles per sample and 50 VALU ~ 120 cycles per pixel with
         # the measured issue costs (profiles/r01_valu_issue_rates.txt), 3.75 waves per field, 1024 SIMDs
         valu = None
-        if dom == "decode" and (w, h) == (640, 480):
+        if dom == "decode" and (args.system, w, h, outw, outh) == ("ntsc", 640, 480, 640, 480):
             cycles_per_field = 3.75 * (756 * 264 + 640 * 120)
             clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_final_sq_counters.json
             need_ms = cycles_per_field * n / 1024.0 / clk * 1e3
@@ -192,8 +208,9 @@ def main():
             "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "NTSC %dx%d BGRA -> %dx%d BGRA, interlaced, full colour, noise %d, hue 0, "
-                                   "scanlines %d (BASELINE configs[1])" % (w, h, w, h, args.noise, args.scanlines),
+            "config": {"workload": "%s %dx%d -> %dx%d BGRA, %s, full colour, noise %d, hue 0, scanlines %d%s"
+                                   % (args.system.upper(), w, h, outw, outh, "progressive" if nes else "interlaced", args.noise,
+                                      args.scanlines, " (BASELINE configs[1])" if (args.system, w, h, outw, outh) == ("ntsc", 640, 480, 640, 480) else ""),
                        "fields_per_gpu_per_step": n, "frames_per_step": world * n,
                        "sharding": "frames by rank, RCCL broadcast of settings only",
                        "mode": "one video per GPU (crthip_sequence)" if args.sequence else "independent frames (crthip_fieldpass)"},
@@ -208,7 +225,7 @@ def main():
                          "note": "640x480 is integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(w, h, w, h, args.noise, args.scanlines, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(w, h, outw, outh, args.noise, args.scanlines, args.cpu_seconds) if args.system == "ntsc" else None
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:

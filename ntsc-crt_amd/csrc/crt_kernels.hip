@@ -508,6 +508,156 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* M5, NES flavour (crt_nes.c:162-193) with a lookup table                     */
+/* ------------------------------------------------------------------------- */
+/* A composite sample of the NES is  ((BLACK + black_point + sum_{k<4} square(p, phase+k)) * white_point / 100) >> 12
+ * truncated to a signed char.  square() depends on the phase only through (hue+phase)%12 and (phase>>1)%6,
+ * both 12-periodic, so the sample is a function of (9-bit pixel, phase mod 12): 512 x 12 bytes, rebuilt per
+ * launch because it contains the black / white point knobs. */
+#define NES_TAB_SIZE (512 * 12)
+template <class S>
+__global__ void k_nes_table(const crthip_params P, signed char *tab)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NES_TAB_SIZE) return;
+    const int p = idx / 12, ph = idx - p * 12;
+    int ire = S::BLACK + P.black_point;
+    ire += ppu_level(p, ph + 0);
+    ire += ppu_level(p, ph + 1);
+    ire += ppu_level(p, ph + 2);
+    ire += ppu_level(p, ph + 3);
+    ire = (ire * P.white_point / 100) >> 12;
+    tab[idx] = (signed char) ire;
+}
+
+template <class S, bool NOISE, bool CLAMP, int ACT>
+__global__ void __launch_bounds__(64)
+k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
+             signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
+             const uint2 *__restrict__ jump16, const signed char *__restrict__ tab)
+{
+    constexpr int AC_TILE = ACT, AC_STRIDE = ACT + 1, AC_PIECES = ACT / 4;
+    constexpr int AC_ROWS = 64 / AC_PIECES, AC_SHIFT = ACT == 32 ? 5 : 4;
+    __shared__ unsigned s_pix[64 * AC_STRIDE];
+    __shared__ unsigned s_out[64 * AC_STRIDE];
+    __shared__ unsigned long long s_src[64], s_dst[64];
+    __shared__ unsigned s_tab[NES_TAB_SIZE / 4];
+
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
+    const int rows = S::LINES;
+    const bool live = gid < n_fields * rows;
+    const int f = live ? gid / rows : 0;
+    const int y = live ? gid - f * rows : 0;
+    const crthip_state st = state[f];
+    const unsigned char *img = images + (size_t) f * istride;
+    const int start = (y + P.yo) * S::HRES + P.xo;
+    unsigned rn = 0;
+    if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, start);
+    for (int i = lane; i < NES_TAB_SIZE / 4; i += 64) s_tab[i] = ((const unsigned *) tab)[i];
+
+    const int w = P.w, destw = P.destw;
+    const int qstep = w / destw, rstep = w - qstep * destw;
+    int col = 0, err = 0;
+    const int ngroups = (destw + 3) >> 2;
+    int sy = (y * P.h) / S::LINES;                              /* crt_nes.c:165-168 */
+    if (sy >= P.h) sy = P.h;
+    if (sy < 0) sy = 0;
+    s_src[lane] = (unsigned long long) (img + (size_t) sy * w * 2);
+    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
+    __syncthreads();
+
+    auto drain = [&](int g0, int ng) {
+        __syncthreads();
+        const int orow = lane / AC_PIECES, piece = lane % AC_PIECES;
+        const int first = (g0 + piece * 4) * 4;
+        const int nbytes = destw - first < 16 ? destw - first : 16;
+#pragma unroll 2
+        for (int i = 0; i < AC_PIECES; i++) {
+            const int r = i * AC_ROWS + orow;
+            const unsigned long long d = s_dst[r];
+            if (d != 0 && piece * 4 < ng && nbytes > 0) {
+                const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
+                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+                if (nbytes == 16) {
+                    gstore16u(d + first, o);
+                } else {
+                    const int wds[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    /* pixel tiles: AC_TILE dwords = 2*AC_TILE PPU pixels per row (see k_active) */
+    const int prow_ = lane / AC_PIECES, piece = lane % AC_PIECES;
+    const int row_bytes = w * 2;
+    const int last_tile = (row_bytes - 1) / (AC_TILE * 4);
+    v4i stage[AC_PIECES];
+    auto piece_offset = [&](int tile) {
+        int off = tile * (AC_TILE * 4) + piece * 16;
+        return off > row_bytes - 16 ? row_bytes - 16 : off;
+    };
+    auto fetch = [&](int tile) {
+        const int off = piece_offset(tile);
+#pragma unroll
+        for (int i = 0; i < AC_PIECES; i++) stage[i] = gload16u(s_src[i * AC_ROWS + prow_] + off);
+    };
+    auto stash = [&](int tile) {
+        const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AC_PIECES; i++) {
+            unsigned *d = s_pix + (i * AC_ROWS + prow_) * AC_STRIDE;
+            if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
+            if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
+            if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
+            if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+        }
+        __syncthreads();
+    };
+    int have = 0;
+    fetch(0);
+    stash(0);
+    if (last_tile > 0) fetch(1);
+
+    int ph = 4 * ((y + P.yo + st.aux) % 3);                    /* phasetab {0,4,8}; advances by 3 per sample, mod 12 */
+    const signed char *tb = (const signed char *) s_tab;
+    for (int g = 0; g < ngroups; g++) {
+        unsigned pack = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = 4 * g + k;
+            if (x < destw) {
+                const int need = col >> (AC_SHIFT + 1);         /* wave-uniform */
+                if (need != have) {
+                    if (need != have + 1) fetch(need);
+                    stash(need);
+                    have = need;
+                    if (need < last_tile) fetch(need + 1);
+                }
+                const unsigned dw = s_pix[lane * AC_STRIDE + ((col >> 1) & (AC_TILE - 1))];
+                const int p = (int) ((col & 1) ? dw >> 16 : dw & 0xffffu);
+                /* data[] is unsigned short (crt_nes.h:133): the reference's table walks only look at bits 0-8 */
+                int ire = tb[(p & 511) * 12 + ph];
+                if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                else if (CLAMP) ire = clampi(ire, -127, 127);
+                pack |= (unsigned) (ire & 255) << (8 * k);
+                ph += 3;
+                if (ph >= 12) ph -= 12;
+                col += qstep; err += rstep;
+                if (err >= destw) { err -= destw; col++; }
+            }
+        }
+        s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
+        if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+    }
+}
+
 /* Fused path only: everything OUTSIDE the active rectangle of a field that started from a clean
  * analog[] -- skeleton value (or 0) plus channel noise, written straight into inp[].  The complement
  * of the rectangle in flat sample order is
@@ -1561,6 +1711,7 @@ struct crthip_ctx {
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
     bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tier */
+    signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table, rebuilt per encoder launch */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words */
@@ -1660,6 +1811,16 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const int total = n * p->desth;
     const dim3 grid((total + 63) / 64), block(64);
     const unsigned char *img = (const unsigned char *) d_images;
+    if constexpr (S::IS_NES) {
+        if (p->w >= 8) {
+            hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, c->stream, *p, c->d_nes_tab);
+            if (FULL && p->noise != 0)
+                hipLaunchKernelGGL((k_active_nes<S, true, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
+            else
+                hipLaunchKernelGGL((k_active_nes<S, false, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
+            return;
+        }
+    }
     const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
     const bool noise = FULL && p->noise != 0;
     const bool wide_in = c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
@@ -1789,6 +1950,10 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         return CRTHIP_E_HIP;
     }
     free(h);
+    if (system == CRTHIP_SYSTEM_NES && hipMalloc((void **) &c->d_nes_tab, NES_TAB_SIZE) != hipSuccess) {
+        crthip_destroy(c);
+        return CRTHIP_E_NOMEM;
+    }
     if (system == CRTHIP_SYSTEM_NTSCVHS) {
         /* jump coefficients of the rand() recurrence: one row per parallel chunk + one for the tail */
         const int i0 = sd.input_size - 25 * sd.hres;
@@ -1821,6 +1986,7 @@ void crthip_destroy(crthip_ctx *c)
     if (c->d_jump16) hipFree(c->d_jump16);
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
     if (c->d_seq) hipFree(c->d_seq);
+    if (c->d_nes_tab) hipFree(c->d_nes_tab);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
@@ -2162,6 +2328,7 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh;
     if (need > c->seq_cap) {
         if (c->d_seq) hipFree(c->d_seq);
+    if (c->d_nes_tab) hipFree(c->d_nes_tab);
         c->d_seq = 0; c->seq_cap = 0;
         if (hipMalloc((void **) &c->d_seq, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sequence scratch", hipSuccess);
         c->seq_cap = need;
