@@ -825,10 +825,8 @@ k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ ana
  *   - samples [0, I0] use calls 1+2i, 2+2i: PARALLEL, one lane per VHS_CHUNK samples; the lane's
  *     31-value history at its first call K is obtained from the field's base history by the jump
  *     y[K+j] = sum_m c_K[m] * y[m+j]  (c_K = x^K mod x^31-x^28-1, host-made table `rows`);
- *   - samples (I0, INPUT_SIZE) have a data-dependent call count: ONE LANE PER FIELD walks them
- *     serially with the generator's ring buffer in LDS ([index][lane], conflict-free), and hands
- *     back the final history and rn.
- * Both roles run in the same launch (blockIdx < blocks_a: role A).
+ *   - samples (I0, INPUT_SIZE) have a data-dependent call count: k_vhs_tail, ONE WAVE PER FIELD,
+ *     walks them serially on the scalar unit and hands back the final history and rn.
  */
 #define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 */
 
@@ -859,12 +857,11 @@ template <class S>
 __global__ void __launch_bounds__(64)
 k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
             signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
-            unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a, int blocks_a)
+            const unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a)
 {
     constexpr int I0 = S::INPUT_SIZE - 25 * S::HRES;          /* last sample of the parallel region */
     const int lane = threadIdx.x;
-    if ((int) blockIdx.x < blocks_a) {
-        /* ---- role A: parallel region ---------------------------------------------------- */
+    {
         const int gid = blockIdx.x * 64 + lane;
         if (gid >= n_fields * chunks_a) return;
         const int f = gid / chunks_a;
@@ -914,70 +911,96 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
         }
         return;
     }
-    /* ---- role T: the last 25 lines, one lane per field ------------------------------------ */
-    __shared__ unsigned s_ring[31 * 64];
-    const int f = ((int) blockIdx.x - blocks_a) * 64 + lane;
-    const bool live = f < n_fields;
-    const int fc = live ? f : n_fields - 1;
-    unsigned *h = hist + (size_t) fc * 32;
+}
+
+/* The last 25 lines of a VHS field (data-dependent number of rand() calls per sample), ONE WAVE PER FIELD.
+ * Everything is wave-uniform, so the generator ring (31 values, statically indexed: the loop runs over CALLS
+ * and is unrolled by 31), the A/B/C call state machine of crt_core.c:349-351 and the band's cosine sit in
+ * SGPRs / on the scalar unit; analog[] is fetched 64 samples at a time into one VGPR (v_readlane picks the
+ * current one) and the results leave 64 at a time as one coalesced store. */
+template <class S>
+__global__ void __launch_bounds__(64)
+k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+           signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
+           unsigned *__restrict__ hist, const unsigned *__restrict__ tail_row)
+{
+    constexpr int I0 = S::INPUT_SIZE - 25 * S::HRES;
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (f >= n_fields) return;
+    unsigned *h = hist + (size_t) f * 32;
     unsigned z[61];
 #pragma unroll
     for (int j = 0; j < 31; j++) z[j] = h[j];
 #pragma unroll
     for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
     const int vhs_line = (int) (((z[31] >> 1) & 7u)) - 4 + 14;        /* call #0, crt_core.c:344 */
-    {
-        const unsigned *c = rows + (size_t) chunks_a * 31;            /* x^(2*I0+3): first call of sample I0+1 */
-        unsigned w[31];
+    unsigned w[31];                                                    /* history at the first call of sample I0+1 */
 #pragma unroll
-        for (int j = 0; j < 31; j++) w[j] = 0;
+    for (int j = 0; j < 31; j++) w[j] = 0;
 #pragma unroll
-        for (int m = 0; m < 31; m++) {
-            const unsigned cm = c[m];
+    for (int m = 0; m < 31; m++) {
+        const unsigned cm = tail_row[m];                               /* x^(2*I0+3) */
 #pragma unroll
-            for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 31; j++) s_ring[j * 64 + lane] = w[j];
+        for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
     }
-    int p = 0;                                                       /* ring slot of y[n-31] */
-    auto next = [&]() -> unsigned {
-        int p28 = p + 28;
-        if (p28 >= 31) p28 -= 31;
-        const unsigned v = s_ring[p * 64 + lane] + s_ring[p28 * 64 + lane];
-        s_ring[p * 64 + lane] = v;
-        if (++p == 31) p = 0;
-        return v >> 1;
-    };
-    const signed char *src = analog + (size_t) fc * fstride;
-    signed char *dst = inp + (size_t) fc * fstride;
+    const signed char *src = analog + (size_t) f * fstride;
+    signed char *dst = inp + (size_t) f * fstride;
     const int noise = P.noise;
+
+    int i = I0 + 1;                         /* current sample */
+    int i0 = i;                             /* first sample of the current 64-sample window */
+    int role = 0;                           /* the next call is 0: A_i (noise value), 1: B_i, 2: C_i */
+    int p = 0;                              /* ring slot of the next call once the last sample is out */
     unsigned rn = 0;
-    unsigned pack = 0;
-    for (int i = I0 + 1; i < S::INPUT_SIZE; i++) {
-        int nn = noise;
-        rn = next();                                                  /* :349 */
-        const unsigned r2 = next();                                   /* :350 */
-        if (i > S::INPUT_SIZE - S::HRES * (16 + ((int) (r2 % 20u) - 10))) {
-            const unsigned r3 = next();                               /* :351 */
-            if (i < S::INPUT_SIZE - S::HRES * (5 + ((int) (r3 & 7u) - 4))) {
-                const int ln = (i * vhs_line) / S::HRES;              /* :354-356 */
-                nn = dev_cos14(ln * 8192 / 180) >> 8;
+    int abuf = src[i0 + lane];              /* analog[i0 .. i0+63], one per lane */
+    int obuf = 0;
+    while (i < S::INPUT_SIZE) {
+#pragma unroll
+        for (int t = 0; t < 31; t++) {
+            if (i < S::INPUT_SIZE) {
+                const unsigned v = w[t] + w[(t + 28) % 31];
+                w[t] = v;
+                const unsigned o = v >> 1;
+                bool emit = false;
+                int nn = noise;
+                if (role == 0) {
+                    rn = o;                                                                    /* :349 */
+                    role = 1;
+                } else if (role == 1) {
+                    if (i > S::INPUT_SIZE - S::HRES * (16 + ((int) (o % 20u) - 10))) role = 2;  /* :350 */
+                    else { emit = true; role = 0; }
+                } else {
+                    if (i < S::INPUT_SIZE - S::HRES * (5 + ((int) (o & 7u) - 4))) {             /* :351 */
+                        const int ln = (i * vhs_line) / S::HRES;                               /* :354-356 */
+                        nn = dev_cos14(ln * 8192 / 180) >> 8;
+                    }
+                    emit = true;
+                    role = 0;
+                }
+                if (emit) {
+                    const int a = __builtin_amdgcn_readlane(abuf, i - i0);
+                    int sv = a + (((int) ((rn >> 16) & 0xffu) - 0x7f) * nn >> 8);
+                    sv = clampi(sv, -127, 127);
+                    if (lane == i - i0) obuf = sv;
+                    i++;
+                    if (i - i0 == 64 || i == S::INPUT_SIZE) {
+                        if (i0 + lane < i) dst[i0 + lane] = (signed char) obuf;
+                        i0 = i;
+                        if (i < S::INPUT_SIZE) abuf = src[i0 + lane];   /* the last window reads into the field's slack */
+                        else p = (t + 1) % 31;
+                    }
+                }
             }
         }
-        int s = src[i] + (((int) ((rn >> 16) & 0xffu) - 0x7f) * nn >> 8);
-        s = clampi(s, -127, 127);
-        /* INPUT_SIZE and I0+1 are even multiples of ... not necessarily of 4: plain byte stores */
-        if (live) dst[i] = (signed char) s;
     }
-    (void) pack;
-    if (live) {
-        /* final history in logical order, rn, and the struct tail mirror */
+    /* final history in logical order (slot p holds y[n-31]), rn, and the struct tail mirror */
+    if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < 31; j++) {
-            int q = p + j;
-            if (q >= 31) q -= 31;
-            h[j] = s_ring[q * 64 + lane];
+            int q = j - p;
+            if (q < 0) q += 31;
+            h[q] = w[j];
         }
         state[f].rn = (int) rn;                                       /* crt_core.c:367 */
         signed char *tail = dst + S::INPUT_SIZE;
@@ -2083,9 +2106,12 @@ int crthip_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char
         rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
             using S = decltype(tag);
             ProfScope ps(c, CRTHIP_K_NOISE);
-            const int blocks_a = (n * c->vhs_chunks + 63) / 64, blocks_t = (n + 63) / 64;
-            hipLaunchKernelGGL((k_vhs_noise<S>), dim3(blocks_a + blocks_t), dim3(64), 0, c->stream,
-                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks, blocks_a);
+            /* the tail kernel rewrites the histories the parallel region reads: stream order keeps them apart */
+            hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, c->stream,
+                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks);
+            hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
+                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist,
+                               c->d_vhs_rows + (size_t) c->vhs_chunks * 31);
             return CRTHIP_OK;
         });
         HIPCHK(c, hipGetLastError());
