@@ -820,15 +820,24 @@ k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ ana
 /*
  * crt_core.c:343-357.  rand() is modelled as glibc's y[n] = y[n-31] + y[n-3] (crt_setup.c).  Calls:
  * #0 picks the band's phase (`line`); sample i then makes call A_i (its noise value) and call B_i
- * (always), plus call C_i only when the first half of the && is true.  That can only happen for
- * i > I0 = INPUT_SIZE - 25*HRES, so
- *   - samples [0, I0] use calls 1+2i, 2+2i: PARALLEL, one lane per VHS_CHUNK samples; the lane's
- *     31-value history at its first call K is obtained from the field's base history by the jump
- *     y[K+j] = sum_m c_K[m] * y[m+j]  (c_K = x^K mod x^31-x^28-1, host-made table `rows`);
- *   - samples (I0, INPUT_SIZE) have a data-dependent call count: k_vhs_tail, ONE WAVE PER FIELD,
- *     walks them serially on the scalar unit and hands back the final history and rn.
+ * (always), plus call C_i only when the first half of the && is true:
+ *     c1(i, B) = i > INPUT_SIZE - HRES*(6 + B%20)   <=>   6 + B%20 > floor((INPUT_SIZE - i) / HRES)
+ * which can only happen for i > I0 = INPUT_SIZE - 25*HRES.  So
+ *   - samples [0, T0), T0 = a multiple of VHS_CHUNK just below I0, use calls 1+2i, 2+2i: k_vhs_noise,
+ *     PARALLEL, one lane per VHS_CHUNK samples; the lane's 31-value history at its first call K comes
+ *     from the field's base history by the jump  y[K+j] = sum_m c_K[m] * y[m+j]
+ *     (c_K = x^K mod x^31-x^28-1, host-made table `rows`);
+ *   - samples [T0, INPUT_SIZE) have a data-dependent call count: k_vhs_tail, one wave per field,
+ *     speculative block walk (see there); it hands back the final history and rn.
  */
 #define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 */
+#define VHS_BLK   43                       /* calls per lane in the tail's window: 64 * 43 >= 3 * HRES + 3 */
+
+/* first sample of the tail: a chunk boundary with at least 16 samples (>= 31 calls) before I0 + 1 */
+__host__ __device__ constexpr int vhs_tail_start(int input_size, int hres)
+{
+    return (input_size - 25 * hres + 1 - 16) / VHS_CHUNK * VHS_CHUNK;
+}
 
 __device__ __forceinline__ int dev_sine_q1(int a)
 {
@@ -853,157 +862,256 @@ __device__ __forceinline__ int dev_cos14(int n)
     return cs;
 }
 
+/* Parallel region.  A wave's 64 chunks are (mostly) one contiguous 7936-byte run of the field: it is moved
+ * through an LDS tile of 64 x 31 dwords with coalesced 256-byte requests (lane-per-chunk byte accesses cost
+ * 12x the algorithmic HBM write traffic); the lane's own 31 dwords sit at stride 31 = conflict-free. */
 template <class S>
 __global__ void __launch_bounds__(64)
 k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
-            signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
+            signed char *__restrict__ inp, size_t fstride,
             const unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a)
 {
-    constexpr int I0 = S::INPUT_SIZE - 25 * S::HRES;          /* last sample of the parallel region */
+    constexpr int DW = VHS_CHUNK / 4;                            /* 31 dwords per chunk */
+    __shared__ unsigned s_t[64 * DW];
+    __shared__ unsigned long long s_off[64];
     const int lane = threadIdx.x;
-    {
-        const int gid = blockIdx.x * 64 + lane;
-        if (gid >= n_fields * chunks_a) return;
-        const int f = gid / chunks_a;
-        const int q = gid - f * chunks_a;
-        const unsigned *h = hist + (size_t) f * 32;
-        /* base sequence z[0..60]: the history and the next 30 values */
-        unsigned z[61];
-#pragma unroll
-        for (int j = 0; j < 31; j++) z[j] = h[j];
-#pragma unroll
-        for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
-        /* history of call K = 1 + 248 q */
-        const unsigned *c = rows + (size_t) q * 31;
-        unsigned w[31];
-#pragma unroll
-        for (int j = 0; j < 31; j++) w[j] = 0;
-#pragma unroll
-        for (int m = 0; m < 31; m++) {
-            const unsigned cm = c[m];
-#pragma unroll
-            for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
-        }
-        const int i0 = q * VHS_CHUNK;
-        const signed char *src = analog + (size_t) f * fstride + i0;
-        signed char *dst = inp + (size_t) f * fstride + i0;
-        const int noise = P.noise;
-        /* 4 rounds of 62 calls = 31 samples each; ring index = call % 31 is static */
-        for (int r = 0; r < 4; r++) {
-            unsigned char outb[32];
-#pragma unroll
-            for (int t = 0; t < 62; t++) {
-                const unsigned v = w[t % 31] + w[(t + 28) % 31];
-                w[t % 31] = v;
-                if ((t & 1) == 0) {                                  /* call A of sample r*31 + t/2 */
-                    const int k = r * 31 + t / 2;
-                    const int rn = (int) (v >> 1);
-                    int s = 0;
-                    if (i0 + k <= I0) s = src[k];
-                    s = s + ((((rn >> 16) & 0xff) - 0x7f) * noise >> 8);
-                    outb[t / 2] = (unsigned char) clampi(s, -127, 127);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 31; k++) {
-                if (i0 + r * 31 + k <= I0) dst[r * 31 + k] = (signed char) outb[k];
-            }
-        }
-        return;
+    const int gid = blockIdx.x * 64 + lane;
+    const bool live = gid < n_fields * chunks_a;
+    const int f = live ? gid / chunks_a : 0;
+    const int q = live ? gid - f * chunks_a : 0;
+    s_off[lane] = live ? (unsigned long long) f * fstride + (unsigned long long) q * VHS_CHUNK : ~0ull;
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < DW; it++) {
+        const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
+        const unsigned long long off = s_off[owner];
+        s_t[n] = off != ~0ull ? *(const unsigned *) (analog + off + 4 * d) : 0u;
     }
-}
-
-/* The last 25 lines of a VHS field (data-dependent number of rand() calls per sample), ONE WAVE PER FIELD.
- * Everything is wave-uniform, so the generator ring (31 values, statically indexed: the loop runs over CALLS
- * and is unrolled by 31), the A/B/C call state machine of crt_core.c:349-351 and the band's cosine sit in
- * SGPRs / on the scalar unit; analog[] is fetched 64 samples at a time into one VGPR (v_readlane picks the
- * current one) and the results leave 64 at a time as one coalesced store. */
-template <class S>
-__global__ void __launch_bounds__(64)
-k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
-           signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
-           unsigned *__restrict__ hist, const unsigned *__restrict__ tail_row)
-{
-    constexpr int I0 = S::INPUT_SIZE - 25 * S::HRES;
-    const int f = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (f >= n_fields) return;
-    unsigned *h = hist + (size_t) f * 32;
+    const unsigned *h = hist + (size_t) f * 32;
+    /* base sequence z[0..60]: the history and the next 30 values */
     unsigned z[61];
 #pragma unroll
     for (int j = 0; j < 31; j++) z[j] = h[j];
 #pragma unroll
     for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
-    const int vhs_line = (int) (((z[31] >> 1) & 7u)) - 4 + 14;        /* call #0, crt_core.c:344 */
-    unsigned w[31];                                                    /* history at the first call of sample I0+1 */
+    /* history of call K = 1 + 248 q */
+    const unsigned *c = rows + (size_t) q * 31;
+    unsigned w[31];
 #pragma unroll
     for (int j = 0; j < 31; j++) w[j] = 0;
 #pragma unroll
     for (int m = 0; m < 31; m++) {
-        const unsigned cm = tail_row[m];                               /* x^(2*I0+3) */
+        const unsigned cm = c[m];
 #pragma unroll
         for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
     }
+    const int noise = P.noise;
+    __syncthreads();
+    /* 248 calls = 124 samples; ring index = call % 31 is static */
+    unsigned *mine = s_t + lane * DW;
+    unsigned in4 = 0, out4 = 0;
+#pragma unroll
+    for (int t = 0; t < 2 * VHS_CHUNK; t++) {
+        const unsigned v = w[t % 31] + w[(t + 28) % 31];
+        w[t % 31] = v;
+        if ((t & 1) == 0) {                                      /* call A of sample t/2 */
+            const int k = t / 2;
+            if ((k & 3) == 0) in4 = mine[k >> 2];
+            const int rn = (int) (v >> 1);
+            const int a = (int) (in4 << (24 - 8 * (k & 3))) >> 24;
+            const int sv = clampi(a + ((((rn >> 16) & 0xff) - 0x7f) * noise >> 8), -127, 127);
+            out4 = (k & 3) == 0 ? (unsigned) (sv & 255) : out4 | (unsigned) (sv & 255) << (8 * (k & 3));
+            if ((k & 3) == 3) mine[k >> 2] = out4;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < DW; it++) {
+        const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
+        const unsigned long long off = s_off[owner];
+        if (off != ~0ull) *(unsigned *) (inp + off + 4 * d) = s_t[n];
+    }
+}
+
+/*
+ * The tail: samples [T0, INPUT_SIZE), ONE WAVE PER FIELD.  Sample i starts at call position pos_i and
+ * pos_{i+1} = pos_i + 2 + c1(i, call[pos_i + 1]) -- a serial chain, but c1 depends on i only through
+ * k = floor((INPUT_SIZE - i) / HRES), constant over a SEGMENT of at most HRES samples.  Per segment:
+ *   1. the next 64*43 calls (more than a segment can consume) are generated in parallel: lane b jumps
+ *      to call 43*b of the window (x^(43b), 961 multiply-adds) and produces its block of 43 -> LDS;
+ *   2. every lane walks its own block for each of the three possible entry offsets (the first call of
+ *      a sample inside a block is its call 0, 1 or 2) -> exit offset + sample count;
+ *   3. the 64 results are chained on the scalar unit (v_readlane), giving each block its
+ *      real entry offset and the index of its first sample;
+ *   4. every lane walks its block once more, now producing samples (through LDS byte staging); the
+ *      lane that meets the segment's last sample publishes the next window's start and `rn`.
+ */
+template <class S>
+__global__ void __launch_bounds__(64)
+k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+           signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
+           unsigned *__restrict__ hist, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows)
+{
+    constexpr int N = S::INPUT_SIZE, H = S::HRES, B = VHS_BLK;
+    constexpr int T0 = vhs_tail_start(N, H);
+    constexpr int NB = (H + 63) / 64;                              /* bytes per lane and segment */
+    static_assert(64 * B >= 3 * H + 3, "window too small for a segment");
+    __shared__ unsigned s_y[64 * B + 8];                           /* the window's raw generator values */
+    __shared__ unsigned s_h[64];                                   /* 31-value history in front of the window; base sequence */
+    __shared__ unsigned s_misc[2];
+    __shared__ signed char s_a[NB * 64], s_o[NB * 64];
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (f >= n_fields) return;
+    unsigned *h = hist + (size_t) f * 32;
     const signed char *src = analog + (size_t) f * fstride;
     signed char *dst = inp + (size_t) f * fstride;
     const int noise = P.noise;
 
-    int i = I0 + 1;                         /* current sample */
-    int i0 = i;                             /* first sample of the current 64-sample window */
-    int role = 0;                           /* the next call is 0: A_i (noise value), 1: B_i, 2: C_i */
-    int p = 0;                              /* ring slot of the next call once the last sample is out */
-    unsigned rn = 0;
-    int abuf = src[i0 + lane];              /* analog[i0 .. i0+63], one per lane */
-    int obuf = 0;
-    while (i < S::INPUT_SIZE) {
+    /* the field's base sequence -> the history in front of call 1 + 2*T0 (lane j computes element j) */
+    int vhs_line;
+    {
+        unsigned zf[61];
 #pragma unroll
-        for (int t = 0; t < 31; t++) {
-            if (i < S::INPUT_SIZE) {
-                const unsigned v = w[t] + w[(t + 28) % 31];
-                w[t] = v;
-                const unsigned o = v >> 1;
-                bool emit = false;
-                int nn = noise;
-                if (role == 0) {
-                    rn = o;                                                                    /* :349 */
-                    role = 1;
-                } else if (role == 1) {
-                    if (i > S::INPUT_SIZE - S::HRES * (16 + ((int) (o % 20u) - 10))) role = 2;  /* :350 */
-                    else { emit = true; role = 0; }
-                } else {
-                    if (i < S::INPUT_SIZE - S::HRES * (5 + ((int) (o & 7u) - 4))) {             /* :351 */
-                        const int ln = (i * vhs_line) / S::HRES;                               /* :354-356 */
-                        nn = dev_cos14(ln * 8192 / 180) >> 8;
+        for (int j = 0; j < 31; j++) zf[j] = h[j];
+#pragma unroll
+        for (int j = 31; j < 61; j++) zf[j] = zf[j - 31] + zf[j - 3];
+        vhs_line = (int) ((zf[31] >> 1) & 7u) - 4 + 14;            /* call #0, crt_core.c:344 */
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 61; j++) s_y[j] = zf[j];
+        }
+        __syncthreads();
+        unsigned acc = 0;
+        const int j = lane < 31 ? lane : 0;
+        for (int m = 0; m < 31; m++) acc += tail_row[m] * s_y[m + j];
+        __syncthreads();
+        if (lane < 31) s_h[lane] = acc;
+    }
+    unsigned cb[31];                                               /* x^(43*lane) */
+#pragma unroll
+    for (int m = 0; m < 31; m++) cb[m] = blk_rows[m * 64 + lane];
+    __syncthreads();
+
+    int seg_start = T0;
+    while (seg_start < N) {
+        const int kseg = (N - seg_start) / H;
+        int seg_end = N - H * kseg;                                /* last sample with floor((N - i) / H) == kseg */
+        if (seg_end > N - 1) seg_end = N - 1;
+        const int n_s = seg_end - seg_start + 1;
+
+        int abytes[NB];
+#pragma unroll
+        for (int r = 0; r < NB; r++) {
+            const int idx = r * 64 + lane;
+            abytes[r] = idx < n_s ? src[seg_start + idx] : 0;
+        }
+
+        /* 1. my block of the window */
+        unsigned z[61];
+#pragma unroll
+        for (int j = 0; j < 31; j++) z[j] = s_h[j];
+#pragma unroll
+        for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
+        unsigned w[31];
+#pragma unroll
+        for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+        for (int m = 0; m < 31; m++) {
+#pragma unroll
+            for (int j = 0; j < 31; j++) w[j] += cb[m] * z[m + j];
+        }
+        unsigned glo = 0, ghi = 0;                                 /* c1 flags of my 43 calls (as B calls of this segment) */
+#pragma unroll
+        for (int t = 0; t < B; t++) {
+            const unsigned v = w[t % 31] + w[(t + 28) % 31];
+            w[t % 31] = v;
+            s_y[lane * B + t] = v;
+            const unsigned flag = (6 + (int) ((v >> 1) % 20u) > kseg) ? 1u : 0u;
+            if (t < 32) glo |= flag << t; else ghi |= flag << (t - 32);
+        }
+        {
+            const unsigned nb = (unsigned) __shfl_down((int) (glo & 1u), 1);   /* call 43 = the next block's call 0 */
+            if (lane < 63) ghi |= nb << (B - 32);
+        }
+#pragma unroll
+        for (int r = 0; r < NB; r++) s_a[r * 64 + lane] = (signed char) abytes[r];
+        const unsigned long long G = ((unsigned long long) ghi << 32) | glo;
+
+        /* 2. speculative walks: entry offset e -> (samples, exit offset) */
+        unsigned res = 0;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            int pos = e, cnt = 0;
+#pragma unroll
+            for (int it = 0; it < (B + 1) / 2; it++) {
+                const bool in = pos < B;
+                const int step = 2 + (int) ((G >> (pos + 1)) & 1ull);
+                pos += in ? step : 0;
+                cnt += in ? 1 : 0;
+            }
+            res |= (unsigned) (cnt | (pos - B) << 5) << (8 * e);
+        }
+
+        /* 3. chain the blocks */
+        int e_in = 0, first = n_s;
+        {
+            int e = 0, cum = 0;
+            for (int b = 0; b < 64 && cum < n_s; b++) {
+                const unsigned r = (unsigned) __builtin_amdgcn_readlane((int) res, b) >> (8 * e);
+                if (lane == b) { e_in = e; first = cum; }
+                cum += (int) (r & 31u);
+                e = (int) ((r >> 5) & 3u);
+            }
+        }
+        __syncthreads();
+
+        /* 4. samples (crt_core.c:347-365) */
+        {
+            int pos = e_in;
+            for (int k = 0; k < (B + 1) / 2; k++) {
+                const int s = first + k;
+                const bool valid = pos < B && s < n_s;
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break;
+                if (valid) {
+                    const unsigned *yp = s_y + lane * B + pos;
+                    const unsigned rnv = yp[0] >> 1, r2 = yp[1] >> 1;
+                    const int i = seg_start + s;
+                    const int c1 = 6 + (int) (r2 % 20u) > kseg ? 1 : 0;
+                    int nn = noise;
+                    if (c1) {
+                        const unsigned r3 = yp[2] >> 1;
+                        if (i < N - H * (5 + ((int) (r3 & 7u) - 4))) {
+                            const int ln = (i * vhs_line) / H;
+                            nn = dev_cos14(ln * 8192 / 180) >> 8;
+                        }
                     }
-                    emit = true;
-                    role = 0;
-                }
-                if (emit) {
-                    const int a = __builtin_amdgcn_readlane(abuf, i - i0);
-                    int sv = a + (((int) ((rn >> 16) & 0xffu) - 0x7f) * nn >> 8);
-                    sv = clampi(sv, -127, 127);
-                    if (lane == i - i0) obuf = sv;
-                    i++;
-                    if (i - i0 == 64 || i == S::INPUT_SIZE) {
-                        if (i0 + lane < i) dst[i0 + lane] = (signed char) obuf;
-                        i0 = i;
-                        if (i < S::INPUT_SIZE) abuf = src[i0 + lane];   /* the last window reads into the field's slack */
-                        else p = (t + 1) % 31;
-                    }
+                    const int sv = (int) s_a[s] + (((int) ((rnv >> 16) & 0xffu) - 0x7f) * nn >> 8);
+                    s_o[s] = (signed char) clampi(sv, -127, 127);
+                    pos += 2 + c1;
+                    if (s == n_s - 1) { s_misc[0] = (unsigned) (lane * B + pos); s_misc[1] = rnv; }
                 }
             }
         }
-    }
-    /* final history in logical order (slot p holds y[n-31]), rn, and the struct tail mirror */
-    if (lane == 0) {
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 31; j++) {
-            int q = j - p;
-            if (q < 0) q += 31;
-            h[q] = w[j];
+        for (int r = 0; r < NB; r++) {
+            const int idx = r * 64 + lane;
+            if (idx < n_s) dst[seg_start + idx] = s_o[idx];
         }
-        state[f].rn = (int) rn;                                       /* crt_core.c:367 */
-        signed char *tail = dst + S::INPUT_SIZE;
+        /* the next window starts at the first call after this segment's last sample */
+        const int pos_end = (int) s_misc[0];
+        unsigned hv = 0;
+        if (lane < 31) hv = s_y[pos_end - 31 + lane];
+        __syncthreads();
+        if (lane < 31) s_h[lane] = hv;
+        __syncthreads();
+        seg_start += n_s;
+    }
+    if (lane < 31) h[lane] = s_h[lane];                            /* the generator's state after the field */
+    if (lane == 0) {
+        state[f].rn = (int) s_misc[1];                             /* crt_core.c:367 */
+        signed char *tail = dst + N;
         store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
     }
 }
@@ -1737,7 +1845,7 @@ struct crthip_ctx {
     signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table, rebuilt per encoder launch */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
-    unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words */
+    unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
     int vhs_chunks;
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
@@ -1978,16 +2086,25 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         return CRTHIP_E_NOMEM;
     }
     if (system == CRTHIP_SYSTEM_NTSCVHS) {
-        /* jump coefficients of the rand() recurrence: one row per parallel chunk + one for the tail */
-        const int i0 = sd.input_size - 25 * sd.hres;
-        const int chunks = (i0 + 1 + 124 - 1) / 124;
-        unsigned *rows = (unsigned *) malloc(sizeof(unsigned) * 31 * (size_t) (chunks + 1));
+        /* jump coefficients of the rand() recurrence: one row per parallel chunk, one for the first call of
+         * the tail, and the tail's 64 block offsets (transposed: [m][block]) */
+        const int chunks = vhs_tail_start(sd.input_size, sd.hres) / VHS_CHUNK;
+        const size_t words = 31 * (size_t) (chunks + 1) + 31 * 64;
+        unsigned *rows = (unsigned *) malloc(sizeof(unsigned) * words);
         if (!rows) { crthip_destroy(c); return CRTHIP_E_NOMEM; }
-        crt_setup_vhs_power_table(1ul, 248ul, chunks, rows);
-        crt_setup_vhs_power(2ul * (unsigned long) i0 + 3ul, rows + 31 * (size_t) chunks);
+        crt_setup_vhs_power_table(1ul, 2ul * VHS_CHUNK, chunks, rows);
+        crt_setup_vhs_power(1ul + 2ul * (unsigned long) chunks * VHS_CHUNK, rows + 31 * (size_t) chunks);
+        {
+            unsigned blk[31 * 64];
+            unsigned *t = rows + 31 * (size_t) (chunks + 1);
+            crt_setup_vhs_power_table(0ul, (unsigned long) VHS_BLK, 64, blk);
+            for (int b = 0; b < 64; b++) {
+                for (int m = 0; m < 31; m++) t[m * 64 + b] = blk[b * 31 + m];
+            }
+        }
         c->vhs_chunks = chunks;
-        if (hipMalloc((void **) &c->d_vhs_rows, sizeof(unsigned) * 31 * (size_t) (chunks + 1)) != hipSuccess ||
-            hipMemcpy(c->d_vhs_rows, rows, sizeof(unsigned) * 31 * (size_t) (chunks + 1), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMalloc((void **) &c->d_vhs_rows, sizeof(unsigned) * words) != hipSuccess ||
+            hipMemcpy(c->d_vhs_rows, rows, sizeof(unsigned) * words, hipMemcpyHostToDevice) != hipSuccess) {
             free(rows);
             crthip_destroy(c);
             return CRTHIP_E_HIP;
@@ -2106,12 +2223,14 @@ int crthip_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char
         rc = dispatch_system(c->system, c->pattern, [&](auto tag) {
             using S = decltype(tag);
             ProfScope ps(c, CRTHIP_K_NOISE);
-            /* the tail kernel rewrites the histories the parallel region reads: stream order keeps them apart */
-            hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, c->stream,
-                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks);
-            hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
-                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist,
-                               c->d_vhs_rows + (size_t) c->vhs_chunks * 31);
+            if constexpr (S::IS_VHS) {
+                /* the tail kernel rewrites the histories the parallel region reads: stream order keeps them apart */
+                hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, c->stream,
+                                   *p, n, d_analog, d_inp, c->fstride, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks);
+                hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
+                                   *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist,
+                                   c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
+            }
             return CRTHIP_OK;
         });
         HIPCHK(c, hipGetLastError());
