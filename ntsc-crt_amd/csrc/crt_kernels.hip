@@ -2348,17 +2348,21 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     signed char *analog = c->d_analog + (size_t) first * c->fstride;
     crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
     if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
-        /* VHS noise follows the C library's rand() stream, not the LCG: encode into a clean analog[],
-         * then the dedicated noise kernel (which also produces rn) */
-        hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
+        /* VHS noise follows the C library's rand() stream, not the LCG: the fused encoder (margins + active
+         * rectangle = every sample of the field) runs with noise 0 into analog[], then the dedicated noise
+         * kernels (which also produce rn) */
         int r = CRTHIP_OK;
         if (enc == 0) {
+            crthip_params clean = *p;
+            clean.noise = 0;
             r = dispatch_system(c->system, c->pattern, [&](auto tag) {
                 using S = decltype(tag);
-                launch_encoder<S, false>(c, p, n, img, istride, analog, st, 0);
+                launch_encoder<S, true>(c, &clean, n, img, istride, analog, st, 1);
                 hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, st);
                 return CRTHIP_OK;
             });
+        } else {
+            hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);   /* crt_modulate refused the format */
         }
         if (r) return r;
         if (p->out_bpp == 0) return CRTHIP_OK;
