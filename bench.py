@@ -44,24 +44,33 @@ def algorithmic_bytes(w, h, in_bpp, outw, outh, out_bpp, scanlines, blend, lines
     return b
 
 
-def cpu_baseline(w, h, outw, outh, noise, scanlines, budget_s):
+def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s):
     """Time the reference (or the oracle port) on ONE host core on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import crtref as R
-    if R.have_ref("ntsc"):
-        lib, kind = R.RefLib("ntsc"), "reference"
+    if R.have_ref(system):
+        lib, kind = R.RefLib(system), "reference"
     else:
         R.build_oracle()
-        lib, kind = R.Oracle("ntsc"), "port"
-    img = R.synth_image(w, h, 4, 12345)
+        lib, kind = R.Oracle(system), "port"
     c = lib.new_crt(outw, outh, R.FMT_BGRA)
     c.set("scanlines", scanlines)
-    c.settings(img, format=R.FMT_BGRA, w=w, h=h, as_color=1, hue=0, field=0, frame=0)
-    t, _, _ = c.time_fieldpasses(noise, 20, True)            # warm-up + calibration
+    nes = system.startswith("nes")
+    if nes:
+        ppu = R.synth_ppu(w, h, 12345)
+        img = np.concatenate([ppu, ppu[-1:]])                 # the reference reads one row past the image (sic)
+        c.settings(img, w=w, h=h, dot_crawl_offset=0, hue=0)
+    else:
+        img = R.synth_image(w, h, 4, 12345)
+        c.settings(np.concatenate([img, img[-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1, hue=0, field=0, frame=0)
+    if system == "vhs":
+        lib.srand(1)
+    t, _, _ = c.time_fieldpasses(noise, 20, not nes)         # warm-up + calibration
     reps = max(50, min(4000, int(budget_s / (t / 20))))
-    t, _, _ = c.time_fieldpasses(noise, reps, True)
+    t, _, _ = c.time_fieldpasses(noise, reps, not nes)
     return {"value": reps / t, "unit": "frames/sec", "cores": 1, "kind": kind,
-            "sample": "%d field-passes of the same 640x480 interlaced noise-%d workload, 1 thread" % (reps, noise),
+            "sample": "%d field-passes of the same %s %dx%d -> %dx%d noise-%d workload, 1 thread" % (reps, system, w, h, outw, outh, noise),
             "host_cores_visible": os.cpu_count()}
 
 
@@ -186,7 +195,8 @@ def main():
         achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        headline = (args.system, w, h, outw, outh, args.noise, args.scanlines) == ("ntsc", 640, 480, 640, 480, 24, 1)
+        if headline and os.path.exists(tpath):               # the PMC passes were made on the headline workload only
             try:
                 traffic = json.load(open(tpath)).get("k_" + dom + "_bytes_per_field")
                 traffic = traffic * n if traffic else None
@@ -225,7 +235,7 @@ def main():
                          "note": "640x480 is integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(w, h, outw, outh, args.noise, args.scanlines, args.cpu_seconds) if args.system == "ntsc" else None
+            out["cpu_baseline"] = cpu_baseline(args.system, w, h, outw, outh, args.noise, args.scanlines, args.cpu_seconds)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:

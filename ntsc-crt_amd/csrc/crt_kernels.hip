@@ -2477,7 +2477,6 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh;
     if (need > c->seq_cap) {
         if (c->d_seq) hipFree(c->d_seq);
-    if (c->d_nes_tab) hipFree(c->d_nes_tab);
         c->d_seq = 0; c->seq_cap = 0;
         if (hipMalloc((void **) &c->d_seq, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sequence scratch", hipSuccess);
         c->seq_cap = need;
