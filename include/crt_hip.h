@@ -240,7 +240,8 @@ int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
 /* The decoder and encoder normally run kernels whose multiplies are the full-rate 24-bit
  * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,
  * "24-bit multiply envelope"), everything else goes to the exact 32-bit instantiation.  Both
- * give identical results; this switch forces the 32-bit kernels everywhere (tests, debugging). */
+ * give identical results; this switch forces the 32-bit kernels everywhere (tests, debugging).
+ * on: 0 automatic, 1 exact kernels only, 2 no 64-bit-mad tiers, 3 64-bit-mad tier but all filter cascades. */
 int  crthip_set_exact(crthip_ctx *ctx, int on);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg).

@@ -328,7 +328,8 @@ class CRT:
 
     def set_exact(self, on=True):
         """1/True: force the exact 32-bit-multiply kernels everywhere; 2: allow the 24-bit tier but not the
-        64-bit-mad decoder tier; 0: normal dispatch by proven operand range."""
+        64-bit-mad decoder tiers; 3: 64-bit-mad tier, but never drop the I/Q low cascades; 0: normal dispatch
+        by proven operand range."""
         self._check(self.L.crthip_set_exact(self.ctx, int(on)), "crthip_set_exact")
 
     def set_overlap(self, chunks):

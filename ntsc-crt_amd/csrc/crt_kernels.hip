@@ -91,11 +91,13 @@ static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES ==
 
 #define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
 #define CRTHIP_LINE_NROWS_MASK 0xffff     /* crthip_line.nrows bits 0-15: rows written              */
-#define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-28: rank among lines starting on the same row   */
-#define CRTHIP_LINE_RANK_MASK  0x1fff
+#define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-27: rank among lines starting on the same row   */
+#define CRTHIP_LINE_RANK_MASK  0xfff
+#define CRTHIP_LINE_WIDE  0x10000000      /* bit 28: chroma too strong to drop the I/Q low cascades (decoder tier 0) */
 #define CRTHIP_LINE_NOT64 0x20000000      /* bit 29: outside the no-wrap envelope of the 64-bit-mad decoder */
-#define T0_WAVE_MAX       120000          /* |wave[k]| bound of decoder tier 0 */
-#define T0_BRIGHT_MAX     2600            /* |bright| bound of decoder tier 0  */
+#define LOSKIP_WAVE_MAX   65532           /* |wave[k]| bound of decoder tier 0: |s*wave >> 9| <= 16383 */
+#define T0_WAVE_MAX       120000          /* |wave[k]| bound of decoder tiers 0 and 1 */
+#define T0_BRIGHT_MAX     2600            /* |bright| bound of decoder tiers 0 and 1  */
 #define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
 #define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
 #define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
@@ -1381,6 +1383,8 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
                     nrows |= CRTHIP_LINE_EXACT;
                 else if (lp.wave0 > T0_WAVE_MAX || lp.wave0 < -T0_WAVE_MAX || lp.wave1 > T0_WAVE_MAX || lp.wave1 < -T0_WAVE_MAX)
                     nrows |= CRTHIP_LINE_NOT64;
+                else if (lp.wave0 > LOSKIP_WAVE_MAX || lp.wave0 < -LOSKIP_WAVE_MAX || lp.wave1 > LOSKIP_WAVE_MAX || lp.wave1 < -LOSKIP_WAVE_MAX)
+                    nrows |= CRTHIP_LINE_WIDE;
                 lp.nrows = nrows;
                 lp.hsync = hsync;
             }
@@ -1480,20 +1484,39 @@ __device__ __forceinline__ void eq64_reset(Eq64 &f)
     f.lo0 = f.lo1 = f.lo2 = f.lo3 = f.hi0 = f.hi1 = f.hi2 = f.hi3 = (long) KROUND64;
     f.h0 = f.h1 = f.h2 = 0;
 }
-/* lfm / hfm: pre-shifted multipliers (see above); NEAR1: coefficients are >= 2^15 */
-template <bool NEAR1, int G1, int G2>
+/* lfm / hfm: pre-shifted multipliers (see above); NEAR1: coefficients are >= 2^15.
+ * The band gains (crt_core.c:203-206) are applied as (r * g) >> 16 per band IN 32-BIT WRAPPING ARITHMETIC, i.e.
+ * a gain of 65536 is "sign-extend the low 16 bits".  Inside the envelopes that is the identity:
+ *   luma   |lo3|, |hi3| <= 2727                     -> low band = lo3, mid band (gain 8192) = (hi3 - lo3) >> 3
+ *   chroma gains (65536, 65536, g2): low + mid = lo3 + (hi3 - lo3) = hi3 whenever |lo3|, |hi3 - lo3| < 2^15.
+ *          LOSKIP (tier 0, |wave| <= LOSKIP_WAVE_MAX): every stage output stays inside the hull of its inputs
+ *          (0 < c < 2^16, round-to-nearest never overshoots), the input is |s * wave >> 9| <= 16383, hence
+ *          |lo3| <= 16383 and |hi3 - lo3| <= 32766: the four low stages feed nothing and are not computed. */
+template <bool NEAR1, int G1, int G2, bool LOSKIP>
 __device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, const long sp)
 {
 #define EQ64_STAGE(X, UPAIR, M) X = rearm(mad64(hi32(UPAIR) - hi32(X), M, NEAR1 ? UPAIR : X))
-    EQ64_STAGE(f.lo0, sp, lfm);    EQ64_STAGE(f.hi0, sp, hfm);
-    EQ64_STAGE(f.lo1, f.lo0, lfm); EQ64_STAGE(f.hi1, f.hi0, hfm);
-    EQ64_STAGE(f.lo2, f.lo1, lfm); EQ64_STAGE(f.hi2, f.hi1, hfm);
-    EQ64_STAGE(f.lo3, f.lo2, lfm); EQ64_STAGE(f.hi3, f.hi2, hfm);
+    static_assert(!LOSKIP || G1 == 65536, "dropping the low cascade needs low gain == mid gain == 65536");
+    if (!LOSKIP) {
+        EQ64_STAGE(f.lo0, sp, lfm);
+        EQ64_STAGE(f.lo1, f.lo0, lfm);
+        EQ64_STAGE(f.lo2, f.lo1, lfm);
+        EQ64_STAGE(f.lo3, f.lo2, lfm);
+    }
+    EQ64_STAGE(f.hi0, sp, hfm);
+    EQ64_STAGE(f.hi1, f.hi0, hfm);
+    EQ64_STAGE(f.hi2, f.hi1, hfm);
+    EQ64_STAGE(f.hi3, f.hi2, hfm);
 #undef EQ64_STAGE
     const int lo3 = hi32(f.lo3), hi3 = hi32(f.hi3);
-    int r = (lo3 * 65536) >> 16;
-    if (G1 == 65536 || G1 == 8192) r += ((hi3 - lo3) * G1) >> 16;
-    else r += __mul24(hi3 - lo3, G1) >> 16;
+    int r;
+    if (LOSKIP) r = hi3;
+    else if (NEAR1 && G1 == 8192) r = lo3 + ((hi3 - lo3) >> 3);        /* luma envelope, see above */
+    else {
+        r = (lo3 * 65536) >> 16;
+        if (G1 == 65536 || G1 == 8192) r += ((hi3 - lo3) * G1) >> 16;
+        else r += __mul24(hi3 - lo3, G1) >> 16;
+    }
     if (G2 != 0) {
         r += __mul24(f.h2 - hi3, G2) >> 16;
         f.h2 = f.h1; f.h1 = f.h0; f.h0 = hi32(sp);
@@ -1529,7 +1552,8 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
 /* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
-/* TIER: 0 = 64-bit-mad stages, 1 = 24-bit mads, 2 = exact 32-bit multiplies; a line is decoded by the kernel
+/* TIER: 0 = 64-bit-mad stages without the I/Q low cascades, 1 = 64-bit-mad stages, 2 = 24-bit mads,
+ * 3 = exact 32-bit multiplies; a line is decoded by the kernel
  * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
  * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
 template <class S, int TIER, bool BPP3, int PXT>
@@ -1538,7 +1562,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
          int want_rank)
 {
-    constexpr bool FAST = TIER <= 1;        /* tiers 0 and 1 use 24-bit multiplies outside the filter stages */
+    constexpr bool FAST = TIER <= 2;        /* tiers 0-2 use 24-bit multiplies outside the filter stages */
+    constexpr bool LOSKIP = TIER == 0;
     __shared__ unsigned s_in[64 * IN_STRIDE];
     constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
     __shared__ unsigned s_px[64 * PX_STRIDE];
@@ -1552,7 +1577,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
     const int f = live ? gid / S::LINES : 0;
     if (live) lp = lines[gid];
-    int tier = (lp.nrows & CRTHIP_LINE_EXACT) ? 2 : (lp.nrows & CRTHIP_LINE_NOT64) ? 1 : 0;
+    int tier = (lp.nrows & CRTHIP_LINE_EXACT) ? 3 : (lp.nrows & CRTHIP_LINE_NOT64) ? 2 : (lp.nrows & CRTHIP_LINE_WIDE) ? 1 : 0;
     if (tier < min_tier) tier = min_tier;          /* batch-wide floor from the host (brightness, contrast) */
     int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
     const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
@@ -1623,10 +1648,10 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
                 const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
                 int cy, ci, cq;
-                if (TIER == 0) {
-                    cy = eq_step64<true, 8192, 9175>(wy, ylfm, yhfm, pair_of(s + bright)) << 4;
-                    ci = eq_step64<false, 65536, 1311>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
-                    cq = eq_step64<false, 65536, 0>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
+                if (TIER <= 1) {
+                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright)) << 4;
+                    ci = eq_step64<false, 65536, 1311, LOSKIP>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
+                    cq = eq_step64<false, 65536, 0, LOSKIP>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
                 } else {
                     cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
                     ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
@@ -1841,7 +1866,8 @@ struct crthip_ctx {
     crthip_line *d_lines;
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
-    bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tier */
+    bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tiers */
+    bool no_loskip;             /* debug/test: never drop the I/Q low cascades */
     signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table, rebuilt per encoder launch */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
@@ -2282,12 +2308,12 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 {
     const int b = p->bright < 0 ? -p->bright : p->bright;
     const int ct = p->contrast < 0 ? -p->contrast : p->contrast;
-    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23)) return 2;
+    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23)) return 3;
     const bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
                          p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
                          p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
-    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX) return 1;
-    return 0;
+    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX) return 2;
+    return c->no_loskip ? 1 : 0;
 }
 
 static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
@@ -2312,11 +2338,13 @@ static int launch_decode(crthip_ctx *c, const crthip_params *p, int n, const sig
             if (p->out_bpp == 3) {
                 if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, true);
                 if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, true);
-                CRTHIP_LAUNCH_DECODE(2, true);
+                if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, true);
+                CRTHIP_LAUNCH_DECODE(3, true);
             } else {
                 if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, false);
                 if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, false);
-                CRTHIP_LAUNCH_DECODE(2, false);
+                if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, false);
+                CRTHIP_LAUNCH_DECODE(3, false);
             }
 #undef CRTHIP_LAUNCH_DECODE
         }
@@ -2559,7 +2587,8 @@ int crthip_set_exact(crthip_ctx *c, int on)
 {
     if (!c) return CRTHIP_E_ARG;
     c->force_exact = on == 1;
-    c->no_tier0 = on == 2;      /* 2: allow the 24-bit tier but not the 64-bit-mad one */
+    c->no_tier0 = on == 2;      /* 2: allow the 24-bit tier but not the 64-bit-mad ones */
+    c->no_loskip = on == 3;     /* 3: allow the 64-bit-mad tier but keep the I/Q low cascades */
     return CRTHIP_OK;
 }
 

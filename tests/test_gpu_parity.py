@@ -64,6 +64,9 @@ CASES = [
     ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(saturation=40)),
     ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(brightness=5000, contrast=20)),
     ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 60, dict(as_color=1), dict(brightness=-2600, saturation=24)),
+    # either side of tier 0's chroma bound (|wave| <= 65532: I/Q low cascades dropped), with heavy noise
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 110, dict(as_color=1, hue=77), dict(saturation=13)),
+    ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 110, dict(as_color=1, hue=77), dict(saturation=14)),
     # outside the 24-bit multiply envelope: huge saturation (lines flagged CRTHIP_LINE_EXACT by k_sync) ...
     ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1), dict(saturation=900, contrast=300)),
     # ... and huge brightness / contrast / white point (host-side check picks the exact kernels)
@@ -149,11 +152,12 @@ def test_fused_fieldpass_parity(crtlib, case):
     _run_case(crtlib, CASES[case], fused=True)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("case", [1, 2, 3, 5])
 def test_slower_decoder_tiers_parity(crtlib, case, mode):
-    """ordinary inputs normally run decoder tier 0 (64-bit mads); force tier 2 (mode 1: exact 32-bit
-    multiplies everywhere) and tier 1 (mode 2: 24-bit mads) onto them"""
+    """ordinary inputs normally run decoder tier 0 (64-bit mads, no I/Q low cascades); force tier 3 (mode 1:
+    exact 32-bit multiplies everywhere), tier 2 (mode 2: 24-bit mads) and tier 1 (mode 3: 64-bit mads, all
+    cascades) onto them"""
     _run_case(crtlib, CASES[case], fused=True, exact=mode, steps=2)
 
 
