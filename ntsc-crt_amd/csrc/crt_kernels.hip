@@ -150,6 +150,14 @@ template <bool FAST> __device__ __forceinline__ int mulq_vs(int v, int s_uniform
     return v * s_uniform;
 }
 
+/* vgpr * sgpr + vgpr, 24-bit operands */
+__device__ __forceinline__ int mad24_vs(int v, int s_uniform, int acc)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(s_uniform), "v"(acc));
+    return r;
+}
+
 /* noise LCG, crt_core.c:359-364 */
 __device__ __forceinline__ unsigned lcg_step(unsigned rn) { return LCG_MUL * rn + LCG_ADD; }
 __device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)
@@ -1649,7 +1657,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
                 int cy, ci, cq;
                 if (TIER <= 1) {
-                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright)) << 4;
+                    /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
+                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
                     ci = eq_step64<false, 65536, 1311, LOSKIP>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
                     cq = eq_step64<false, 65536, 0, LOSKIP>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
                 } else {
@@ -1660,14 +1669,21 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 /* D9: every output pixel whose left tap is sample x-1 is now computable */
                 while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
                     const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
-                    const int yy = (mulq_vs<FAST>(py, L) >> 2) + (mulq<FAST>(cy, R) >> 2);
-                    const int ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq<FAST>(ci, R) >> 14);
-                    const int qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq<FAST>(cq, R) >> 14);
+                    int yy;
+                    if (TIER <= 1) {
+                        /* crt_core.c:556: (py * L >> 2) + (cy * R >> 2) with py, cy = luma << 4.  |luma| <= 4173
+                         * inside the tier's envelope, so no product wraps and both shifts are exact */
+                        yy = mad24_vs(cy, R << 2, mulq_vs<true>(py, L << 2));
+                    } else {
+                        yy = (mulq_vs<FAST>(py, L) >> 2) + (mulq_vs<FAST>(cy, R) >> 2);
+                    }
+                    const int ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq_vs<FAST>(ci, R) >> 14);
+                    const int qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq_vs<FAST>(cq, R) >> 14);
                     int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
                     int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
                     int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
                     r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
-                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = (unsigned) (r << 16 | g << 8 | b);
+                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = (unsigned) (((r << 8 | g) << 8) | b);
                     if ((px & (PX_TILE - 1)) == PX_TILE - 1 || px == outw - 1) {
                         /* drain the pixel tile: pixels [px0, px0+cnt) of every row, + D10 duplicates (:661-664) */
                         const int px0 = px & ~(PX_TILE - 1);
