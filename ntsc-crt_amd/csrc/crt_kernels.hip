@@ -158,6 +158,14 @@ __device__ __forceinline__ int mad24_vs(int v, int s_uniform, int acc)
     return r;
 }
 
+/* the low bytes of four ints -> one dword (3 permutes instead of 4 x (mask, shift, or)) */
+__device__ __forceinline__ unsigned pack4(int v0, int v1, int v2, int v3)
+{
+    const unsigned lo = __builtin_amdgcn_perm((unsigned) v1, (unsigned) v0, 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm((unsigned) v3, (unsigned) v2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 /* noise LCG, crt_core.c:359-364 */
 __device__ __forceinline__ unsigned lcg_step(unsigned rn) { return LCG_MUL * rn + LCG_ADD; }
 __device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)
@@ -253,10 +261,10 @@ k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, s
     }
     if (wmask == 0xffffu) {
         v4i pk;
-        pk.x = (vals[0] & 255) | (vals[1] & 255) << 8 | (vals[2] & 255) << 16 | vals[3] << 24;
-        pk.y = (vals[4] & 255) | (vals[5] & 255) << 8 | (vals[6] & 255) << 16 | vals[7] << 24;
-        pk.z = (vals[8] & 255) | (vals[9] & 255) << 8 | (vals[10] & 255) << 16 | vals[11] << 24;
-        pk.w = (vals[12] & 255) | (vals[13] & 255) << 8 | (vals[14] & 255) << 16 | vals[15] << 24;
+        pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+        pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+        pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+        pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
         store16u(out + idx0, pk);
     } else {
 #pragma unroll
@@ -470,8 +478,9 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
             stash(0);
             if (last_tile > 0) fetch(1);
         }
+        const int noise127 = 0x7f * noise;
         for (int g = 0; g < ngroups; g++) {
-            unsigned pack = 0;
+            int smp[4] = { 0, 0, 0, 0 };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = 4 * g + k;
@@ -505,14 +514,15 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     ire = clampi(ire, 0, 110);
                     if (NOISE) {
                         rn = lcg_step(rn);
-                        ire = clampi(ire + (mulq<FAST>((int) ((rn >> 16) & 0xffu) - 0x7f, noise) >> 8), -127, 127);
+                        /* (byte - 0x7f) * noise, distributed: the byte select rides on the multiply (SDWA) */
+                        ire = clampi(ire + ((mulq<FAST>((int) ((rn >> 16) & 0xffu), noise) - noise127) >> 8), -127, 127);
                     }
-                    pack |= (unsigned) (ire & 255) << (8 * k);
+                    smp[k] = ire;
                     col += qstep; err += rstep;
                     if (err >= destw) { err -= destw; col++; }
                 }
             }
-            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
+            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack4(smp[0], smp[1], smp[2], smp[3]);
             if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
         }
     }
@@ -638,7 +648,7 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     int ph = 4 * ((y + P.yo + st.aux) % 3);                    /* phasetab {0,4,8}; advances by 3 per sample, mod 12 */
     const signed char *tb = (const signed char *) s_tab;
     for (int g = 0; g < ngroups; g++) {
-        unsigned pack = 0;
+        int smp[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = 4 * g + k;
@@ -656,14 +666,14 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
                 int ire = tb[(p & 511) * 12 + ph];
                 if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
                 else if (CLAMP) ire = clampi(ire, -127, 127);
-                pack |= (unsigned) (ire & 255) << (8 * k);
+                smp[k] = ire;
                 ph += 3;
                 if (ph >= 12) ph -= 12;
                 col += qstep; err += rstep;
                 if (err >= destw) { err -= destw; col++; }
             }
         }
-        s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
+        s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack4(smp[0], smp[1], smp[2], smp[3]);
         if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
     }
 }
@@ -762,10 +772,10 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     }
     if (len == 16) {
         v4i pk;
-        pk.x = (vals[0] & 255) | (vals[1] & 255) << 8 | (vals[2] & 255) << 16 | vals[3] << 24;
-        pk.y = (vals[4] & 255) | (vals[5] & 255) << 8 | (vals[6] & 255) << 16 | vals[7] << 24;
-        pk.z = (vals[8] & 255) | (vals[9] & 255) << 8 | (vals[10] & 255) << 16 | vals[11] << 24;
-        pk.w = (vals[12] & 255) | (vals[13] & 255) << 8 | (vals[14] & 255) << 16 | vals[15] << 24;
+        pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+        pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+        pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+        pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
         store16u(out + idx0, pk);
     } else {
 #pragma unroll

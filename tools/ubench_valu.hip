@@ -50,6 +50,19 @@ DEF(and_b32, "v_and_b32 %0, %0, %1")
 DEF(lshlrev, "v_lshlrev_b32 %0, 1, %0")
 DEF(max_i32, "v_max_i32 %0, %0, %1")
 DEF(mul_i24_sdwa, "v_mul_i32_i24_sdwa %0, %1, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0")
+DEF(mul_f32, "v_mul_f32 %0, %0, %1")
+DEF(floor_f32, "v_floor_f32 %0, %0")
+DEF(cvt_f32_ubyte1, "v_cvt_f32_ubyte1 %0, %0")
+DEF(cvt_f32_ubyte2, "v_cvt_f32_ubyte2 %0, %1")
+DEF(cvt_i32_f32, "v_cvt_i32_f32 %0, %0")
+DEF(cvt_f32_i32, "v_cvt_f32_i32 %0, %0")
+DEF(cvt_pk_u8_f32, "v_cvt_pk_u8_f32 %0, %1, 1, %0")
+DEF(med3_f32, "v_med3_f32 %0, %0, %1, %2")
+DEF(max_f32, "v_max_f32 %0, %0, %1")
+DEF(dot4_i32_i8, "v_dot4_i32_i8 %0, %0, %1, %2")
+DEF(fract_f32, "v_fract_f32 %0, %0")
+DEF(sub_f32, "v_sub_f32 %0, %0, %1")
+DEF(xor_b32, "v_xor_b32 %0, %0, %1")
 template <class K> void run(const char *name, K kern, int *d)
 {
     hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
@@ -70,5 +83,7 @@ int main()
     RUN(add_u32); RUN(sub_u32); RUN(ashr); RUN(mad_i24); RUN(mul_i24); RUN(mad_u24); RUN(mul_lo); RUN(add_sdwa); RUN(bfe_i32);
     RUN(perm); RUN(med3); RUN(add3); RUN(lshl_add); RUN(add_lshl); RUN(lshl_or); RUN(fma_f32); RUN(mad_i32_i16);
     RUN(dot2_i32_i16); RUN(pk_add_i16); RUN(mul_hi_i32); RUN(mad_i64_i32); RUN(mov); RUN(cndmask); RUN(and_b32); RUN(lshlrev); RUN(max_i32); RUN(mul_i24_sdwa);
+    RUN(mul_f32); RUN(floor_f32); RUN(cvt_f32_ubyte1); RUN(cvt_f32_ubyte2); RUN(cvt_i32_f32); RUN(cvt_f32_i32); RUN(cvt_pk_u8_f32);
+    RUN(med3_f32); RUN(max_f32); RUN(dot4_i32_i8); RUN(fract_f32); RUN(sub_f32); RUN(xor_b32);
     return 0;
 }
