@@ -723,14 +723,32 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, idx0);
     int vals[16];
     if constexpr (S::IS_NES) {
+        /* crt_nes.c:81-104,173-178: SYNC on [SYNC_BEG, sync_end), the burst of the line's phase row on
+         * [CB_BEG, CB_BEG+40) if the line belongs to the picture, BLANK elsewhere; set up once per line */
+        unsigned sync_len, bpack;
+        bool has_burst;
+        auto setup_line = [&](int n) {
+            sync_len = (unsigned) ((n >= 259 ? S::VS_SEP_END : S::BW_BEG) - S::SYNC_BEG);
+            has_burst = n >= P.yo && n < P.yo + S::LINES;
+            const int row = (n % 3 + st.aux) % 3;
+            bpack = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int cb = row == 0 ? P.burst[0][q] : row == 1 ? P.burst[1][q] : P.burst[2][q];
+                bpack |= (unsigned) (((S::BLANK + cb * S::BURST) >> 5) & 255) << (8 * q);
+            }
+        };
+        setup_line(line);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            int v = 0;
-            if (!skeleton<S>(P, line, t, field, inv_phase, st.aux, true, v)) v = 0;
+            int v = S::BLANK;
+            if ((unsigned) (t - S::SYNC_BEG) < sync_len) v = S::SYNC;
+            if (has_burst && (unsigned) (t - S::CB_BEG) < (unsigned) CB_SAMPLES)
+                v = (int) (signed char) (bpack >> (8 * (t & 3)));
             if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
             else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
             vals[k] = v;
-            if (++t == S::HRES) { t = 0; line++; }
+            if (++t == S::HRES) { t = 0; line++; setup_line(line); }
         }
     } else {
         /* RGB systems (crt_ntsc.c:205-252): a line of the skeleton is SYNC on [a0,a1) and [b0,b1), carries the
@@ -850,7 +868,7 @@ k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ ana
  *   - samples [T0, INPUT_SIZE) have a data-dependent call count: k_vhs_tail, one wave per field,
  *     speculative block walk (see there); it hands back the final history and rn.
  */
-#define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 */
+#define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 (248: measured slower) */
 #define VHS_BLK   43                       /* calls per lane in the tail's window: 64 * 43 >= 3 * HRES + 3 */
 
 /* first sample of the tail: a chunk boundary with at least 16 samples (>= 31 calls) before I0 + 1 */
@@ -882,17 +900,19 @@ __device__ __forceinline__ int dev_cos14(int n)
     return cs;
 }
 
-/* Parallel region.  A wave's 64 chunks are (mostly) one contiguous 7936-byte run of the field: it is moved
- * through an LDS tile of 64 x 31 dwords with coalesced 256-byte requests (lane-per-chunk byte accesses cost
- * 12x the algorithmic HBM write traffic); the lane's own 31 dwords sit at stride 31 = conflict-free. */
+/* Parallel region.  A wave's 64 chunks are (mostly) one contiguous 15872-byte run of the field: it is moved
+ * through an LDS tile of 64 x 62 dwords with coalesced 256-byte requests (lane-per-chunk byte accesses cost
+ * 12x the algorithmic HBM write traffic); the lane's own dwords sit at an odd stride = conflict-free. */
 template <class S>
 __global__ void __launch_bounds__(64)
 k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
             signed char *__restrict__ inp, size_t fstride,
             const unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a)
 {
-    constexpr int DW = VHS_CHUNK / 4;                            /* 31 dwords per chunk */
-    __shared__ unsigned s_t[64 * DW];
+    constexpr int DW = VHS_CHUNK / 4;                            /* dwords per chunk */
+    constexpr int DWS = DW | 1;                                  /* odd LDS stride: conflict-free lane-per-chunk access */
+    static_assert((2 * VHS_CHUNK) % 31 == 0 && VHS_CHUNK % 4 == 0, "static ring index / dword packing");
+    __shared__ unsigned s_t[64 * DWS];
     __shared__ unsigned long long s_off[64];
     const int lane = threadIdx.x;
     const int gid = blockIdx.x * 64 + lane;
@@ -905,7 +925,7 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
     for (int it = 0; it < DW; it++) {
         const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
         const unsigned long long off = s_off[owner];
-        s_t[n] = off != ~0ull ? *(const unsigned *) (analog + off + 4 * d) : 0u;
+        s_t[owner * DWS + d] = off != ~0ull ? *(const unsigned *) (analog + off + 4 * d) : 0u;
     }
     const unsigned *h = hist + (size_t) f * 32;
     /* base sequence z[0..60]: the history and the next 30 values */
@@ -914,7 +934,7 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
     for (int j = 0; j < 31; j++) z[j] = h[j];
 #pragma unroll
     for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
-    /* history of call K = 1 + 248 q */
+    /* history of call K = 1 + 2 * VHS_CHUNK * q */
     const unsigned *c = rows + (size_t) q * 31;
     unsigned w[31];
 #pragma unroll
@@ -927,8 +947,8 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
     }
     const int noise = P.noise;
     __syncthreads();
-    /* 248 calls = 124 samples; ring index = call % 31 is static */
-    unsigned *mine = s_t + lane * DW;
+    /* 2 calls per sample; ring index = call % 31 is static */
+    unsigned *mine = s_t + lane * DWS;
     unsigned in4 = 0, out4 = 0;
 #pragma unroll
     for (int t = 0; t < 2 * VHS_CHUNK; t++) {
@@ -949,7 +969,7 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
     for (int it = 0; it < DW; it++) {
         const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
         const unsigned long long off = s_off[owner];
-        if (off != ~0ull) *(unsigned *) (inp + off + 4 * d) = s_t[n];
+        if (off != ~0ull) *(unsigned *) (inp + off + 4 * d) = s_t[owner * DWS + d];
     }
 }
 
@@ -1571,7 +1591,7 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
 /* TIER: 0 = 64-bit-mad stages without the I/Q low cascades, 1 = 64-bit-mad stages, 2 = 24-bit mads,
- * 3 = exact 32-bit multiplies; a line is decoded by the kernel
+ * 3 = exact 32-bit multiplies; a wave of 64 lines is decoded by the kernel
  * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
  * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
 template <class S, int TIER, bool BPP3, int PXT>
@@ -1595,11 +1615,16 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
     const int f = live ? gid / S::LINES : 0;
     if (live) lp = lines[gid];
-    int tier = (lp.nrows & CRTHIP_LINE_EXACT) ? 3 : (lp.nrows & CRTHIP_LINE_NOT64) ? 2 : (lp.nrows & CRTHIP_LINE_WIDE) ? 1 : 0;
-    if (tier < min_tier) tier = min_tier;          /* batch-wide floor from the host (brightness, contrast) */
+    /* the WAVE's tier = the highest one any of its lines needs (a higher tier decodes lower-tier lines just
+     * as exactly), at least the batch-wide floor from the host (brightness, contrast): a wave with mixed lines
+     * runs once, not once per tier */
+    int tier = __ballot(lp.nrows & CRTHIP_LINE_EXACT) ? 3 : __ballot(lp.nrows & CRTHIP_LINE_NOT64) ? 2
+             : __ballot(lp.nrows & CRTHIP_LINE_WIDE) ? 1 : 0;
+    if (tier < min_tier) tier = min_tier;
+    if (tier != TIER) return;
     int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
     const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
-    if (!live || tier != TIER || rank != want_rank) nrows = 0;
+    if (!live || rank != want_rank) nrows = 0;
     if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
     const bool act = nrows > 0;
     constexpr int bpp = BPP3 ? 3 : 4;
