@@ -203,11 +203,12 @@ def main():
             except Exception:
                 traffic = None
         # cycle-weighted VALU bound of the dominant kernel at 640x480 (the bound that actually binds there):
-        # ISA-inspected inner loops, 94 VALU ~ 264 cycles per sample and 50 VALU ~ 120 cycles per pixel with
-        # the measured issue costs (profiles/r01_valu_issue_rates.txt), 3.75 waves per field, 1024 SIMDs
+        # ISA-inspected inner loops of decoder tier 0, ~60 VALU ~ 170 cycles per sample (16 filter stages) and
+        # ~46 VALU ~ 130 cycles per pixel with the measured issue costs (profiles/r01_valu_issue_rates.txt),
+        # 3.75 waves per field, 1024 SIMDs
         valu = None
         if dom == "decode" and (args.system, w, h, outw, outh) == ("ntsc", 640, 480, 640, 480):
-            cycles_per_field = 3.75 * (756 * 264 + 640 * 120)
+            cycles_per_field = 3.75 * (756 * 170 + 640 * 130)
             clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_final_sq_counters.json
             need_ms = cycles_per_field * n / 1024.0 / clk * 1e3
             valu = {"bound": "int-valu (cycle-weighted)", "simd_cycles_per_field": cycles_per_field, "clock_hz": clk,
