@@ -678,18 +678,54 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     }
 }
 
+/* The clean skeleton (blanking / sync / burst, 0 where crt_modulate writes nothing) of a whole field depends
+ * only on a handful of per-field inputs: RGB systems (field, frame parity) -> 4 variants; NES the dot crawl
+ * offset mod 3 -> 3 variants.  k_skeleton writes the variants once per launch (a few fields' worth of work),
+ * k_margin then only copies 16 bytes and adds the channel noise. */
+#define SKEL_VARIANTS 4
+template <class S>
+__global__ void __launch_bounds__(256)
+k_skeleton(const crthip_params P, signed char *__restrict__ skel, size_t fstride)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= SKEL_VARIANTS * CHUNKS) return;
+    const int var = gid / CHUNKS;
+    const int idx0 = (gid - var * CHUNKS) * 16;
+    const int field = S::IS_NES ? 0 : var >> 1;
+    const int inv_phase = S::IS_NES ? 0 : (field == (var & 1));
+    const int aux = S::IS_NES ? var : 0;                       /* VHS: the aberration band is patched in by k_margin */
+    int line = idx0 / S::HRES;
+    int t = idx0 - line * S::HRES;
+    int vals[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int v = 0;
+        if (!skeleton<S>(P, line, t, field, inv_phase, aux, true, v)) v = 0;
+        vals[k] = v;
+        if (++t == S::HRES) { t = 0; line++; }
+    }
+    v4i pk;
+    pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+    pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+    pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+    pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
+    store16u(skel + (size_t) var * fstride + idx0, pk);        /* the last chunk runs into the field's slack */
+}
+
 /* Fused path only: everything OUTSIDE the active rectangle of a field that started from a clean
  * analog[] -- skeleton value (or 0) plus channel noise, written straight into inp[].  The complement
  * of the rectangle in flat sample order is
  *     head   [0, S0)                                   S0 = yo*HRES + xo
  *     gap y  [S0 + y*HRES + destw, S0 + (y+1)*HRES)    y = 0 .. desth-2
  *     tail   [S0 + (desth-1)*HRES + destw, INPUT_SIZE)
- * and each lane takes one run of up to 16 samples of it. */
+ * and each lane takes one run of up to 16 samples of it: 16 bytes of the cached skeleton variant
+ * (k_skeleton), + noise (LCG state by the 16-step jump table and a 16-entry table for the remainder). */
 template <class S, bool NOISE>
 __global__ void __launch_bounds__(256)
 k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
-         const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16,
-         int head_chunks, int gap_chunks, int tail_chunks)
+         const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1,
+         const signed char *__restrict__ skel, int head_chunks, int gap_chunks, int tail_chunks)
 {
     const int per_field = head_chunks + (P.desth - 1) * gap_chunks + tail_chunks;
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -713,92 +749,53 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
         len = S::INPUT_SIZE - idx0;
     }
     if (len > 16) len = 16;
-    const crthip_state st = state[f];
-    const int field = st.field & 1;
-    const int inv_phase = (field == (st.frame & 1));
-    int line = idx0 / S::HRES;
-    int t = idx0 - line * S::HRES;
+    const crthip_state *st = state + f;
+    const int aux = st->aux;
+    const int var = S::IS_NES ? aux % 3 : ((st->field & 1) << 1) | (st->frame & 1);
     signed char *out = dst + (size_t) f * fstride;
-    unsigned rn = 0;
-    if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, idx0);
-    int vals[16];
-    if constexpr (S::IS_NES) {
-        /* crt_nes.c:81-104,173-178: SYNC on [SYNC_BEG, sync_end), the burst of the line's phase row on
-         * [CB_BEG, CB_BEG+40) if the line belongs to the picture, BLANK elsewhere; set up once per line */
-        unsigned sync_len, bpack;
-        bool has_burst;
-        auto setup_line = [&](int n) {
-            sync_len = (unsigned) ((n >= 259 ? S::VS_SEP_END : S::BW_BEG) - S::SYNC_BEG);
-            has_burst = n >= P.yo && n < P.yo + S::LINES;
-            const int row = (n % 3 + st.aux) % 3;
-            bpack = 0;
+    const v4i sk = load16u(skel + (size_t) var * fstride + idx0);
+    int wds[4] = { sk.x, sk.y, sk.z, sk.w };
+    if constexpr (S::IS_VHS) {
+        /* no sync pulse inside the aberration band (crt_ntscvhs.c:234-238): lines n >= VRES - aux */
+        const int line0 = idx0 / S::HRES, t0 = idx0 - line0 * S::HRES;
+        if (aux > 0 && line0 + 1 >= S::VRES - aux) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int cb = row == 0 ? P.burst[0][q] : row == 1 ? P.burst[1][q] : P.burst[2][q];
-                bpack |= (unsigned) (((S::BLANK + cb * S::BURST) >> 5) & 255) << (8 * q);
+            for (int k = 0; k < 16; k++) {
+                int t = t0 + k, n = line0;
+                if (t >= S::HRES) { t -= S::HRES; n++; }
+                if (n >= S::VRES - aux && n >= 10 && t >= S::SYNC_BEG && t < S::BW_BEG)
+                    wds[k >> 2] = (wds[k >> 2] & ~(0xff << (8 * (k & 3)))) | ((S::BLANK & 0xff) << (8 * (k & 3)));
             }
-        };
-        setup_line(line);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int v = S::BLANK;
-            if ((unsigned) (t - S::SYNC_BEG) < sync_len) v = S::SYNC;
-            if (has_burst && (unsigned) (t - S::CB_BEG) < (unsigned) CB_SAMPLES)
-                v = (int) (signed char) (bpack >> (8 * (t & 3)));
-            if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
-            else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
-            vals[k] = v;
-            if (++t == S::HRES) { t = 0; line++; setup_line(line); }
-        }
-    } else {
-        /* RGB systems (crt_ntsc.c:205-252): a line of the skeleton is SYNC on [a0,a1) and [b0,b1), carries the
-         * burst on [CB_BEG, CB_BEG+40) if it is an ordinary line, BLANK elsewhere (a clean field has 0 in the
-         * never-written active part).  The ranges are set up per line, each sample costs a few range tests. */
-        unsigned bpack = 0;                                    /* the 4 burst bytes by (t & 3) */
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int cb = S::PATTERN == 1 ? P.burst[0][(q + inv_phase * 2) & 3] : P.burst[0][q];
-            bpack |= (unsigned) (((S::BLANK + cb * S::BURST) >> 5) & 255) << (8 * q);
-        }
-        unsigned a0, alen, b0, blen;
-        bool ordinary;
-        auto setup_line = [&](int n) {
-            if (n <= 3 || (n >= 7 && n <= 9)) {                /* equalising pulses */
-                a0 = 0; alen = 4 * S::HRES / 100; b0 = 50 * S::HRES / 100; blen = 54 * S::HRES / 100 - 50 * S::HRES / 100;
-                ordinary = false;
-            } else if (n >= 4 && n <= 6) {                     /* vertical sync */
-                a0 = 0; alen = (field == 1 ? 4 : 46) * S::HRES / 100;
-                b0 = 50 * S::HRES / 100; blen = 96 * S::HRES / 100 - 50 * S::HRES / 100;
-                ordinary = false;
-            } else {                                           /* ordinary line; no sync pulse inside the VHS aberration band */
-                a0 = S::SYNC_BEG; alen = n < S::VRES - st.aux ? S::BW_BEG - S::SYNC_BEG : 0; b0 = 0; blen = 0;
-                ordinary = true;
-            }
-        };
-        setup_line(line);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int v = S::BLANK;
-            if ((unsigned) t - a0 < alen || (unsigned) t - b0 < blen) v = S::SYNC;
-            if (ordinary && (unsigned) (t - S::CB_BEG) < (unsigned) CB_SAMPLES)
-                v = (int) (signed char) (bpack >> (8 * (t & 3)));
-            if (NOISE) { rn = lcg_step(rn); v = noisy(v, rn, P.noise); }
-            else v = clampi(v, -127, 127);                    /* noise 0: crt_core.c:362-364 still clamps */
-            vals[k] = v;
-            if (++t == S::HRES) { t = 0; line++; setup_line(line); }
         }
     }
-    if (len == 16) {
-        v4i pk;
+    v4i pk;
+    if (NOISE) {
+        unsigned rn;
+        {
+            const uint2 j = jump16[idx0 >> 4], r = jump1[idx0 & 15];
+            rn = r.x * (j.x * (unsigned) st->rn + j.y) + r.y;
+        }
+        int vals[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            rn = lcg_step(rn);
+            vals[k] = noisy((wds[k >> 2] << (24 - 8 * (k & 3))) >> 24, rn, P.noise);
+        }
         pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
         pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
         pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
         pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
+    } else {
+        /* noise 0: crt_core.c:362-364 still clamps to +-127, which no skeleton value exceeds */
+        pk.x = wds[0]; pk.y = wds[1]; pk.z = wds[2]; pk.w = wds[3];
+    }
+    if (len == 16) {
         store16u(out + idx0, pk);
     } else {
+        const int o4[4] = { pk.x, pk.y, pk.z, pk.w };
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            if (k < len) out[idx0 + k] = (signed char) vals[k];
+            if (k < len) out[idx0 + k] = (signed char) (o4[k >> 2] >> (8 * (k & 3)));
         }
     }
     if (gid - f * per_field == 0) {
@@ -1920,6 +1917,8 @@ struct crthip_ctx {
     bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tiers */
     bool no_loskip;             /* debug/test: never drop the I/Q low cascades */
     signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table, rebuilt per encoder launch */
+    signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields, rebuilt per fused encoder launch */
+    uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
@@ -2053,12 +2052,14 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
         const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
         const int tail = (tail_len + 15) / 16;
         const int total = n * (head + (p->desth - 1) * gap + tail);
+        constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
+        hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
         if (p->noise != 0)
             hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                               *p, n, dst, c->fstride, d_state, c->d_jump16, head, gap, tail);
+                               *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
         else
             hipLaunchKernelGGL((k_margin<S, false>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                               *p, n, dst, c->fstride, d_state, c->d_jump16, head, gap, tail);
+                               *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
     } else {
         constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
         ProfScope ps(c, CRTHIP_K_TEMPLATE);
@@ -2162,6 +2163,17 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         crthip_destroy(c);
         return CRTHIP_E_NOMEM;
     }
+    {
+        uint2 j1[16];
+        j1[0] = make_uint2(1u, 0u);
+        for (int k = 1; k < 16; k++) j1[k] = make_uint2(LCG_MUL * j1[k - 1].x, LCG_MUL * j1[k - 1].y + LCG_ADD);
+        if (hipMalloc((void **) &c->d_skel, (size_t) SKEL_VARIANTS * c->fstride) != hipSuccess ||
+            hipMalloc((void **) &c->d_jump1, sizeof(j1)) != hipSuccess ||
+            hipMemcpy(c->d_jump1, j1, sizeof(j1), hipMemcpyHostToDevice) != hipSuccess) {
+            crthip_destroy(c);
+            return CRTHIP_E_NOMEM;
+        }
+    }
     if (system == CRTHIP_SYSTEM_NTSCVHS) {
         /* jump coefficients of the rand() recurrence: one row per parallel chunk, one for the first call of
          * the tail, and the tail's 64 block offsets (transposed: [m][block]) */
@@ -2204,6 +2216,8 @@ void crthip_destroy(crthip_ctx *c)
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
     if (c->d_seq) hipFree(c->d_seq);
     if (c->d_nes_tab) hipFree(c->d_nes_tab);
+    if (c->d_skel) hipFree(c->d_skel);
+    if (c->d_jump1) hipFree(c->d_jump1);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
