@@ -311,6 +311,52 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
     g.close()
 
 
+@pytest.mark.parametrize("noise", [7, 100])
+def test_vhs_rand_noise_many_seeds(crtlib, noise):
+    """The data-dependent part of the VHS rand() walk (last 25 lines: 2 or 3 calls per sample) under many
+    generator seeds, two crt_demodulate calls in a row so that the second one
+    starts from the history the first one hands back.  Checked: inp[], rn, hsync/vsync and the picture."""
+    import ctypes as C
+    import torch
+    libc = C.CDLL(None)
+    n, w, h = 40, 96, 240
+    seeds = [1 + 7919 * k for k in range(n)]
+    orc = R.Oracle("vhs")
+    # a properly encoded field (the decoder must find its sync pulses, or it reads past inp[] like the reference
+    # would), the same for every seed
+    img = R.synth_image(w, h, 4, 4242)
+    c0 = orc.new_crt(w, h, R.FMT_BGRA)
+    c0.settings(np.concatenate([img, img[-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1, field=0, frame=0, do_aberration=0)
+    c0.modulate()
+    analog = np.repeat(c0.analog.copy()[None, :], n, axis=0)
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "vhs", device=0)
+    g.srand(seeds)
+    g.analog[:, :orc.input_size].copy_(torch.from_numpy(analog).to(g.dev))
+    want = []
+    for k in range(n):
+        c = orc.new_crt(w, h, R.FMT_BGRA)
+        c.analog[:] = analog[k]
+        libc.srand(seeds[k])
+        per = []
+        for step in range(2):
+            c.demodulate(noise)
+            per.append((c.inp.copy(), c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn")))
+        want.append(per)
+    for step in range(2):
+        g.demodulate(noise)
+        g.synchronize()
+        ginp = g.inp[:, :orc.input_size].cpu().numpy()
+        gout = g.out.cpu().numpy()
+        for k in range(n):
+            inp, out, hs, vs, rn = want[k][step]
+            what = "seed %d noise %d call %d" % (seeds[k], noise, step)
+            bad = np.nonzero(ginp[k] != inp)[0]
+            assert bad.size == 0, "%s: inp differs first at sample %d (of %d)" % (what, bad[0], orc.input_size)
+            assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), what
+            np.testing.assert_array_equal(gout[k].reshape(-1), out, err_msg=what)
+    g.close()
+
+
 @pytest.mark.parametrize("name,noise,scanlines,outsz", [("ntsc", 24, 1, (640, 480)), ("ntsc", 0, 0, (832, 624)),
                                                          ("ntsc", 120, 1, (320, 240)), ("nes", 12, 1, (640, 480))])
 def test_sequence_mode_equals_sequential_processing(crtlib, name, noise, scanlines, outsz):
