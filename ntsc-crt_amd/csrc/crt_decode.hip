@@ -1,0 +1,396 @@
+/* crt_decode.hip -- D8-D10: equalisers, resampling, YIQ->RGB, row duplication.  See crt_dev.h. */
+#include "crt_dev.h"
+
+/* ------------------------------------------------------------------------- */
+/* D8-D10: equalisers + resample + YIQ->RGB, one lane per CRT line              */
+/* ------------------------------------------------------------------------- */
+/*
+ * Multiplies.  The reference multiplies 32x32->32 with wrap-around.  gfx950's
+ * v_mul_lo_u32 does exactly that but runs at quarter rate; v_mul_i32_i24 /
+ * v_mad_i32_i24 run at full rate and return the low 32 bits of the 48-bit product
+ * of the operands' low 24 bits (sign-extended) -- identical to the wrapped 32-bit
+ * product WHENEVER both operands are within [-2^23, 2^23).  FAST=true uses them and
+ * is only dispatched when that range is proven (see fast_path_ok() below and
+ * DESIGN.md "24-bit multiply envelope"); lines outside the envelope are flagged by
+ * k_sync (CRTHIP_LINE_EXACT) and re-run by the FAST=false instantiation.
+ */
+
+struct Eq3 { int lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3, h0, h1, h2; };
+
+/* eqf, crt_core.c:206-233.  Band gains are the compile-time constants of crt_core.c:278-280
+ * (G0 is always 65536: (x * 65536) >> 16 wraps to the sign-extended low half of x). */
+template <bool FAST, int G1, int G2>
+__device__ __forceinline__ int eq_step(Eq3 &f, const int lf, const int hf, const int s)
+{
+    f.lo0 += (mulq<FAST>(lf, s - f.lo0) + 32768) >> 16;
+    f.hi0 += (mulq<FAST>(hf, s - f.hi0) + 32768) >> 16;
+    f.lo1 += (mulq<FAST>(lf, f.lo0 - f.lo1) + 32768) >> 16;
+    f.hi1 += (mulq<FAST>(hf, f.hi0 - f.hi1) + 32768) >> 16;
+    f.lo2 += (mulq<FAST>(lf, f.lo1 - f.lo2) + 32768) >> 16;
+    f.hi2 += (mulq<FAST>(hf, f.hi1 - f.hi2) + 32768) >> 16;
+    f.lo3 += (mulq<FAST>(lf, f.lo2 - f.lo3) + 32768) >> 16;
+    f.hi3 += (mulq<FAST>(hf, f.hi2 - f.hi3) + 32768) >> 16;
+    int r = (f.lo3 * 65536) >> 16;
+    if (G1 == 65536 || G1 == 8192) r += ((f.hi3 - f.lo3) * G1) >> 16;      /* shifts / bit-field extract */
+    else r += mulq<FAST>(f.hi3 - f.lo3, G1) >> 16;
+    if (G2 != 0) {
+        r += mulq<FAST>(f.h2 - f.hi3, G2) >> 16;
+        f.h2 = f.h1; f.h1 = f.h0; f.h0 = s;
+    }
+    return r;
+}
+
+/*
+ * Tier 0 of the decoder: one v_mad_i64_i32 per filter stage.
+ *   x' = x + ((c*(u-x) + 2^15) >> 16)  ==  hi32( (c<<16)*(u-x) + {lo: 2^31, hi: x} )          c < 2^15
+ *   and, because x + (u-x) = u,        ==  hi32( ((c-2^16)<<16)*(u-x) + {lo: 2^31, hi: u} )   2^15 <= c < 1.5*2^16
+ * -- multiply, rounding, shift and accumulate in ONE 4-cycle instruction (measured: v_mad_i64_i32 issues
+ * like v_mad_i32_i24, profiles/r01_valu_issue_rates.txt), i.e. v_sub + v_mov(lo = 2^31) + v_mad_i64_i32
+ * = 8 cycles per stage instead of 10.  Every state lives in the HIGH half of a register pair whose low
+ * half is re-armed with 2^31 after each update, so a pair can serve as addend of its own stage (small c)
+ * or of the next stage (c near 2^16).  The 64-bit product is exact, whereas the reference's 32-bit one
+ * wraps: equal only while |c*(u-x)| + 2^15 < 2^31, which is what the tier-0 envelope guarantees
+ * (DESIGN.md): luma |s+bright| <= 2727, chroma |wave| <= 120000.  Luma coefficients are near 2^16,
+ * chroma ones below 2^15 for every system of this build (checked on the host).
+ */
+#define KROUND64 0x80000000ul
+__device__ __forceinline__ int hi32(long v) { return (int) (v >> 32); }
+__device__ __forceinline__ long pair_of(int v) { return (long) (((unsigned long) (unsigned) v << 32) | KROUND64); }
+__device__ __forceinline__ long rearm(long v) { return (long) (((unsigned long) v & 0xffffffff00000000ul) | KROUND64); }
+__device__ __forceinline__ long mad64(int d, int cc, long acc)
+{
+    long r, carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(d), "s"(cc), "v"(acc));
+    return r;
+}
+struct Eq64 { long lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3; int h0, h1, h2; };
+__device__ __forceinline__ void eq64_reset(Eq64 &f)
+{
+    f.lo0 = f.lo1 = f.lo2 = f.lo3 = f.hi0 = f.hi1 = f.hi2 = f.hi3 = (long) KROUND64;
+    f.h0 = f.h1 = f.h2 = 0;
+}
+/* lfm / hfm: pre-shifted multipliers (see above); NEAR1: coefficients are >= 2^15.
+ * The band gains (crt_core.c:203-206) are applied as (r * g) >> 16 per band IN 32-BIT WRAPPING ARITHMETIC, i.e.
+ * a gain of 65536 is "sign-extend the low 16 bits".  Inside the envelopes that is the identity:
+ *   luma   |lo3|, |hi3| <= 2727                     -> low band = lo3, mid band (gain 8192) = (hi3 - lo3) >> 3
+ *   chroma gains (65536, 65536, g2): low + mid = lo3 + (hi3 - lo3) = hi3 whenever |lo3|, |hi3 - lo3| < 2^15.
+ *          LOSKIP (tier 0, |wave| <= LOSKIP_WAVE_MAX): every stage output stays inside the hull of its inputs
+ *          (0 < c < 2^16, round-to-nearest never overshoots), the input is |s * wave >> 9| <= 16383, hence
+ *          |lo3| <= 16383 and |hi3 - lo3| <= 32766: the four low stages feed nothing and are not computed. */
+template <bool NEAR1, int G1, int G2, bool LOSKIP>
+__device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, const long sp)
+{
+#define EQ64_STAGE(X, UPAIR, M) X = rearm(mad64(hi32(UPAIR) - hi32(X), M, NEAR1 ? UPAIR : X))
+    static_assert(!LOSKIP || G1 == 65536, "dropping the low cascade needs low gain == mid gain == 65536");
+    if (!LOSKIP) {
+        EQ64_STAGE(f.lo0, sp, lfm);
+        EQ64_STAGE(f.lo1, f.lo0, lfm);
+        EQ64_STAGE(f.lo2, f.lo1, lfm);
+        EQ64_STAGE(f.lo3, f.lo2, lfm);
+    }
+    EQ64_STAGE(f.hi0, sp, hfm);
+    EQ64_STAGE(f.hi1, f.hi0, hfm);
+    EQ64_STAGE(f.hi2, f.hi1, hfm);
+    EQ64_STAGE(f.hi3, f.hi2, hfm);
+#undef EQ64_STAGE
+    const int lo3 = hi32(f.lo3), hi3 = hi32(f.hi3);
+    int r;
+    if (LOSKIP) r = hi3;
+    else if (NEAR1 && G1 == 8192) r = lo3 + ((hi3 - lo3) >> 3);        /* luma envelope, see above */
+    else {
+        r = (lo3 * 65536) >> 16;
+        if (G1 == 65536 || G1 == 8192) r += ((hi3 - lo3) * G1) >> 16;
+        else r += __mul24(hi3 - lo3, G1) >> 16;
+    }
+    if (G2 != 0) {
+        r += __mul24(f.h2 - hi3, G2) >> 16;
+        f.h2 = f.h1; f.h1 = f.h0; f.h0 = hi32(sp);
+    }
+    return r;
+}
+
+/* byte selectors for v_perm_b32: 0xffRRGGBB (bytes B,G,R,ff) <-> the four 4-byte output formats,
+ * crt_core.c:587-656 */
+__device__ __forceinline__ unsigned pack_selector(int format)
+{
+    return format == CRTHIP_FMT_BGRA ? 0x03020100u : format == CRTHIP_FMT_RGBA ? 0x03000102u
+         : format == CRTHIP_FMT_ARGB ? 0x00010203u : 0x02010003u /* ABGR */;
+}
+__device__ __forceinline__ unsigned unpack_selector(int format)
+{
+    return format == CRTHIP_FMT_BGRA ? 0x03020100u : format == CRTHIP_FMT_RGBA ? 0x03000102u
+         : format == CRTHIP_FMT_ARGB ? 0x00010203u : 0x00030201u /* ABGR */;
+}
+
+/*
+ * Global memory traffic of the lane-per-line kernels.  A lane walks along its own scanline, so a
+ * wave's 64 lanes touch 64 different rows: per-lane loads/stores would move 16 bytes out of every
+ * 128-byte line at a time (measured: 3-8x the algorithmic HBM traffic, profiles/r01_v1_*).  Instead
+ * all global I/O goes through LDS tiles [64 rows][TILE] that the wave fills / drains COOPERATIVELY
+ * with row-contiguous 16-byte pieces (8 lanes x 16 B = one 128-byte line of one row per 8 lanes),
+ * while each lane reads / writes only its own row of the tile.  Row stride = TILE+1 dwords, all LDS
+ * accesses are 32-bit: bank = (row + column) % 32, conflict-free for both access directions.
+ * Workgroup = one wave, so __syncthreads() is only an ordering fence between the two phases.
+ */
+#define IN_TILE_DW   16                    /* decoder input tile: 64 samples per row            */
+#define IN_STRIDE    (IN_TILE_DW + 1)
+/* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
+ * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
+ * pictures that lean on HBM write bandwidth) */
+/* TIER: 0 = 64-bit-mad stages without the I/Q low cascades, 1 = 64-bit-mad stages, 2 = 24-bit mads,
+ * 3 = exact 32-bit multiplies; a wave of 64 lines is decoded by the kernel
+ * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
+ * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
+template <class S, int TIER, bool BPP3, int PXT>
+__global__ void __launch_bounds__(64)
+k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+         const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
+         int want_rank)
+{
+    constexpr bool FAST = TIER <= 2;        /* tiers 0-2 use 24-bit multiplies outside the filter stages */
+    constexpr bool LOSKIP = TIER == 0;
+    __shared__ unsigned s_in[64 * IN_STRIDE];
+    constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
+    __shared__ unsigned s_px[64 * PX_STRIDE];
+    __shared__ unsigned long long s_src[64], s_dst[64];
+    __shared__ int s_nrows[64];
+
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
+    const bool live = gid < n_fields * S::LINES;
+    crthip_line lp;
+    lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0;
+    const int f = live ? gid / S::LINES : 0;
+    if (live) lp = lines[gid];
+    /* the WAVE's tier = the highest one any of its lines needs (a higher tier decodes lower-tier lines just
+     * as exactly), at least the batch-wide floor from the host (brightness, contrast): a wave with mixed lines
+     * runs once, not once per tier */
+    int tier = __ballot(lp.nrows & CRTHIP_LINE_EXACT) ? 3 : __ballot(lp.nrows & CRTHIP_LINE_NOT64) ? 2
+             : __ballot(lp.nrows & CRTHIP_LINE_WIDE) ? 1 : 0;
+    if (tier < min_tier) tier = min_tier;
+    if (tier != TIER) return;
+    int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
+    if (!live || rank != want_rank) nrows = 0;
+    if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
+    const bool act = nrows > 0;
+    constexpr int bpp = BPP3 ? 3 : 4;
+    const size_t pitch = (size_t) P.outw * bpp;
+    s_src[lane] = (unsigned long long) (inp + (size_t) f * fstride + (act ? lp.pos : 0));
+    s_dst[lane] = (unsigned long long) (outp + (size_t) f * ostride + (size_t) (act ? lp.beg : 0) * pitch);
+    s_nrows[lane] = nrows;
+    __syncthreads();
+
+    const int w0 = lp.wave0, w1 = lp.wave1, nw0 = -lp.wave0, nw1 = -lp.wave1;
+    const int bright = P.bright, contrast = P.contrast;
+    const int ylf = P.eq_lf[0], yhf = P.eq_hf[0], ilf = P.eq_lf[1], ihf = P.eq_hf[1], qlf = P.eq_lf[2], qhf = P.eq_hf[2];
+    const unsigned psel = pack_selector(P.out_format), usel = unpack_selector(P.out_format);
+    const bool rgb_order = P.out_format == CRTHIP_FMT_RGB;
+    const bool blend = P.blend != 0;
+    Eq3 ey = {}, ei = {}, eq = {};
+    Eq64 wy, wi_, wq_;                             /* tier 0 state (register pairs) */
+    eq64_reset(wy); eq64_reset(wi_); eq64_reset(wq_);
+    /* tier 0 multipliers: luma coefficients are 2^16 + c', chroma ones < 2^15 (host-checked) */
+    const int ylfm = (ylf - 65536) << 16, yhfm = (yhf - 65536) << 16;
+    const int ilfm = ilf << 16, ihfm = ihf << 16, qlfm = qlf << 16, qhfm = qhf << 16;
+    int py = 0, pi = 0, pq = 0;                    /* yiq of the previous sample */
+
+    /* wave-uniform output pixel schedule, crt_core.c:528-531,555-562 */
+    const unsigned scan_r = (unsigned) (S::AV_LEN - 1) << 12;
+    const unsigned dx = (unsigned) P.dx;
+    unsigned ppos = 0;
+    int px = 0;
+    const int outw = P.outw;
+
+    /* cooperative input tile: piece = 16 bytes, 4 pieces per row, 16 rows per load instruction */
+    const int in_row = lane >> 2, in_piece = lane & 3;
+    v4i stage[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        stage[i] = gload16u(s_src[i * 16 + in_row] + in_piece * 16);
+    }
+    constexpr int NQ = (S::AV_LEN + 3) / 4;        /* dwords per line window; the last one may run past
+                                                      AV_LEN: the filters are causal, the extra samples feed nothing */
+    constexpr int NT = (NQ + IN_TILE_DW - 1) / IN_TILE_DW;
+    for (int t = 0; t < NT; t++) {
+        /* stash tile t (already in registers), then start fetching tile t+1 */
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned *d = s_in + (i * 16 + in_row) * IN_STRIDE + in_piece * 4;
+            d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
+        }
+        __syncthreads();
+        if (t + 1 < NT) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                stage[i] = gload16u(s_src[i * 16 + in_row] + (t + 1) * (IN_TILE_DW * 4) + in_piece * 16);
+            }
+        }
+        const int xq_end = (t + 1) * IN_TILE_DW < NQ ? (t + 1) * IN_TILE_DW : NQ;
+        for (int xq = t * IN_TILE_DW; xq < xq_end; xq++) {
+            const int word = (int) s_in[lane * IN_STRIDE + (xq - t * IN_TILE_DW)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = xq * 4 + k;
+                const int s = (word << (24 - 8 * k)) >> 24;
+                /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
+                const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
+                const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
+                int cy, ci, cq;
+                if (TIER <= 1) {
+                    /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
+                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
+                    ci = eq_step64<false, 65536, 1311, LOSKIP>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
+                    cq = eq_step64<false, 65536, 0, LOSKIP>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
+                } else {
+                    cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
+                    ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
+                    cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
+                }
+                /* D9: every output pixel whose left tap is sample x-1 is now computable */
+                while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
+                    const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
+                    int yy;
+                    if (TIER <= 1) {
+                        /* crt_core.c:556: (py * L >> 2) + (cy * R >> 2) with py, cy = luma << 4.  |luma| <= 4173
+                         * inside the tier's envelope, so no product wraps and both shifts are exact */
+                        yy = mad24_vs(cy, R << 2, mulq_vs<true>(py, L << 2));
+                    } else {
+                        yy = (mulq_vs<FAST>(py, L) >> 2) + (mulq_vs<FAST>(cy, R) >> 2);
+                    }
+                    const int ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq_vs<FAST>(ci, R) >> 14);
+                    const int qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq_vs<FAST>(cq, R) >> 14);
+                    int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
+                    int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
+                    int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
+                    r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
+                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = (unsigned) (((r << 8 | g) << 8) | b);
+                    if ((px & (PX_TILE - 1)) == PX_TILE - 1 || px == outw - 1) {
+                        /* drain the pixel tile: pixels [px0, px0+cnt) of every row, + D10 duplicates (:661-664) */
+                        const int px0 = px & ~(PX_TILE - 1);
+                        const int cnt = px - px0 + 1;
+                        __syncthreads();
+                        if (!BPP3) {
+                            const int orow_ = lane / PX_PIECES, piece = lane % PX_PIECES;  /* 4 pixels = 16 bytes per piece */
+                            const int have = cnt - piece * 4;                      /* pixels of this piece that exist */
+#pragma unroll 2
+                            for (int i = 0; i < PX_PIECES; i++) {
+                                const int rr_ = i * (64 / PX_PIECES) + orow_;
+                                const int nr = s_nrows[rr_];
+                                if (nr > 0 && have > 0) {
+                                    const unsigned long long d = s_dst[rr_] + (size_t) (px0 + piece * 4) * 4;
+                                    const unsigned *sp = s_px + rr_ * PX_STRIDE + piece * 4;
+                                    unsigned v[4] = { sp[0], sp[1], sp[2], sp[3] };
+                                    if (blend) {
+#pragma unroll
+                                        for (int c = 0; c < 4; c++) {
+                                            if (c < have) {
+                                                const unsigned oldw = gload32(d + 4 * c);
+                                                const unsigned old = __builtin_amdgcn_perm(oldw, oldw, usel);
+                                                v[c] = ((v[c] & 0xfefeffu) >> 1) + ((old & 0xfefeffu) >> 1);
+                                            }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int c = 0; c < 4; c++) {
+                                        const unsigned full = 0xff000000u | v[c];
+                                        v[c] = __builtin_amdgcn_perm(full, full, psel);
+                                    }
+                                    for (int dup = 0; dup < nr; dup++) {
+                                        const unsigned long long dd = d + (size_t) dup * pitch;
+                                        if (have >= 4) {
+                                            v4i o; o.x = (int) v[0]; o.y = (int) v[1]; o.z = (int) v[2]; o.w = (int) v[3];
+                                            gstore16u(dd, o);
+                                        } else {
+                                            gstore32(dd, v[0]);
+                                            if (have > 1) gstore32(dd + 4, v[1]);
+                                            if (have > 2) gstore32(dd + 8, v[2]);
+                                        }
+                                    }
+                                }
+                            }
+                        } else {
+                            /* 3-byte formats: one pixel per lane, PX_TILE pixels of 64/PX_TILE rows per pass */
+                            const int half = lane / PX_TILE, c = lane % PX_TILE;
+                            for (int i = 0; i < PX_TILE; i++) {
+                                const int rr_ = i * (64 / PX_TILE) + half;
+                                const int nr = s_nrows[rr_];
+                                if (nr > 0 && c < cnt) {
+                                    const unsigned long long d = s_dst[rr_] + (size_t) (px0 + c) * 3;
+                                    int rgb = (int) s_px[rr_ * PX_STRIDE + c];
+                                    if (blend) {
+                                        const int o0 = (int) gload8(d), o1 = (int) gload8(d + 1), o2 = (int) gload8(d + 2);
+                                        const int old = rgb_order ? (o0 << 16 | o1 << 8 | o2) : (o2 << 16 | o1 << 8 | o0);
+                                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
+                                    }
+                                    const unsigned char c0 = (unsigned char) (rgb_order ? rgb >> 16 : rgb);
+                                    const unsigned char c2 = (unsigned char) (rgb_order ? rgb : rgb >> 16);
+                                    for (int dup = 0; dup < nr; dup++) {
+                                        const unsigned long long dd = d + (size_t) dup * pitch;
+                                        gstore8(dd, c0); gstore8(dd + 1, (unsigned) (rgb >> 8)); gstore8(dd + 2, c2);
+                                    }
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    ppos += dx;
+                    px++;
+                }
+                py = cy; pi = ci; pq = cq;
+            }
+        }
+    }
+}
+
+/* host half of the decoder envelopes: the batch-wide floor of the decoder tier.
+ * tier 0 additionally needs the luma coefficients in [2^15, 1.5*2^16) and the chroma ones below 2^15 */
+static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
+{
+    const int b = p->bright < 0 ? -p->bright : p->bright;
+    const int ct = p->contrast < 0 ? -p->contrast : p->contrast;
+    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23)) return 3;
+    const bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
+                         p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
+                         p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
+    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX) return 2;
+    return c->no_loskip ? 1 : 0;
+}
+
+int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
+                   const crthip_line *d_lines, void *d_out, size_t ostride)
+{
+    const int min_tier = decoder_min_tier(c, p);
+    const bool wide = c->px_tile ? c->px_tile == 32 : p->outw >= 1280;
+    /* lines per output row when the picture is shorter than the raster: one pass per rank */
+    const unsigned span = (unsigned) p->outh + p->v_fac;
+    const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        const int total = n * S::LINES;
+        const dim3 grid((total + 63) / 64), block(64);
+        unsigned char *o = (unsigned char *) d_out;
+        ProfScope ps(c, CRTHIP_K_DECODE);
+        for (int rank = 0; rank < passes; rank++) {
+#define CRTHIP_LAUNCH_DECODE(T, B3) \
+    do { if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
+         else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); } while (0)
+            /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */
+            if (p->out_bpp == 3) {
+                if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, true);
+                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, true);
+                if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, true);
+                CRTHIP_LAUNCH_DECODE(3, true);
+            } else {
+                if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, false);
+                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, false);
+                if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, false);
+                CRTHIP_LAUNCH_DECODE(3, false);
+            }
+#undef CRTHIP_LAUNCH_DECODE
+        }
+        return CRTHIP_OK;
+    });
+}
+

@@ -1,0 +1,320 @@
+/*
+ * crt_dev.h -- shared by the HIP translation units of libcrthip (gfx950 / MI355X only).
+ *
+ * The reference (LMP88959/NTSC-CRT, C89, single threaded) processes one field with
+ * strictly serial per-scanline recurrences that floor after every multiply
+ * (crt_ntsc.c:117-126 iirf, crt_core.c:206-233 eqf), so no parallel scan can be
+ * bit-exact.  What IS independent: scanlines (filter state is reset per line,
+ * crt_ntsc.c:267-269, crt_core.c:534-536) and fields.  The design is therefore
+ *
+ *     one LANE per scanline, 64 scanlines per wavefront, many fields per launch
+ *
+ * with wave-uniform control flow: all 64 lanes are at the same sample x at the same
+ * time, so everything that depends only on x (source column, carrier phase, which
+ * output pixels become ready and their interpolation weights) lives in SGPRs / the
+ * scalar unit and costs no vector issue slots.
+ *
+ * Translation units (stage names M0-M6 / D0-D10 as in DESIGN.md):
+ *   crt_encode.hip  M4-M6   k_template / k_skeleton + k_margin (skeleton), k_active, k_nes_table + k_active_nes
+ *   crt_noise.hip   D1      k_noise (LCG, jump-ahead tables), k_vhs_noise + k_vhs_tail (libc rand() model)
+ *   crt_sync.hip    D2-D7   k_vsync, k_hsync (serial chain over the lines of a field)
+ *   crt_decode.hip  D8-D10  k_decode (3x 3-band IIR equaliser, resample, YIQ->RGB, row duplication)
+ *   crt_host.hip            context, the crthip_* C ABI, sequence mode
+ * Integer-only; signed overflow wraps (-fwrapv), >> of negatives is arithmetic, / truncates --
+ * identical to the reference on x86-64.
+ */
+#ifndef CRT_DEV_H
+#define CRT_DEV_H
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "crt_hip.h"
+#include "crt_setup.h"
+
+/* ------------------------------------------------------------------------- */
+/* compile-time system tables (device side); cross-checked against the C89    */
+/* host table crt_sysdef_get() when a context is created                      */
+/* ------------------------------------------------------------------------- */
+template <int CC_LINE>
+struct RgbTiming {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h */
+    static constexpr int HRES = CC_LINE * 4 / 10;
+    static constexpr int VRES = 262;
+    static constexpr int INPUT_SIZE = HRES * VRES;
+    static constexpr int TOP = 21, BOT = 261, LINES = BOT - TOP;
+    static constexpr int VPER = 1;
+    static constexpr int HWIN = 8, VWIN = 8;
+    static constexpr int WHITE = 100, BURST = 20, BLACK = 7, BLANK = 0, SYNC = -40;
+    static constexpr int HTHR = 4 * SYNC, VTHR = 94 * SYNC;
+    static constexpr int SYNC_BEG = 1500 * HRES / 63500;
+    static constexpr int BW_BEG = 6200 * HRES / 63500;
+    static constexpr int CB_BEG = 6800 * HRES / 63500;
+    static constexpr int AV_BEG = 10900 * HRES / 63500;
+    static constexpr int AV_LEN = 52600 * HRES / 63500;
+    static constexpr int VS_SEP_END = 0;
+    static constexpr bool IS_NES = false;
+};
+template <int CC_LINE>
+struct NesTiming {   /* crt_nes.h:30-126 */
+    static constexpr int HRES = CC_LINE * 4 / 10;
+    static constexpr int VRES = 262;
+    static constexpr int INPUT_SIZE = HRES * VRES;
+    static constexpr int TOP = 15, BOT = 255, LINES = BOT - TOP;
+    static constexpr int VPER = 3;
+    static constexpr int HWIN = 6, VWIN = 6;
+    static constexpr int WHITE = 110, BURST = 30, BLACK = 0, BLANK = 0, SYNC = -37;
+    static constexpr int HTHR = 4 * SYNC, VTHR = 94 * SYNC;
+    static constexpr int SYNC_BEG = 9 * HRES / 341;
+    static constexpr int BW_BEG = 34 * HRES / 341;
+    static constexpr int CB_BEG = 38 * HRES / 341;
+    static constexpr int AV_BEG = 74 * HRES / 341;
+    static constexpr int AV_LEN = 256 * HRES / 341;
+    static constexpr int VS_SEP_END = 327 * HRES / 341;
+    static constexpr bool IS_NES = true;
+};
+struct SysNTSC : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 1; static constexpr bool IS_VHS = false; };
+struct SysNTSC0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 0; static constexpr bool IS_VHS = false; };
+struct SysVHS : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 1; static constexpr bool IS_VHS = true; };
+struct SysVHS0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 0; static constexpr bool IS_VHS = true; };
+struct SysNES2 : NesTiming<2273> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 2; static constexpr bool IS_VHS = false; };
+struct SysNES1 : NesTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 1; static constexpr bool IS_VHS = false; };
+struct SysNES0 : NesTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 0; static constexpr bool IS_VHS = false; };
+
+static_assert(SysNTSC::HRES == 910 && SysNTSC::AV_BEG == 156 && SysNTSC::AV_LEN == 753 &&
+              SysNTSC::SYNC_BEG == 21 && SysNTSC::CB_BEG == 97, "NTSC timing (SURVEY.md section 8)");
+static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES == 912 &&
+              SysNES0::AV_LEN == 684, "NES timing (SURVEY.md section 8)");
+
+#define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
+#define CRTHIP_LINE_NROWS_MASK 0xffff     /* crthip_line.nrows bits 0-15: rows written              */
+#define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-27: rank among lines starting on the same row   */
+#define CRTHIP_LINE_RANK_MASK  0xfff
+#define CRTHIP_LINE_WIDE  0x10000000      /* bit 28: chroma too strong to drop the I/Q low cascades (decoder tier 0) */
+#define CRTHIP_LINE_NOT64 0x20000000      /* bit 29: outside the no-wrap envelope of the 64-bit-mad decoder */
+#define LOSKIP_WAVE_MAX   65532           /* |wave[k]| bound of decoder tier 0: |s*wave >> 9| <= 16383 */
+#define T0_WAVE_MAX       120000          /* |wave[k]| bound of decoder tiers 0 and 1 */
+#define T0_BRIGHT_MAX     2600            /* |bright| bound of decoder tiers 0 and 1  */
+#define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
+#define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
+#define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
+#define LCG_MUL 214019u          /* crt_core.c:359 */
+#define LCG_ADD 140327895u
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) unaligned16 { v4i v; };
+struct __attribute__((packed)) unaligned4 { int v; };
+
+/* The same through an explicit global (address space 1) pointer: addresses that went through LDS
+ * as integers would otherwise be treated as generic ("flat") and unaligned 16-byte accesses to them
+ * get split into dwords, because flat could mean LDS, where misaligned wide accesses are illegal. */
+typedef __attribute__((address_space(1))) unaligned16 g_unaligned16;
+typedef __attribute__((address_space(1))) unsigned g_u32;
+typedef __attribute__((address_space(1))) unsigned char g_u8;
+__device__ __forceinline__ v4i gload16u(unsigned long long a) { return ((const g_unaligned16 *) a)->v; }
+__device__ __forceinline__ void gstore16u(unsigned long long a, v4i v) { ((g_unaligned16 *) a)->v = v; }
+__device__ __forceinline__ unsigned gload32(unsigned long long a) { return *(const g_u32 *) a; }
+__device__ __forceinline__ void gstore32(unsigned long long a, unsigned v) { *(g_u32 *) a = v; }
+__device__ __forceinline__ unsigned gload8(unsigned long long a) { return *(const g_u8 *) a; }
+__device__ __forceinline__ void gstore8(unsigned long long a, unsigned v) { *(g_u8 *) a = (unsigned char) v; }
+
+__device__ __forceinline__ v4i load16u(const void *p) { return ((const unaligned16 *) p)->v; }
+__device__ __forceinline__ void store16u(void *p, v4i v) { ((unaligned16 *) p)->v = v; }
+__device__ __forceinline__ int load4u(const void *p) { return ((const unaligned4 *) p)->v; }
+__device__ __forceinline__ void store4u(void *p, int v) { ((unaligned4 *) p)->v = v; }
+
+__device__ __forceinline__ int posmod(int x, int n) { return ((x % n) + n) % n; }  /* crt_core.c:17 */
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* full-rate 24-bit multiply when FAST (operands proven inside [-2^23, 2^23)), else the
+ * quarter-rate exact 32-bit one -- see the comment above k_decode */
+template <bool FAST> __device__ __forceinline__ int mulq(int a, int b)
+{
+    if (FAST) return __mul24(a, b);
+    return a * b;
+}
+
+/* vgpr * sgpr.  __mul24's sign-extension of a LOOP-CARRIED operand gets hoisted to its definition in
+ * another basic block, after which instruction selection (per block) no longer knows the value fits
+ * 24 bits and falls back to the quarter-rate v_mul_lo_u32; pinning the instruction avoids that. */
+template <bool FAST> __device__ __forceinline__ int mulq_vs(int v, int s_uniform)
+{
+    if (FAST) {
+        int r;
+        asm("v_mul_i32_i24 %0, %2, %1" : "=v"(r) : "v"(v), "s"(s_uniform));
+        return r;
+    }
+    return v * s_uniform;
+}
+
+/* vgpr * sgpr + vgpr, 24-bit operands */
+__device__ __forceinline__ int mad24_vs(int v, int s_uniform, int acc)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(s_uniform), "v"(acc));
+    return r;
+}
+
+/* the low bytes of four ints -> one dword (3 permutes instead of 4 x (mask, shift, or)) */
+__device__ __forceinline__ unsigned pack4(int v0, int v1, int v2, int v3)
+{
+    const unsigned lo = __builtin_amdgcn_perm((unsigned) v1, (unsigned) v0, 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm((unsigned) v3, (unsigned) v2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+/* noise LCG, crt_core.c:359-364 */
+__device__ __forceinline__ unsigned lcg_step(unsigned rn) { return LCG_MUL * rn + LCG_ADD; }
+__device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)
+{
+    int s = sample + (((int) ((rn >> 16) & 0xffu) - 0x7f) * noise >> 8);
+    return clampi(s, -127, 127);
+}
+/* LCG state after `idx` steps from rn0; jump16[q] = affine map of 16*q steps */
+__device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, unsigned rn0, int idx)
+{
+    uint2 j = jump16[idx >> 4];
+    unsigned rn = j.x * rn0 + j.y;
+    for (int k = idx & 15; k > 0; k--) rn = lcg_step(rn);
+    return rn;
+}
+
+/* sizes shared between kernels and the context */
+#define NES_TAB_SIZE (512 * 12)            /* NES composite-sample table: 9-bit pixel x phase mod 12 */
+#define SKEL_VARIANTS 4                    /* cached clean skeleton fields (k_skeleton) */
+#define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 (248: measured slower) */
+#define VHS_BLK   43                       /* calls per lane in the tail's window: 64 * 43 >= 3 * HRES + 3 */
+
+/* first sample of the tail: a chunk boundary with at least 16 samples (>= 31 calls) before I0 + 1 */
+__host__ __device__ constexpr int vhs_tail_start(int input_size, int hres)
+{
+    return (input_size - 25 * hres + 1 - 16) / VHS_CHUNK * VHS_CHUNK;
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* host side: context, dispatch by system, C ABI                               */
+/* ------------------------------------------------------------------------- */
+struct crthip_ctx {
+    int device;
+    int system, pattern;
+    struct crt_sysdef sd;
+    hipStream_t stream;
+    bool own_stream;
+    uint2 *d_jump16;
+    uint2 whole_field;          /* affine map of INPUT_SIZE LCG steps */
+    size_t fstride;
+    /* workspace for crthip_fieldpass */
+    int cap_fields;
+    signed char *d_analog, *d_inp;
+    crthip_line *d_lines;
+    /* profiling */
+    bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
+    bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tiers */
+    bool no_loskip;             /* debug/test: never drop the I/Q low cascades */
+    signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table, rebuilt per encoder launch */
+    signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields, rebuilt per fused encoder launch */
+    uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
+    unsigned char *d_seq;       /* crthip_sequence scratch */
+    size_t seq_cap;
+    unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
+    int vhs_chunks;
+    unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
+    int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
+    int ac_tile;                /* encoder tile, same convention, by input width */
+    int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
+    hipStream_t aux_stream;
+    hipEvent_t ev_fork, ev_join;
+    bool prof;
+    double prof_ms[CRTHIP_K_COUNT];
+    int prof_n[CRTHIP_K_COUNT];
+    struct Pending { int k; hipEvent_t a, b; } *pend;
+    int npend, cappend;
+    char err[256];
+};
+
+static inline int set_err(crthip_ctx *c, int code, const char *what, hipError_t e)
+{
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+    return code;
+}
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(ctx, CRTHIP_E_HIP, #call, e_); } while (0)
+
+static inline void lcg_jump_host(unsigned k, unsigned *mul, unsigned *add)
+{
+    unsigned am = LCG_MUL, ac = LCG_ADD, rm = 1u, rc = 0u;
+    while (k) {
+        if (k & 1u) { rm = am * rm; rc = am * rc + ac; }
+        ac = am * ac + ac;
+        am = am * am;
+        k >>= 1;
+    }
+    *mul = rm;
+    *add = rc;
+}
+
+template <class S> static inline bool sysdef_matches(const struct crt_sysdef &d)
+{
+    return d.hres == S::HRES && d.vres == S::VRES && d.input_size == S::INPUT_SIZE && d.top == S::TOP &&
+           d.bot == S::BOT && d.vper == S::VPER && d.hsync_window == S::HWIN && d.vsync_window == S::VWIN &&
+           d.hsync_thresh == S::HTHR && d.vsync_thresh == S::VTHR && d.sync_beg == S::SYNC_BEG &&
+           d.bw_beg == S::BW_BEG && d.cb_beg == S::CB_BEG && d.av_beg == S::AV_BEG && d.av_len == S::AV_LEN &&
+           d.vs_sep_end == S::VS_SEP_END && d.white_level == S::WHITE && d.burst_level == S::BURST &&
+           d.black_level == S::BLACK && d.blank_level == S::BLANK && d.sync_level == S::SYNC;
+}
+
+/* call fn(S{}) with the system table type S of (system, pattern); fn is a generic lambda */
+template <class F> static int dispatch_system(int system, int pattern, F &&fn)
+{
+    if (system == CRTHIP_SYSTEM_NTSC) return pattern == 1 ? fn(SysNTSC{}) : fn(SysNTSC0{});
+    if (system == CRTHIP_SYSTEM_NTSCVHS) return pattern == 1 ? fn(SysVHS{}) : fn(SysVHS0{});
+    if (system == CRTHIP_SYSTEM_NES) {
+        if (pattern == 2) return fn(SysNES2{});
+        if (pattern == 1) return fn(SysNES1{});
+        return fn(SysNES0{});
+    }
+    return CRTHIP_E_ARG;
+}
+
+struct ProfScope {
+    crthip_ctx *c; int k; hipEvent_t a, b; bool on;
+    ProfScope(crthip_ctx *ctx, int kernel) : c(ctx), k(kernel), on(ctx->prof)
+    {
+        if (on) {
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        hipEventRecord(b, c->stream);
+        if (c->npend == c->cappend) {
+            int ncap = c->cappend ? c->cappend * 2 : 64;
+            c->pend = (crthip_ctx::Pending *) realloc(c->pend, sizeof(*c->pend) * (size_t) ncap);
+            c->cappend = ncap;
+        }
+        c->pend[c->npend].k = k; c->pend[c->npend].a = a; c->pend[c->npend].b = b;
+        c->npend++;
+    }
+};
+
+
+/* launch entry points of the other translation units (enqueue on c->stream; no synchronisation) */
+int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state);
+int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state);
+int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
+                  crthip_state *d_state, bool advance_rn);
+int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
+int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
+                 crthip_line *d_lines, int advance_rn);
+int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
+                   const crthip_line *d_lines, void *d_out, size_t ostride);
+
+#endif /* CRT_DEV_H */

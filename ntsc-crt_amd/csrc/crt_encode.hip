@@ -1,0 +1,743 @@
+/* crt_encode.hip -- crt_modulate on the GPU: skeleton (M4), active video (M5), ccf preset (M6).  See crt_dev.h. */
+#include "crt_dev.h"
+
+/* ------------------------------------------------------------------------- */
+/* M4: blanking / sync / burst skeleton                                        */
+/* ------------------------------------------------------------------------- */
+/* value of skeleton sample (line n, column t) and whether crt_modulate writes it.
+ * RGB systems: crt_ntsc.c:205-252 (+ crt_ntscvhs.c:234-238);  NES: crt_nes.c:81-104,173-178 */
+template <class S>
+__device__ __forceinline__ bool
+skeleton(const crthip_params &P, int n, int t, int field, int inv_phase, int aux, bool nes_setup, int &val)
+{
+    if constexpr (S::IS_NES) {
+        bool written = nes_setup;
+        val = S::BLANK;
+        if (t >= S::SYNC_BEG && t < (n >= 259 ? S::VS_SEP_END : S::BW_BEG)) val = S::SYNC;
+        if (n >= P.yo && n < P.yo + S::LINES && t >= S::CB_BEG && t < S::CB_BEG + CB_SAMPLES) {
+            int cb = P.burst[(n % 3 + aux) % 3][t & 3];
+            val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
+            written = true;
+        }
+        return written;
+    } else {
+        if (n <= 3 || (n >= 7 && n <= 9)) {            /* equalising pulses */
+            val = (t < 4 * S::HRES / 100 || (t >= 50 * S::HRES / 100 && t < 54 * S::HRES / 100)) ? S::SYNC : S::BLANK;
+            return true;
+        }
+        if (n >= 4 && n <= 6) {                        /* vertical sync */
+            int a = (field == 1 ? 4 : 46) * S::HRES / 100;
+            val = (t < a || (t >= 50 * S::HRES / 100 && t < 96 * S::HRES / 100)) ? S::SYNC : S::BLANK;
+            return true;
+        }
+        if (t >= S::AV_BEG) {                          /* active part: only cleared above CRT_TOP */
+            val = S::BLANK;
+            return n < S::TOP;
+        }
+        val = S::BLANK;
+        if (t >= S::SYNC_BEG && t < S::BW_BEG && n < S::VRES - aux) val = S::SYNC;
+        if (t >= S::CB_BEG && t < S::CB_BEG + CB_SAMPLES) {
+            int cb = S::PATTERN == 1 ? P.burst[0][(t + inv_phase * 2) & 3] : P.burst[0][t & 3];
+            val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
+        }
+        return true;
+    }
+}
+
+/* Drop-in (stage-level) path: write exactly the reference's write-set into analog[]; all other
+ * samples keep their contents.  One lane per 16 consecutive samples. */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
+           const crthip_state *__restrict__ state, int nes_setup)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_fields * CHUNKS) return;
+    const int f = gid / CHUNKS;
+    const int q = gid - f * CHUNKS;
+    const int idx0 = q * 16;
+    const crthip_state st = state[f];
+    const int field = st.field & 1;
+    const int inv_phase = (field == (st.frame & 1));
+    int line = idx0 / S::HRES;
+    int t = idx0 - line * S::HRES;
+    signed char *out = dst + (size_t) f * fstride;
+
+    /* chunks entirely inside the active rectangle belong to k_active */
+    if (t >= P.xo && t + 15 < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth) return;
+    int vals[16];
+    unsigned wmask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int v = 0;
+        const bool in_field = idx0 + k < S::INPUT_SIZE;
+        const bool active = t >= P.xo && t < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth;
+        const bool wr = skeleton<S>(P, line, t, field, inv_phase, st.aux, nes_setup != 0, v);
+        if (wr && !active && in_field) wmask |= 1u << k;
+        vals[k] = v;
+        if (++t == S::HRES) { t = 0; line++; }
+    }
+    if (wmask == 0xffffu) {
+        v4i pk;
+        pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+        pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+        pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+        pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
+        store16u(out + idx0, pk);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (wmask >> k & 1u) out[idx0 + k] = (signed char) vals[k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* M5: active video, one lane per destination row                              */
+/* ------------------------------------------------------------------------- */
+/* v_perm_b32 selector turning a loaded pixel (bytes in memory order, 3-byte formats zero-extended)
+ * into 0x??RRGGBB for the 6 byte orders of crt_ntsc.c:278-305 */
+__device__ __forceinline__ unsigned input_selector(int format)
+{
+    switch (format) {
+    case CRTHIP_FMT_BGR: case CRTHIP_FMT_BGRA: return 0x03020100u;
+    case CRTHIP_FMT_RGB: case CRTHIP_FMT_RGBA: return 0x03000102u;
+    case CRTHIP_FMT_ARGB: return 0x00010203u;
+    default /* ABGR */:   return 0x00030201u;
+    }
+}
+
+/* NES PPU square wave, crt_nes.c:21-61 */
+__device__ __forceinline__ int ppu_level(int p, int phase)
+{
+    const int hue = p & 15;
+    if (hue >= 14) return 0;
+    int high = ((hue + phase) % 12) < 6;
+    if (hue == 0) high = 1;
+    if (hue == 13) high = 0;
+    /* active[] = {0300,0100,0500,0400,0600,0200}: emphasis bits attenuating this phase */
+    const int slot = (phase >> 1) % 6;
+    const int mask = slot == 0 ? 0300 : slot == 1 ? 0100 : slot == 2 ? 0500 : slot == 3 ? 0400 : slot == 4 ? 0600 : 0200;
+    const int emph = (p & 0700 & mask) != 0;
+    const int lum = (p >> 4) & 3;
+    /* IRE[(high<<3) + (emph<<2) + lum] */
+    int v;
+    if (high) {
+        v = emph ? (lum == 0 ? 26951 : lum == 1 ? 52181 : 83721)
+                 : (lum == 0 ? 43581 : lum == 1 ? 75693 : 112965);
+    } else {
+        v = emph ? (lum == 0 ? -17203 : lum == 1 ? -8028 : lum == 2 ? 19497 : 57342)
+                 : (lum == 0 ? -12042 : lum == 1 ? 0 : lum == 2 ? 34406 : 81427);
+    }
+    return v;
+}
+
+/* FAST: 24-bit multiplies (always in range for the IIRs and the carrier products: 8-bit pixels
+ * bound every state; `white` and `noise` are range-checked on the host).
+ * IN4: 4-byte input pixels moved through a cooperative LDS tile (see the comment above k_decode);
+ * otherwise (3-byte formats, tiny images) each lane reads its own pixels bytewise.
+ * The produced samples always leave through a cooperative LDS tile. */
+/* ACT = dwords per row and tile (ACT pixels in, 4*ACT samples out): 32 moves full 128-byte lines per row
+ * piece group, 16 halves the LDS footprint (more waves per SIMD) -- chosen by input width at launch */
+/* CLAMP: output is inp[] (fused path), i.e. the +-127 clamp of crt_core.c:363-364 applies even when
+ * no noise is added (only matters for NES, whose samples can be -128) */
+template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT>
+__global__ void __launch_bounds__(64)
+k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
+         signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
+         const uint2 *__restrict__ jump16)
+{
+    constexpr int AC_TILE = ACT, AC_STRIDE = ACT + 1, AC_PIECES = ACT / 4;   /* 16-byte pieces per tile row */
+    constexpr int AC_ROWS = 64 / AC_PIECES, AC_SHIFT = ACT == 32 ? 5 : 4;      /* rows per load instruction */
+    __shared__ unsigned s_pix[64 * AC_STRIDE];
+    __shared__ unsigned s_out[64 * AC_STRIDE];
+    __shared__ unsigned long long s_src[64], s_dst[64];
+
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
+    const int rows = P.desth;
+    const bool live = gid < n_fields * rows;
+    const int f = live ? gid / rows : 0;
+    const int y = live ? gid - f * rows : 0;
+    const crthip_state st = state[f];
+    const unsigned char *img = images + (size_t) f * istride;
+    const int start = (y + P.yo) * S::HRES + P.xo;
+    unsigned rn = 0;
+    if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, start);
+
+    const int w = P.w, destw = P.destw;
+    const int qstep = w / destw, rstep = w - qstep * destw;   /* column = floor(x*w/destw), incrementally */
+    int col = 0, err = 0;                                     /* wave-uniform */
+    const int ngroups = (destw + 3) >> 2;
+
+    /* per-row source / destination, published to the whole wave */
+    int sy;
+    if constexpr (S::IS_NES) {
+        sy = (y * P.h) / S::LINES;                            /* crt_nes.c:165-168 */
+        if (sy >= P.h) sy = P.h;
+        if (sy < 0) sy = 0;
+    } else {
+        const int field = st.field & 1;
+        const int field_offset = (field * P.h + P.desth) / P.desth / 2;
+        sy = (y * P.h) / P.desth + field_offset;              /* crt_ntsc.c:258-263 */
+        if (sy >= P.h) sy = P.h;                              /* (sic) */
+    }
+    const int in_bpp = S::IS_NES ? 2 : P.in_bpp;
+    const unsigned char *row = img + (size_t) sy * w * in_bpp;
+    s_src[lane] = (unsigned long long) row;
+    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
+    __syncthreads();
+
+    /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
+    auto drain = [&](int g0, int ng) {
+        __syncthreads();
+        const int orow = lane / AC_PIECES, piece = lane % AC_PIECES;   /* 16 bytes per piece */
+        const int first = (g0 + piece * 4) * 4;               /* first sample of my piece */
+        const int nbytes = destw - first < 16 ? destw - first : 16;
+#pragma unroll 2
+        for (int i = 0; i < AC_PIECES; i++) {
+            const int r = i * AC_ROWS + orow;
+            const unsigned long long d = s_dst[r];
+            if (d != 0 && piece * 4 < ng && nbytes > 0) {
+                const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
+                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+                if (nbytes == 16) {
+                    gstore16u(d + first, o);
+                } else {
+                    const int wds[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    if constexpr (S::IS_NES) {
+        /* crt_nes.c:162-193 */
+        const unsigned short *prow = (const unsigned short *) row;
+        int phase = 4 * ((y + P.yo + st.aux) % 3);           /* phasetab {0,4,8} */
+        for (int g = 0; g < ngroups; g++) {
+            unsigned pack = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = 4 * g + k;
+                if (x < destw) {
+                    int p = prow[col];
+                    int ire = S::BLACK + P.black_point;
+                    ire += ppu_level(p, phase + 0);
+                    ire += ppu_level(p, phase + 1);
+                    ire += ppu_level(p, phase + 2);
+                    ire += ppu_level(p, phase + 3);
+                    ire = (ire * P.white_point / 100) >> 12;
+                    ire = (int) (signed char) ire;
+                    if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                    else if (CLAMP) ire = clampi(ire, -127, 127);
+                    pack |= (unsigned) (ire & 255) << (8 * k);
+                    phase += 3;
+                    col += qstep; err += rstep;
+                    if (err >= destw) { err -= destw; col++; }
+                }
+            }
+            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
+            if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+        }
+    } else {
+        /* crt_ntsc.c:254-324 */
+        const int field = st.field & 1;
+        const int inv_phase = (field == (st.frame & 1));
+        const int ph = (S::PATTERN == 1 && (inv_phase & 1)) ? -1 : 1;
+        /* (h * ph) * cc == h * (ph * cc) in wrapping arithmetic; xo is a multiple of 4 (crt_ntsc.c:203)
+         * so the carrier phase (x + xo) % 4 is x & 3 */
+        const int cI0 = ph * P.modI[0], cI1 = ph * P.modI[1], cI2 = ph * P.modI[2], cI3 = ph * P.modI[3];
+        const int cQ0 = ph * P.modQ[0], cQ1 = ph * P.modQ[1], cQ2 = ph * P.modQ[2], cQ3 = ph * P.modQ[3];
+        const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
+        const unsigned isel = input_selector(P.format);
+        const int white = P.white, ire_base = P.ire_base, noise = P.noise;
+        int hy = 0, hi = 0, hq = 0;
+
+        /* IN4 pixel tiles: 32 pixels (128 bytes) per row; pieces of 16 bytes, 8 per row, 8 rows per
+         * load instruction.  `have` = tile in LDS, `stage[]` = tile have+1 in flight / in registers.
+         * A piece that would run past the row end is moved back to the row's last 16 bytes, so
+         * nothing beyond the image is touched (w >= 4). */
+        const int prow_ = lane / AC_PIECES, piece = lane % AC_PIECES;
+        const int last_tile = (w - 1) >> AC_SHIFT;
+        const int row_bytes = w * 4;
+        v4i stage[AC_PIECES];
+        auto piece_offset = [&](int tile) {
+            int off = tile * (AC_TILE * 4) + piece * 16;
+            return off > row_bytes - 16 ? row_bytes - 16 : off;
+        };
+        auto fetch = [&](int tile) {
+            const int off = piece_offset(tile);
+#pragma unroll
+            for (int i = 0; i < AC_PIECES; i++) stage[i] = gload16u(s_src[i * AC_ROWS + prow_] + off);
+        };
+        auto stash = [&](int tile) {
+            /* dword index inside the tile where my (possibly moved-back) piece belongs; moved-back
+             * pieces of several lanes overlap and carry identical bytes */
+            const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;     /* may be negative for a moved-back piece */
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < AC_PIECES; i++) {
+                unsigned *d = s_pix + (i * AC_ROWS + prow_) * AC_STRIDE;
+                if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
+                if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
+                if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
+                if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+            }
+            __syncthreads();
+        };
+        int have = 0;
+        if (IN4) {
+            fetch(0);
+            stash(0);
+            if (last_tile > 0) fetch(1);
+        }
+        const int noise127 = 0x7f * noise;
+        for (int g = 0; g < ngroups; g++) {
+            int smp[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = 4 * g + k;
+                if (x < destw) {
+                    unsigned pixel;
+                    if (IN4) {
+                        const int need = col >> AC_SHIFT;          /* wave-uniform */
+                        if (need != have) {
+                            if (need != have + 1) fetch(need);      /* only when w > 32*destw */
+                            stash(need);
+                            have = need;
+                            if (need < last_tile) fetch(need + 1);
+                        }
+                        pixel = s_pix[lane * AC_STRIDE + (col & (AC_TILE - 1))];
+                    } else {
+                        const unsigned char *pp = row + (size_t) col * in_bpp;
+                        pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
+                        if (in_bpp == 4) pixel |= (unsigned) pp[3] << 24;
+                    }
+                    const unsigned rgb = __builtin_amdgcn_perm(pixel, pixel, isel);
+                    const int r = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, b = rgb & 255;
+                    const int fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
+                    const int fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
+                    const int fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
+                    hy += mulq<FAST>(fy - hy, cy_) >> 11;           /* iirf, crt_ntsc.c:117-126 */
+                    hi += mulq<FAST>(fi - hi, ci_) >> 11;
+                    hq += mulq<FAST>(fq - hq, cq_) >> 11;
+                    const int mi = mulq<FAST>(hi, k == 0 ? cI0 : k == 1 ? cI1 : k == 2 ? cI2 : cI3) >> 4;
+                    const int mq = mulq<FAST>(hq, k == 0 ? cQ0 : k == 1 ? cQ1 : k == 2 ? cQ2 : cQ3) >> 4;
+                    int ire = ire_base + (mulq<FAST>(hy + mi + mq, white) >> 10);
+                    ire = clampi(ire, 0, 110);
+                    if (NOISE) {
+                        rn = lcg_step(rn);
+                        /* (byte - 0x7f) * noise, distributed: the byte select rides on the multiply (SDWA) */
+                        ire = clampi(ire + ((mulq<FAST>((int) ((rn >> 16) & 0xffu), noise) - noise127) >> 8), -127, 127);
+                    }
+                    smp[k] = ire;
+                    col += qstep; err += rstep;
+                    if (err >= destw) { err -= destw; col++; }
+                }
+            }
+            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack4(smp[0], smp[1], smp[2], smp[3]);
+            if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* M5, NES flavour (crt_nes.c:162-193) with a lookup table                     */
+/* ------------------------------------------------------------------------- */
+/* A composite sample of the NES is  ((BLACK + black_point + sum_{k<4} square(p, phase+k)) * white_point / 100) >> 12
+ * truncated to a signed char.  square() depends on the phase only through (hue+phase)%12 and (phase>>1)%6,
+ * both 12-periodic, so the sample is a function of (9-bit pixel, phase mod 12): 512 x 12 bytes, rebuilt per
+ * launch because it contains the black / white point knobs. */
+template <class S>
+__global__ void k_nes_table(const crthip_params P, signed char *tab)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NES_TAB_SIZE) return;
+    const int p = idx / 12, ph = idx - p * 12;
+    int ire = S::BLACK + P.black_point;
+    ire += ppu_level(p, ph + 0);
+    ire += ppu_level(p, ph + 1);
+    ire += ppu_level(p, ph + 2);
+    ire += ppu_level(p, ph + 3);
+    ire = (ire * P.white_point / 100) >> 12;
+    tab[idx] = (signed char) ire;
+}
+
+template <class S, bool NOISE, bool CLAMP, int ACT>
+__global__ void __launch_bounds__(64)
+k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
+             signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
+             const uint2 *__restrict__ jump16, const signed char *__restrict__ tab)
+{
+    constexpr int AC_TILE = ACT, AC_STRIDE = ACT + 1, AC_PIECES = ACT / 4;
+    constexpr int AC_ROWS = 64 / AC_PIECES, AC_SHIFT = ACT == 32 ? 5 : 4;
+    __shared__ unsigned s_pix[64 * AC_STRIDE];
+    __shared__ unsigned s_out[64 * AC_STRIDE];
+    __shared__ unsigned long long s_src[64], s_dst[64];
+    __shared__ unsigned s_tab[NES_TAB_SIZE / 4];
+
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
+    const int rows = S::LINES;
+    const bool live = gid < n_fields * rows;
+    const int f = live ? gid / rows : 0;
+    const int y = live ? gid - f * rows : 0;
+    const crthip_state st = state[f];
+    const unsigned char *img = images + (size_t) f * istride;
+    const int start = (y + P.yo) * S::HRES + P.xo;
+    unsigned rn = 0;
+    if (NOISE) rn = lcg_at(jump16, (unsigned) st.rn, start);
+    for (int i = lane; i < NES_TAB_SIZE / 4; i += 64) s_tab[i] = ((const unsigned *) tab)[i];
+
+    const int w = P.w, destw = P.destw;
+    const int qstep = w / destw, rstep = w - qstep * destw;
+    int col = 0, err = 0;
+    const int ngroups = (destw + 3) >> 2;
+    int sy = (y * P.h) / S::LINES;                              /* crt_nes.c:165-168 */
+    if (sy >= P.h) sy = P.h;
+    if (sy < 0) sy = 0;
+    s_src[lane] = (unsigned long long) (img + (size_t) sy * w * 2);
+    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
+    __syncthreads();
+
+    auto drain = [&](int g0, int ng) {
+        __syncthreads();
+        const int orow = lane / AC_PIECES, piece = lane % AC_PIECES;
+        const int first = (g0 + piece * 4) * 4;
+        const int nbytes = destw - first < 16 ? destw - first : 16;
+#pragma unroll 2
+        for (int i = 0; i < AC_PIECES; i++) {
+            const int r = i * AC_ROWS + orow;
+            const unsigned long long d = s_dst[r];
+            if (d != 0 && piece * 4 < ng && nbytes > 0) {
+                const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
+                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+                if (nbytes == 16) {
+                    gstore16u(d + first, o);
+                } else {
+                    const int wds[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    /* pixel tiles: AC_TILE dwords = 2*AC_TILE PPU pixels per row (see k_active) */
+    const int prow_ = lane / AC_PIECES, piece = lane % AC_PIECES;
+    const int row_bytes = w * 2;
+    const int last_tile = (row_bytes - 1) / (AC_TILE * 4);
+    v4i stage[AC_PIECES];
+    auto piece_offset = [&](int tile) {
+        int off = tile * (AC_TILE * 4) + piece * 16;
+        return off > row_bytes - 16 ? row_bytes - 16 : off;
+    };
+    auto fetch = [&](int tile) {
+        const int off = piece_offset(tile);
+#pragma unroll
+        for (int i = 0; i < AC_PIECES; i++) stage[i] = gload16u(s_src[i * AC_ROWS + prow_] + off);
+    };
+    auto stash = [&](int tile) {
+        const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AC_PIECES; i++) {
+            unsigned *d = s_pix + (i * AC_ROWS + prow_) * AC_STRIDE;
+            if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
+            if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
+            if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
+            if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+        }
+        __syncthreads();
+    };
+    int have = 0;
+    fetch(0);
+    stash(0);
+    if (last_tile > 0) fetch(1);
+
+    int ph = 4 * ((y + P.yo + st.aux) % 3);                    /* phasetab {0,4,8}; advances by 3 per sample, mod 12 */
+    const signed char *tb = (const signed char *) s_tab;
+    for (int g = 0; g < ngroups; g++) {
+        int smp[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = 4 * g + k;
+            if (x < destw) {
+                const int need = col >> (AC_SHIFT + 1);         /* wave-uniform */
+                if (need != have) {
+                    if (need != have + 1) fetch(need);
+                    stash(need);
+                    have = need;
+                    if (need < last_tile) fetch(need + 1);
+                }
+                const unsigned dw = s_pix[lane * AC_STRIDE + ((col >> 1) & (AC_TILE - 1))];
+                const int p = (int) ((col & 1) ? dw >> 16 : dw & 0xffffu);
+                /* data[] is unsigned short (crt_nes.h:133): the reference's table walks only look at bits 0-8 */
+                int ire = tb[(p & 511) * 12 + ph];
+                if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, P.noise); }
+                else if (CLAMP) ire = clampi(ire, -127, 127);
+                smp[k] = ire;
+                ph += 3;
+                if (ph >= 12) ph -= 12;
+                col += qstep; err += rstep;
+                if (err >= destw) { err -= destw; col++; }
+            }
+        }
+        s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack4(smp[0], smp[1], smp[2], smp[3]);
+        if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+    }
+}
+
+/* The clean skeleton (blanking / sync / burst, 0 where crt_modulate writes nothing) of a whole field depends
+ * only on a handful of per-field inputs: RGB systems (field, frame parity) -> 4 variants; NES the dot crawl
+ * offset mod 3 -> 3 variants.  k_skeleton writes the variants once per launch (a few fields' worth of work),
+ * k_margin then only copies 16 bytes and adds the channel noise. */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_skeleton(const crthip_params P, signed char *__restrict__ skel, size_t fstride)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= SKEL_VARIANTS * CHUNKS) return;
+    const int var = gid / CHUNKS;
+    const int idx0 = (gid - var * CHUNKS) * 16;
+    const int field = S::IS_NES ? 0 : var >> 1;
+    const int inv_phase = S::IS_NES ? 0 : (field == (var & 1));
+    const int aux = S::IS_NES ? var : 0;                       /* VHS: the aberration band is patched in by k_margin */
+    int line = idx0 / S::HRES;
+    int t = idx0 - line * S::HRES;
+    int vals[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int v = 0;
+        if (!skeleton<S>(P, line, t, field, inv_phase, aux, true, v)) v = 0;
+        vals[k] = v;
+        if (++t == S::HRES) { t = 0; line++; }
+    }
+    v4i pk;
+    pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+    pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+    pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+    pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
+    store16u(skel + (size_t) var * fstride + idx0, pk);        /* the last chunk runs into the field's slack */
+}
+
+/* Fused path only: everything OUTSIDE the active rectangle of a field that started from a clean
+ * analog[] -- skeleton value (or 0) plus channel noise, written straight into inp[].  The complement
+ * of the rectangle in flat sample order is
+ *     head   [0, S0)                                   S0 = yo*HRES + xo
+ *     gap y  [S0 + y*HRES + destw, S0 + (y+1)*HRES)    y = 0 .. desth-2
+ *     tail   [S0 + (desth-1)*HRES + destw, INPUT_SIZE)
+ * and each lane takes one run of up to 16 samples of it: 16 bytes of the cached skeleton variant
+ * (k_skeleton), + noise (LCG state by the 16-step jump table and a 16-entry table for the remainder). */
+template <class S, bool NOISE>
+__global__ void __launch_bounds__(256)
+k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
+         const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1,
+         const signed char *__restrict__ skel, int head_chunks, int gap_chunks, int tail_chunks)
+{
+    const int per_field = head_chunks + (P.desth - 1) * gap_chunks + tail_chunks;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_fields * per_field) return;
+    const int f = gid / per_field;
+    int q = gid - f * per_field;
+    const int s0 = P.yo * S::HRES + P.xo;
+    const int gap_len = S::HRES - P.destw;
+    int idx0, len;
+    if (q < head_chunks) {
+        idx0 = q * 16;
+        len = s0 - idx0;
+    } else if (q < head_chunks + (P.desth - 1) * gap_chunks) {
+        q -= head_chunks;
+        const int yy = q / gap_chunks, c = q - yy * gap_chunks;
+        idx0 = s0 + yy * S::HRES + P.destw + c * 16;
+        len = gap_len - c * 16;
+    } else {
+        q -= head_chunks + (P.desth - 1) * gap_chunks;
+        idx0 = s0 + (P.desth - 1) * S::HRES + P.destw + q * 16;
+        len = S::INPUT_SIZE - idx0;
+    }
+    if (len > 16) len = 16;
+    const crthip_state *st = state + f;
+    const int aux = st->aux;
+    const int var = S::IS_NES ? aux % 3 : ((st->field & 1) << 1) | (st->frame & 1);
+    signed char *out = dst + (size_t) f * fstride;
+    const v4i sk = load16u(skel + (size_t) var * fstride + idx0);
+    int wds[4] = { sk.x, sk.y, sk.z, sk.w };
+    if constexpr (S::IS_VHS) {
+        /* no sync pulse inside the aberration band (crt_ntscvhs.c:234-238): lines n >= VRES - aux */
+        const int line0 = idx0 / S::HRES, t0 = idx0 - line0 * S::HRES;
+        if (aux > 0 && line0 + 1 >= S::VRES - aux) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                int t = t0 + k, n = line0;
+                if (t >= S::HRES) { t -= S::HRES; n++; }
+                if (n >= S::VRES - aux && n >= 10 && t >= S::SYNC_BEG && t < S::BW_BEG)
+                    wds[k >> 2] = (wds[k >> 2] & ~(0xff << (8 * (k & 3)))) | ((S::BLANK & 0xff) << (8 * (k & 3)));
+            }
+        }
+    }
+    v4i pk;
+    if (NOISE) {
+        unsigned rn;
+        {
+            const uint2 j = jump16[idx0 >> 4], r = jump1[idx0 & 15];
+            rn = r.x * (j.x * (unsigned) st->rn + j.y) + r.y;
+        }
+        int vals[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            rn = lcg_step(rn);
+            vals[k] = noisy((wds[k >> 2] << (24 - 8 * (k & 3))) >> 24, rn, P.noise);
+        }
+        pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+        pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+        pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+        pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
+    } else {
+        /* noise 0: crt_core.c:362-364 still clamps to +-127, which no skeleton value exceeds */
+        pk.x = wds[0]; pk.y = wds[1]; pk.z = wds[2]; pk.w = wds[3];
+    }
+    if (len == 16) {
+        store16u(out + idx0, pk);
+    } else {
+        const int o4[4] = { pk.x, pk.y, pk.z, pk.w };
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < len) out[idx0 + k] = (signed char) (o4[k >> 2] >> (8 * (k & 3)));
+        }
+    }
+    if (gid - f * per_field == 0) {
+        /* mirror of the struct members behind inp[] (see CRTHIP_TAIL) */
+        signed char *tail = out + S::INPUT_SIZE;
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+    }
+}
+
+static bool encoder_fast_ok(const crthip_params *p)
+{
+    const int wh = p->white < 0 ? -p->white : p->white;
+    const int nz = p->noise < 0 ? -p->noise : p->noise;
+    return wh < (1 << 23) && nz < (1 << 23);
+}
+
+template <class S, bool FULL, bool FAST>
+static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                          signed char *dst, const crthip_state *d_state)
+{
+    ProfScope ps(c, CRTHIP_K_ACTIVE);
+    const int total = n * p->desth;
+    const dim3 grid((total + 63) / 64), block(64);
+    const unsigned char *img = (const unsigned char *) d_images;
+    if constexpr (S::IS_NES) {
+        if (p->w >= 8) {
+            hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, c->stream, *p, c->d_nes_tab);
+            if (FULL && p->noise != 0)
+                hipLaunchKernelGGL((k_active_nes<S, true, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
+            else
+                hipLaunchKernelGGL((k_active_nes<S, false, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
+            return;
+        }
+    }
+    const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
+    const bool noise = FULL && p->noise != 0;
+    const bool wide_in = c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
+#define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
+         else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
+    if (noise) { if (in4) CRTHIP_LAUNCH_ACTIVE(true, true); else CRTHIP_LAUNCH_ACTIVE(true, false); }
+    else       { if (in4) CRTHIP_LAUNCH_ACTIVE(false, true); else CRTHIP_LAUNCH_ACTIVE(false, false); }
+#undef CRTHIP_LAUNCH_ACTIVE
+}
+
+template <class S, bool FULL>
+static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                          signed char *dst, const crthip_state *d_state, int nes_setup)
+{
+    if (FULL) {
+        /* fused path: skeleton + noise for everything outside the active rectangle */
+        ProfScope ps(c, CRTHIP_K_TEMPLATE);
+        const int s0 = p->yo * S::HRES + p->xo;
+        const int head = (s0 + 15) / 16;
+        const int gap = (S::HRES - p->destw + 15) / 16;
+        const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
+        const int tail = (tail_len + 15) / 16;
+        const int total = n * (head + (p->desth - 1) * gap + tail);
+        constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
+        hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
+        if (p->noise != 0)
+            hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+        else
+            hipLaunchKernelGGL((k_margin<S, false>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+    } else {
+        constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+        ProfScope ps(c, CRTHIP_K_TEMPLATE);
+        const int total = n * CHUNKS;
+        hipLaunchKernelGGL((k_template<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, nes_setup);
+    }
+    if (encoder_fast_ok(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
+    else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state);
+    return CRTHIP_OK;
+}
+
+/* after crt_modulate: ccf preset (crt_ntsc.c:325-329, crt_nes.c:196-200), VHS resets (crt_ntscvhs.c:259,332-336) */
+template <class S>
+__global__ void k_encoder_state(const crthip_params P, int n_fields, crthip_state *state)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_fields) return;
+    crthip_state *st = state + f;
+    if constexpr (S::IS_NES) {
+        for (int r = 0; r < 3; r++) {
+            /* iccf[n % 3] is last written by the bottom-most line with that residue; all lines of a
+             * residue class write the same burst, so any line n of the class will do */
+            for (int k = 0; k < 4; k++) {
+                int cb = P.burst[(r + st->aux) % 3][k];
+                st->ccf[r][k] = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
+            }
+        }
+    } else {
+        const int inv_phase = ((st->field & 1) == (st->frame & 1));
+        for (int k = 0; k < 4; k++) {
+            int cb = S::PATTERN == 1 ? P.burst[0][(k + inv_phase * 2) & 3] : P.burst[0][k];
+            int v = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
+            st->ccf[0][k] = S::IS_VHS ? 0 : v;
+        }
+        if (S::IS_VHS) st->hsync = 0;
+        st->field &= 1;
+        st->frame &= 1;
+    }
+}
+
+
+int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        int r = fused ? launch_encoder<S, true>(c, p, n, d_images, istride, dst, d_state, nes_setup)
+                      : launch_encoder<S, false>(c, p, n, d_images, istride, dst, d_state, nes_setup);
+        if (with_state) hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
+        return r;
+    });
+}
+
+int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
+        return CRTHIP_OK;
+    });
+}

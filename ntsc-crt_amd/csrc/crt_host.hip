@@ -1,0 +1,614 @@
+/* crt_host.hip -- context, the crthip_* C ABI (include/crt_hip.h), sequence mode.  See crt_dev.h. */
+#include "crt_dev.h"
+
+/* ------------------------------------------------------------------------- */
+/* Sequence mode: n consecutive fields of ONE television set  */
+/* ------------------------------------------------------------------------- */
+/* Sequential semantics of   for k: crt_modulate(field k); crt_demodulate(); save(out)   (the loop of
+ * extra/video_convert.c:246-277) reproduced with parallel kernels:
+ *   rn      : closed form, rn_k = J^k(rn_0), J = INPUT_SIZE steps of the LCG;
+ *   encoder : independent per field (fused, writes the noisy field);
+ *   sync    : field k starts from field k-1's final (hsync, vsync).  Solved as a fixed point: every
+ *             pass runs k_vsync/k_hsync for ALL fields in parallel with init_k = final_{k-1} of the
+ *             previous pass; after pass j fields 0..j-1 are final for good, and because a field's final
+ *             state hardly ever depends on its initial one the iteration normally stops after 2-3 passes;
+ *   decoder : independent per field given its line table (blend must be 0: with blend the output is a
+ *             recurrence over fields);
+ *   weave   : output image k = the single output buffer after field k: rows field k does not write come
+ *             from the latest earlier field that wrote them (or the initial buffer). */
+__global__ void k_seq_rn(int n_fields, crthip_state *state, uint2 whole_field)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fields) return;
+    /* (m, a) = J^k by square and multiply */
+    unsigned pm = whole_field.x, pa = whole_field.y, m = 1u, a = 0u;
+    for (unsigned e = (unsigned) k; e; e >>= 1) {
+        if (e & 1u) { m = pm * m; a = pm * a + pa; }
+        pa = pm * pa + pa;
+        pm = pm * pm;
+    }
+    const unsigned rn0 = (unsigned) state[0].rn;       /* entry 0 is never written here */
+    if (k > 0) state[k].rn = (int) (m * rn0 + a);
+}
+
+/* init_k = (k ? guess[k-1] : first); also remembers nothing else */
+__global__ void k_seq_load(int n_fields, crthip_state *state, const int2 *guess, int2 first)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fields) return;
+    const int2 v = k ? guess[k - 1] : first;
+    state[k].hsync = v.x;
+    state[k].vsync = v.y;
+}
+
+/* guess <- finals; *changed |= any difference */
+__global__ void k_seq_compare(int n_fields, const crthip_state *state, int2 *guess, int *changed)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_fields) return;
+    const int2 f = make_int2(state[k].hsync, state[k].vsync);
+    const int2 g = guess[k];
+    if (f.x != g.x || f.y != g.y) {
+        guess[k] = f;
+        atomicOr(changed, 1);
+    }
+}
+
+/* rows written by field k (crt_core.c:552,661-664) -> owner[k][row] = 1 */
+__global__ void k_seq_rows(int n_fields, int lines_per_field, int outh, const crthip_line *lines, unsigned char *owner)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_fields * lines_per_field) return;
+    const int k = gid / lines_per_field;
+    const crthip_line lp = lines[gid];
+    const int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    for (int r = 0; r < nrows; r++) {
+        if (lp.beg + r < outh) owner[(size_t) k * outh + lp.beg + r] = 1;
+    }
+}
+
+/* latest[k][row] = last field <= k that wrote the row, -1 = none (serial in k, one lane per row) */
+__global__ void k_seq_latest(int n_fields, int outh, const unsigned char *owner, int *latest)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= outh) return;
+    int last = -1;
+    for (int k = 0; k < n_fields; k++) {
+        if (owner[(size_t) k * outh + r]) last = k;
+        latest[(size_t) k * outh + r] = last;
+    }
+}
+
+/* rows of image k that field k did not write <- the same row of image latest[k][row] (or the initial image) */
+__global__ void __launch_bounds__(256)
+k_seq_weave(int n_fields, int outh, size_t pitch, unsigned char *out, size_t ostride, const unsigned char *init,
+            const int *latest)
+{
+    const int row = blockIdx.x % outh, k = blockIdx.x / outh;
+    if (k >= n_fields) return;
+    const int src_k = latest[(size_t) k * outh + row];
+    if (src_k == k) return;
+    unsigned char *dst = out + (size_t) k * ostride + (size_t) row * pitch;
+    const unsigned char *src = src_k >= 0 ? out + (size_t) src_k * ostride + (size_t) row * pitch
+                                          : (init ? init + (size_t) row * pitch : nullptr);
+    for (size_t b = (size_t) threadIdx.x * 16; b < pitch; b += 256 * 16) {
+        const size_t nb = pitch - b < 16 ? pitch - b : 16;
+        if (nb == 16) {
+            v4i v = { 0, 0, 0, 0 };
+            if (src) v = load16u(src + b);
+            store16u(dst + b, v);
+        } else {
+            for (size_t c = 0; c < nb; c++) dst[b + c] = src ? src[b + c] : (unsigned char) 0;
+        }
+    }
+}
+
+extern "C" {
+
+int crthip_abi_version(void) { return CRTHIP_ABI_VERSION; }
+
+int crthip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
+{
+    if (!out) return CRTHIP_E_ARG;
+    *out = 0;
+    struct crt_sysdef sd;
+    if (crt_sysdef_get(&sd, system, chroma_pattern) != CRTHIP_OK) return CRTHIP_E_ARG;
+    if (dispatch_system(system, chroma_pattern, [&](auto tag) {
+            return sysdef_matches<decltype(tag)>(sd) ? CRTHIP_OK : CRTHIP_E_ARG; }) != CRTHIP_OK) {
+        fprintf(stderr, "crthip: host/device system tables disagree (system %d pattern %d)\n", system, chroma_pattern);
+        return CRTHIP_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CRTHIP_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CRTHIP_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "crthip: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return CRTHIP_E_NODEVICE;
+    }
+    crthip_ctx *c = new (std::nothrow) crthip_ctx();
+    if (!c) return CRTHIP_E_NOMEM;
+    memset(c, 0, sizeof(*c));
+    c->device = device; c->system = system; c->pattern = chroma_pattern; c->sd = sd;
+    c->fstride = crthip_field_stride(system, chroma_pattern);
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return CRTHIP_E_HIP;
+    }
+    c->stream = 0;              /* the device's default stream until crthip_set_stream() */
+    c->overlap_chunks = 1;
+    c->own_stream = false;
+    /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
+    const int nq = sd.input_size / 16 + 2;
+    uint2 *h = (uint2 *) malloc(sizeof(uint2) * (size_t) nq);
+    if (!h) { crthip_destroy(c); return CRTHIP_E_NOMEM; }
+    unsigned m16, a16;
+    lcg_jump_host(16, &m16, &a16);
+    h[0].x = 1u; h[0].y = 0u;
+    for (int q = 1; q < nq; q++) { h[q].x = m16 * h[q - 1].x; h[q].y = m16 * h[q - 1].y + a16; }
+    lcg_jump_host((unsigned) sd.input_size, &c->whole_field.x, &c->whole_field.y);
+    if (hipMalloc((void **) &c->d_jump16, sizeof(uint2) * (size_t) nq) != hipSuccess ||
+        hipMemcpy(c->d_jump16, h, sizeof(uint2) * (size_t) nq, hipMemcpyHostToDevice) != hipSuccess) {
+        free(h);
+        crthip_destroy(c);
+        return CRTHIP_E_HIP;
+    }
+    free(h);
+    if (system == CRTHIP_SYSTEM_NES && hipMalloc((void **) &c->d_nes_tab, NES_TAB_SIZE) != hipSuccess) {
+        crthip_destroy(c);
+        return CRTHIP_E_NOMEM;
+    }
+    {
+        uint2 j1[16];
+        j1[0] = make_uint2(1u, 0u);
+        for (int k = 1; k < 16; k++) j1[k] = make_uint2(LCG_MUL * j1[k - 1].x, LCG_MUL * j1[k - 1].y + LCG_ADD);
+        if (hipMalloc((void **) &c->d_skel, (size_t) SKEL_VARIANTS * c->fstride) != hipSuccess ||
+            hipMalloc((void **) &c->d_jump1, sizeof(j1)) != hipSuccess ||
+            hipMemcpy(c->d_jump1, j1, sizeof(j1), hipMemcpyHostToDevice) != hipSuccess) {
+            crthip_destroy(c);
+            return CRTHIP_E_NOMEM;
+        }
+    }
+    if (system == CRTHIP_SYSTEM_NTSCVHS) {
+        /* jump coefficients of the rand() recurrence: one row per parallel chunk, one for the first call of
+         * the tail, and the tail's 64 block offsets (transposed: [m][block]) */
+        const int chunks = vhs_tail_start(sd.input_size, sd.hres) / VHS_CHUNK;
+        const size_t words = 31 * (size_t) (chunks + 1) + 31 * 64;
+        unsigned *rows = (unsigned *) malloc(sizeof(unsigned) * words);
+        if (!rows) { crthip_destroy(c); return CRTHIP_E_NOMEM; }
+        crt_setup_vhs_power_table(1ul, 2ul * VHS_CHUNK, chunks, rows);
+        crt_setup_vhs_power(1ul + 2ul * (unsigned long) chunks * VHS_CHUNK, rows + 31 * (size_t) chunks);
+        {
+            unsigned blk[31 * 64];
+            unsigned *t = rows + 31 * (size_t) (chunks + 1);
+            crt_setup_vhs_power_table(0ul, (unsigned long) VHS_BLK, 64, blk);
+            for (int b = 0; b < 64; b++) {
+                for (int m = 0; m < 31; m++) t[m * 64 + b] = blk[b * 31 + m];
+            }
+        }
+        c->vhs_chunks = chunks;
+        if (hipMalloc((void **) &c->d_vhs_rows, sizeof(unsigned) * words) != hipSuccess ||
+            hipMemcpy(c->d_vhs_rows, rows, sizeof(unsigned) * words, hipMemcpyHostToDevice) != hipSuccess) {
+            free(rows);
+            crthip_destroy(c);
+            return CRTHIP_E_HIP;
+        }
+        free(rows);
+    }
+    *out = c;
+    return CRTHIP_OK;
+}
+
+void crthip_destroy(crthip_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->npend; i++) { hipEventDestroy(c->pend[i].a); hipEventDestroy(c->pend[i].b); }
+    free(c->pend);
+    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
+    if (c->d_jump16) hipFree(c->d_jump16);
+    if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
+    if (c->d_seq) hipFree(c->d_seq);
+    if (c->d_nes_tab) hipFree(c->d_nes_tab);
+    if (c->d_skel) hipFree(c->d_skel);
+    if (c->d_jump1) hipFree(c->d_jump1);
+    if (c->d_analog) hipFree(c->d_analog);
+    if (c->d_inp) hipFree(c->d_inp);
+    if (c->d_lines) hipFree(c->d_lines);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int crthip_set_stream(crthip_ctx *c, void *hip_stream)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t) hip_stream;       /* NULL = the default stream */
+    return CRTHIP_OK;
+}
+
+int crthip_synchronize(crthip_ctx *c)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRTHIP_OK;
+}
+
+const char *crthip_error_string(const crthip_ctx *c) { return c ? c->err : "null context"; }
+
+int crthip_reserve(crthip_ctx *c, int n)
+{
+    if (!c || n <= 0) return CRTHIP_E_ARG;
+    if (n <= c->cap_fields) return CRTHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_analog) hipFree(c->d_analog);
+    if (c->d_inp) hipFree(c->d_inp);
+    if (c->d_lines) hipFree(c->d_lines);
+    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->cap_fields = 0;
+    const size_t bytes = c->fstride * (size_t) n + 4096;
+    if (hipMalloc((void **) &c->d_inp, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc inp", hipSuccess);
+    if (hipMalloc((void **) &c->d_analog, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc analog", hipSuccess);
+    if (hipMalloc((void **) &c->d_lines, sizeof(crthip_line) * (size_t) n * c->sd.lines) != hipSuccess)
+        return set_err(c, CRTHIP_E_NOMEM, "hipMalloc lines", hipSuccess);
+    HIPCHK(c, hipMemsetAsync(c->d_inp, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_analog, 0, bytes, c->stream));
+    c->cap_fields = n;
+    return CRTHIP_OK;
+}
+
+static int check_params(crthip_ctx *c, const crthip_params *p, int n)
+{
+    if (!c || !p || n <= 0) return CRTHIP_E_ARG;
+    if (p->finalized != CRTHIP_PARAMS_MAGIC) return set_err(c, CRTHIP_E_ARG, "params not finalized", hipSuccess);
+    if (p->system != c->system || p->chroma_pattern != c->pattern) return set_err(c, CRTHIP_E_ARG, "params are for another system", hipSuccess);
+    return CRTHIP_OK;
+}
+
+/* the encoder contract: the active rectangle lies inside the field (the reference would
+ * scribble over neighbouring lines / out of bounds otherwise, crt_ntsc.c:322) */
+static int check_encoder(crthip_ctx *c, const crthip_params *p)
+{
+    if (c->system != CRTHIP_SYSTEM_NES && p->in_bpp == 0) return 1;   /* silent no-op, crt_ntsc.c:190-193 */
+    if (p->xo < 0 || p->yo < 0 || p->xo + p->destw > c->sd.hres || p->yo + p->desth > c->sd.vres || p->destw <= 0 || p->desth <= 0)
+        return set_err(c, CRTHIP_E_ARG, "active rectangle leaves the field (xoffset/yoffset out of contract)", hipSuccess);
+    return CRTHIP_OK;
+}
+
+int crthip_modulate(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    signed char *d_analog, crthip_state *d_state)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    rc = check_encoder(c, p);
+    if (rc) return rc < 0 ? rc : CRTHIP_OK;
+    if (!d_images || !d_analog || !d_state) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = crt_run_encoder(c, p, n, d_images, istride, d_analog, d_state, false, (p->flags & CRTHIP_F_NES_SETUP) != 0, true);
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+int crthip_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
+                 crthip_state *d_state)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (p->out_bpp == 0) return CRTHIP_OK;                       /* crt_core.c:312-315 */
+    if (!d_analog || !d_inp || !d_state) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = crt_run_noise(c, p, n, d_analog, d_inp, d_state, true);
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+int crthip_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
+                crthip_line *d_lines)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (p->out_bpp == 0) return CRTHIP_OK;
+    if (!d_inp || !d_state || !d_lines) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = crt_run_sync(c, p, n, d_inp, d_state, d_lines, 0);
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+int crthip_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, const crthip_line *d_lines,
+                  void *d_out, size_t ostride)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (p->out_bpp == 0) return CRTHIP_OK;
+    if (!d_inp || !d_lines || !d_out) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = crt_run_decode(c, p, n, d_inp, d_lines, d_out, ostride);
+    HIPCHK(c, hipGetLastError());
+    return rc;
+}
+
+/* one chunk of a batch: fields [first, first+n) on the context's current stream */
+static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n,
+                           const void *d_images, size_t istride, void *d_out, size_t ostride, crthip_state *d_state)
+{
+    const unsigned char *img = (const unsigned char *) d_images + (size_t) first * istride;
+    unsigned char *out = (unsigned char *) d_out + (size_t) first * ostride;
+    crthip_state *st = d_state + first;
+    signed char *inp = c->d_inp + (size_t) first * c->fstride;
+    signed char *analog = c->d_analog + (size_t) first * c->fstride;
+    crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+        /* VHS noise follows the C library's rand() stream, not the LCG: the fused encoder (margins + active
+         * rectangle = every sample of the field) runs with noise 0 into analog[], then the dedicated noise
+         * kernels (which also produce rn) */
+        int r = CRTHIP_OK;
+        if (enc == 0) {
+            crthip_params clean = *p;
+            clean.noise = 0;
+            r = crt_run_encoder(c, &clean, n, img, istride, analog, st, true, 1, true);
+        } else {
+            hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);   /* crt_modulate refused the format */
+        }
+        if (r) return r;
+        if (p->out_bpp == 0) return CRTHIP_OK;
+        unsigned *saved = c->d_vhs_hist;
+        c->d_vhs_hist = saved + (size_t) first * 32;
+        r = crthip_noise(c, p, n, analog, inp, st);
+        c->d_vhs_hist = saved;
+        if (r) return r;
+        r = crt_run_sync(c, p, n, inp, st, ln, 0);
+        if (r) return r;
+        return crt_run_decode(c, p, n, inp, ln, out, ostride);
+    }
+    int rc;
+    if (enc == 0) {
+        /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
+        rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, true);
+    } else {
+        /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise
+         * (rn is advanced by k_vsync below) */
+        hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
+        rc = crt_run_noise(c, p, n, analog, inp, st, false);
+    }
+    if (rc) return rc;
+    if (p->out_bpp != 0) {
+        rc = crt_run_sync(c, p, n, inp, st, ln, 1);
+        if (rc) return rc;
+        rc = crt_run_decode(c, p, n, inp, ln, out, ostride);
+        if (rc) return rc;
+    }
+    return CRTHIP_OK;
+}
+
+int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                     void *d_out, size_t ostride, crthip_state *d_state)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !c->d_vhs_hist)
+        return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
+    int enc = check_encoder(c, p);
+    if (enc < 0) return enc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->cap_fields) {
+        rc = crthip_reserve(c, n);
+        if (rc) return rc;
+    }
+    /* Fields are independent, so a large batch is cut into chunks that alternate between the
+     * caller's stream and an internal one: the latency-bound kernels of one chunk (sync chain,
+     * margins, launch gaps) then overlap the VALU-bound kernels of the other.  The internal stream
+     * is fenced by events on both sides, so to the caller everything is still ordered on ITS stream. */
+    const int nchunks = (c->overlap_chunks > 1 && n >= 256 * c->overlap_chunks && !c->prof) ? c->overlap_chunks : 1;
+    if (nchunks == 1) {
+        rc = fieldpass_chunk(c, p, enc, 0, n, d_images, istride, d_out, ostride, d_state);
+    } else {
+        if (!c->aux_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        hipStream_t main_stream = c->stream;
+        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        const int per = ((n + nchunks - 1) / nchunks + 3) & ~3;
+        for (int k = 0, first = 0; first < n && rc == CRTHIP_OK; k++, first += per) {
+            const int cnt = n - first < per ? n - first : per;
+            c->stream = (k & 1) ? c->aux_stream : main_stream;
+            rc = fieldpass_chunk(c, p, enc, first, cnt, d_images, istride, d_out, ostride, d_state);
+        }
+        c->stream = main_stream;
+        HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+    }
+    if (rc) return rc;
+    HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_pixel_tile(crthip_ctx *c, int px)
+{
+    if (!c || (px != 0 && px != 16 && px != 32)) return CRTHIP_E_ARG;
+    c->px_tile = px;
+    c->ac_tile = px;
+    return CRTHIP_OK;
+}
+
+int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    void *d_out, size_t ostride, const void *d_out_init, crthip_state *d_state, int *passes_out)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS)
+        return set_err(c, CRTHIP_E_ARG, "sequence mode: the VHS rand() stream is a chain over fields, use crthip_fieldpass per field", hipSuccess);
+    if (p->blend) return set_err(c, CRTHIP_E_ARG, "sequence mode needs blend == 0 (blend is a recurrence over fields)", hipSuccess);
+    if (p->out_bpp == 0) return CRTHIP_OK;
+    int enc = check_encoder(c, p);
+    if (enc != 0) return enc < 0 ? enc : set_err(c, CRTHIP_E_ARG, "sequence mode: unknown input pixel format", hipSuccess);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->cap_fields) {
+        rc = crthip_reserve(c, n);
+        if (rc) return rc;
+    }
+    const int outh = p->outh;
+    const size_t pitch = (size_t) p->outw * p->out_bpp;
+    /* scratch: guess[n] (int2), changed flag, owner[n][outh] (u8), latest[n][outh] (int) */
+    const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh;
+    if (need > c->seq_cap) {
+        if (c->d_seq) hipFree(c->d_seq);
+        c->d_seq = 0; c->seq_cap = 0;
+        if (hipMalloc((void **) &c->d_seq, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sequence scratch", hipSuccess);
+        c->seq_cap = need;
+    }
+    int2 *guess = (int2 *) c->d_seq;
+    int *changed = (int *) (c->d_seq + sizeof(int2) * (size_t) n);
+    unsigned char *owner = c->d_seq + sizeof(int2) * (size_t) n + 256;
+    int *latest = (int *) (owner + (((size_t) n * outh + 255) & ~(size_t) 255));
+    const dim3 gn((n + 63) / 64), b64(64);
+
+    crthip_state first;
+    HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_seq_rn, gn, b64, 0, c->stream, n, d_state, c->whole_field);
+    /* encode every field (noise fused), ccf presets */
+    rc = crt_run_encoder(c, p, n, d_images, istride, c->d_inp, d_state, true, 1, false);
+    if (rc) return rc;
+    /* first guess: nobody's sync state moves */
+    {
+        int2 *h = (int2 *) malloc(sizeof(int2) * (size_t) n);
+        if (!h) return CRTHIP_E_NOMEM;
+        for (int k = 0; k < n; k++) h[k] = make_int2(first.hsync, first.vsync);
+        hipError_t e = hipMemcpyAsync(guess, h, sizeof(int2) * (size_t) n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        free(h);
+        HIPCHK(c, e);
+    }
+    int passes = 0;
+    for (;;) {
+        passes++;
+        HIPCHK(c, hipMemsetAsync(changed, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_seq_load, gn, b64, 0, c->stream, n, d_state, guess, make_int2(first.hsync, first.vsync));
+        rc = crt_run_encoder_state(c, p, n, d_state);                 /* ccf preset, crt_ntsc.c:325-329 */
+        if (rc) return rc;
+        rc = crt_run_sync(c, p, n, c->d_inp, d_state, c->d_lines, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_seq_compare, gn, b64, 0, c->stream, n, d_state, guess, changed);
+        int flag = 0;
+        HIPCHK(c, hipMemcpyAsync(&flag, changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!flag || passes > n + 1) break;
+    }
+    if (passes_out) *passes_out = passes;
+    /* rn after each field, decode, weave */
+    crt_run_advance_rn(c, n, d_state);
+    rc = crt_run_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(owner, 0, (size_t) n * outh, c->stream));
+    hipLaunchKernelGGL(k_seq_rows, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, owner);
+    hipLaunchKernelGGL(k_seq_latest, dim3((outh + 63) / 64), b64, 0, c->stream, n, outh, owner, latest);
+    hipLaunchKernelGGL(k_seq_weave, dim3((unsigned) n * (unsigned) outh), dim3(256), 0, c->stream, n, outh, pitch,
+                       (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, latest);
+    HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_overlap(crthip_ctx *c, int chunks)
+{
+    if (!c || chunks < 1 || chunks > 64) return CRTHIP_E_ARG;
+    c->overlap_chunks = chunks;
+    return CRTHIP_OK;
+}
+
+int crthip_vhs_bind_history(crthip_ctx *c, unsigned *d_hist)
+{
+    if (!c || c->system != CRTHIP_SYSTEM_NTSCVHS) return CRTHIP_E_ARG;
+    c->d_vhs_hist = d_hist;
+    return CRTHIP_OK;
+}
+
+int crthip_set_exact(crthip_ctx *c, int on)
+{
+    if (!c) return CRTHIP_E_ARG;
+    c->force_exact = on == 1;
+    c->no_tier0 = on == 2;      /* 2: allow the 24-bit tier but not the 64-bit-mad ones */
+    c->no_loskip = on == 3;     /* 3: allow the 64-bit-mad tier but keep the I/Q low cascades */
+    return CRTHIP_OK;
+}
+
+int crthip_profile_enable(crthip_ctx *c, int on)
+{
+    if (!c) return CRTHIP_E_ARG;
+    c->prof = on != 0;
+    return CRTHIP_OK;
+}
+
+int crthip_profile_read(crthip_ctx *c, double total_ms[CRTHIP_K_COUNT], int launches[CRTHIP_K_COUNT])
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->npend; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->pend[i].a, c->pend[i].b) == hipSuccess) {
+            c->prof_ms[c->pend[i].k] += ms;
+            c->prof_n[c->pend[i].k]++;
+        }
+        hipEventDestroy(c->pend[i].a);
+        hipEventDestroy(c->pend[i].b);
+    }
+    c->npend = 0;
+    for (int k = 0; k < CRTHIP_K_COUNT; k++) {
+        if (total_ms) total_ms[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_n[k];
+        c->prof_ms[k] = 0.0;
+        c->prof_n[k] = 0;
+    }
+    return CRTHIP_OK;
+}
+
+void *crthip_malloc(crthip_ctx *c, size_t bytes)
+{
+    void *p = 0;
+    if (!c || hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return 0;
+    return p;
+}
+
+void crthip_free(crthip_ctx *c, void *d)
+{
+    if (c && d) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); hipFree(d); }
+}
+
+int crthip_upload(crthip_ctx *c, void *d, const void *h, size_t bytes)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRTHIP_OK;
+}
+
+int crthip_download(crthip_ctx *c, void *h, const void *d, size_t bytes)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRTHIP_OK;
+}
+
+int crthip_memset(crthip_ctx *c, void *d, int value, size_t bytes)
+{
+    if (!c) return CRTHIP_E_ARG;
+    HIPCHK(c, hipMemsetAsync(d, value, bytes, c->stream));
+    return CRTHIP_OK;
+}
+
+}  /* extern "C" */

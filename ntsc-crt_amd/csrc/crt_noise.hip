@@ -1,0 +1,389 @@
+/* crt_noise.hip -- D1, the noisy channel: LCG noise and the VHS build's libc rand() stream.  See crt_dev.h. */
+#include "crt_dev.h"
+
+/* ------------------------------------------------------------------------- */
+/* D1: channel noise (elementwise, 16 samples per lane)                        */
+/* ------------------------------------------------------------------------- */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+        signed char *__restrict__ inp, size_t fstride, const crthip_state *__restrict__ state,
+        const uint2 *__restrict__ jump16)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_fields * CHUNKS) return;
+    const int f = gid / CHUNKS;
+    const int q = gid - f * CHUNKS;
+    const signed char *src = analog + (size_t) f * fstride + q * 16;
+    signed char *dst = inp + (size_t) f * fstride + q * 16;
+    const uint2 j = jump16[q];
+    unsigned rn = j.x * (unsigned) state[f].rn + j.y;
+    const v4i in = load16u(src);
+    const int wds[4] = { in.x, in.y, in.z, in.w };
+    int outw[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        unsigned o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int s = (wds[d] << (24 - 8 * k)) >> 24;
+            rn = lcg_step(rn);
+            o |= (unsigned) (noisy(s, rn, P.noise) & 255) << (8 * k);
+        }
+        outw[d] = (int) o;
+    }
+    if (q * 16 + 16 <= S::INPUT_SIZE) {
+        v4i o4; o4.x = outw[0]; o4.y = outw[1]; o4.z = outw[2]; o4.w = outw[3];
+        store16u(dst, o4);
+    } else {
+        for (int k = 0; q * 16 + k < S::INPUT_SIZE; k++) dst[k] = (signed char) (outw[k >> 2] >> (8 * (k & 3)));
+    }
+    if (q == 0) {
+        signed char *tail = inp + (size_t) f * fstride + S::INPUT_SIZE;
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* D1, VHS flavour: noise from the C library's rand() stream                   */
+/* ------------------------------------------------------------------------- */
+/*
+ * crt_core.c:343-357.  rand() is modelled as glibc's y[n] = y[n-31] + y[n-3] (crt_setup.c).  Calls:
+ * #0 picks the band's phase (`line`); sample i then makes call A_i (its noise value) and call B_i
+ * (always), plus call C_i only when the first half of the && is true:
+ *     c1(i, B) = i > INPUT_SIZE - HRES*(6 + B%20)   <=>   6 + B%20 > floor((INPUT_SIZE - i) / HRES)
+ * which can only happen for i > I0 = INPUT_SIZE - 25*HRES.  So
+ *   - samples [0, T0), T0 = a multiple of VHS_CHUNK just below I0, use calls 1+2i, 2+2i: k_vhs_noise,
+ *     PARALLEL, one lane per VHS_CHUNK samples; the lane's 31-value history at its first call K comes
+ *     from the field's base history by the jump  y[K+j] = sum_m c_K[m] * y[m+j]
+ *     (c_K = x^K mod x^31-x^28-1, host-made table `rows`);
+ *   - samples [T0, INPUT_SIZE) have a data-dependent call count: k_vhs_tail, one wave per field,
+ *     speculative block walk (see there); it hands back the final history and rn.
+ */
+__device__ __forceinline__ int dev_sine_q1(int a)
+{
+    /* crt_core.c:19-39 */
+    const int knots[18] = { 0, 3208, 6392, 9512, 12536, 15440, 18200, 20784, 23168,
+                            25328, 27240, 28896, 30272, 31352, 32136, 32608, 32768, 32608 };
+    const int k = (a >> 8) & 255, t = a & 255;
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < 17; q++) {
+        if (k == q) { lo = knots[q]; hi = knots[q + 1]; }
+    }
+    return lo + (((hi - lo) * t) >> 8);
+}
+/* cosine only (crt_core.c:42-61), 14-bit angle */
+__device__ __forceinline__ int dev_cos14(int n)
+{
+    n &= 16383;
+    const int a = n & 8191;
+    int cs = a < 4096 ? dev_sine_q1(4096 - a) : -dev_sine_q1(a - 4096);
+    if (n & 8192) cs = -cs;
+    return cs;
+}
+
+/* Parallel region.  A wave's 64 chunks are (mostly) one contiguous 15872-byte run of the field: it is moved
+ * through an LDS tile of 64 x 62 dwords with coalesced 256-byte requests (lane-per-chunk byte accesses cost
+ * 12x the algorithmic HBM write traffic); the lane's own dwords sit at an odd stride = conflict-free. */
+template <class S>
+__global__ void __launch_bounds__(64)
+k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+            signed char *__restrict__ inp, size_t fstride,
+            const unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a)
+{
+    constexpr int DW = VHS_CHUNK / 4;                            /* dwords per chunk */
+    constexpr int DWS = DW | 1;                                  /* odd LDS stride: conflict-free lane-per-chunk access */
+    static_assert((2 * VHS_CHUNK) % 31 == 0 && VHS_CHUNK % 4 == 0, "static ring index / dword packing");
+    __shared__ unsigned s_t[64 * DWS];
+    __shared__ unsigned long long s_off[64];
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * 64 + lane;
+    const bool live = gid < n_fields * chunks_a;
+    const int f = live ? gid / chunks_a : 0;
+    const int q = live ? gid - f * chunks_a : 0;
+    s_off[lane] = live ? (unsigned long long) f * fstride + (unsigned long long) q * VHS_CHUNK : ~0ull;
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < DW; it++) {
+        const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
+        const unsigned long long off = s_off[owner];
+        s_t[owner * DWS + d] = off != ~0ull ? *(const unsigned *) (analog + off + 4 * d) : 0u;
+    }
+    const unsigned *h = hist + (size_t) f * 32;
+    /* base sequence z[0..60]: the history and the next 30 values */
+    unsigned z[61];
+#pragma unroll
+    for (int j = 0; j < 31; j++) z[j] = h[j];
+#pragma unroll
+    for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
+    /* history of call K = 1 + 2 * VHS_CHUNK * q */
+    const unsigned *c = rows + (size_t) q * 31;
+    unsigned w[31];
+#pragma unroll
+    for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+    for (int m = 0; m < 31; m++) {
+        const unsigned cm = c[m];
+#pragma unroll
+        for (int j = 0; j < 31; j++) w[j] += cm * z[m + j];
+    }
+    const int noise = P.noise;
+    __syncthreads();
+    /* 2 calls per sample; ring index = call % 31 is static */
+    unsigned *mine = s_t + lane * DWS;
+    unsigned in4 = 0, out4 = 0;
+#pragma unroll
+    for (int t = 0; t < 2 * VHS_CHUNK; t++) {
+        const unsigned v = w[t % 31] + w[(t + 28) % 31];
+        w[t % 31] = v;
+        if ((t & 1) == 0) {                                      /* call A of sample t/2 */
+            const int k = t / 2;
+            if ((k & 3) == 0) in4 = mine[k >> 2];
+            const int rn = (int) (v >> 1);
+            const int a = (int) (in4 << (24 - 8 * (k & 3))) >> 24;
+            const int sv = clampi(a + ((((rn >> 16) & 0xff) - 0x7f) * noise >> 8), -127, 127);
+            out4 = (k & 3) == 0 ? (unsigned) (sv & 255) : out4 | (unsigned) (sv & 255) << (8 * (k & 3));
+            if ((k & 3) == 3) mine[k >> 2] = out4;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < DW; it++) {
+        const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
+        const unsigned long long off = s_off[owner];
+        if (off != ~0ull) *(unsigned *) (inp + off + 4 * d) = s_t[owner * DWS + d];
+    }
+}
+
+/*
+ * The tail: samples [T0, INPUT_SIZE), ONE WAVE PER FIELD.  Sample i starts at call position pos_i and
+ * pos_{i+1} = pos_i + 2 + c1(i, call[pos_i + 1]) -- a serial chain, but c1 depends on i only through
+ * k = floor((INPUT_SIZE - i) / HRES), constant over a SEGMENT of at most HRES samples.  Per segment:
+ *   1. the next 64*43 calls (more than a segment can consume) are generated in parallel: lane b jumps
+ *      to call 43*b of the window (x^(43b), 961 multiply-adds) and produces its block of 43 -> LDS;
+ *   2. every lane walks its own block for each of the three possible entry offsets (the first call of
+ *      a sample inside a block is its call 0, 1 or 2) -> exit offset + sample count;
+ *   3. the 64 results are chained on the scalar unit (v_readlane), giving each block its
+ *      real entry offset and the index of its first sample;
+ *   4. every lane walks its block once more, now producing samples (through LDS byte staging); the
+ *      lane that meets the segment's last sample publishes the next window's start and `rn`.
+ */
+template <class S>
+__global__ void __launch_bounds__(64)
+k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
+           signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
+           unsigned *__restrict__ hist, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows)
+{
+    constexpr int N = S::INPUT_SIZE, H = S::HRES, B = VHS_BLK;
+    constexpr int T0 = vhs_tail_start(N, H);
+    constexpr int NB = (H + 63) / 64;                              /* bytes per lane and segment */
+    static_assert(64 * B >= 3 * H + 3, "window too small for a segment");
+    __shared__ unsigned s_y[64 * B + 8];                           /* the window's raw generator values */
+    __shared__ unsigned s_h[64];                                   /* 31-value history in front of the window; base sequence */
+    __shared__ unsigned s_misc[2];
+    __shared__ signed char s_a[NB * 64], s_o[NB * 64];
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (f >= n_fields) return;
+    unsigned *h = hist + (size_t) f * 32;
+    const signed char *src = analog + (size_t) f * fstride;
+    signed char *dst = inp + (size_t) f * fstride;
+    const int noise = P.noise;
+
+    /* the field's base sequence -> the history in front of call 1 + 2*T0 (lane j computes element j) */
+    int vhs_line;
+    {
+        unsigned zf[61];
+#pragma unroll
+        for (int j = 0; j < 31; j++) zf[j] = h[j];
+#pragma unroll
+        for (int j = 31; j < 61; j++) zf[j] = zf[j - 31] + zf[j - 3];
+        vhs_line = (int) ((zf[31] >> 1) & 7u) - 4 + 14;            /* call #0, crt_core.c:344 */
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 61; j++) s_y[j] = zf[j];
+        }
+        __syncthreads();
+        unsigned acc = 0;
+        const int j = lane < 31 ? lane : 0;
+        for (int m = 0; m < 31; m++) acc += tail_row[m] * s_y[m + j];
+        __syncthreads();
+        if (lane < 31) s_h[lane] = acc;
+    }
+    unsigned cb[31];                                               /* x^(43*lane) */
+#pragma unroll
+    for (int m = 0; m < 31; m++) cb[m] = blk_rows[m * 64 + lane];
+    __syncthreads();
+
+    int seg_start = T0;
+    while (seg_start < N) {
+        const int kseg = (N - seg_start) / H;
+        int seg_end = N - H * kseg;                                /* last sample with floor((N - i) / H) == kseg */
+        if (seg_end > N - 1) seg_end = N - 1;
+        const int n_s = seg_end - seg_start + 1;
+
+        int abytes[NB];
+#pragma unroll
+        for (int r = 0; r < NB; r++) {
+            const int idx = r * 64 + lane;
+            abytes[r] = idx < n_s ? src[seg_start + idx] : 0;
+        }
+
+        /* 1. my block of the window */
+        unsigned z[61];
+#pragma unroll
+        for (int j = 0; j < 31; j++) z[j] = s_h[j];
+#pragma unroll
+        for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
+        unsigned w[31];
+#pragma unroll
+        for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+        for (int m = 0; m < 31; m++) {
+#pragma unroll
+            for (int j = 0; j < 31; j++) w[j] += cb[m] * z[m + j];
+        }
+        unsigned glo = 0, ghi = 0;                                 /* c1 flags of my 43 calls (as B calls of this segment) */
+#pragma unroll
+        for (int t = 0; t < B; t++) {
+            const unsigned v = w[t % 31] + w[(t + 28) % 31];
+            w[t % 31] = v;
+            s_y[lane * B + t] = v;
+            const unsigned flag = (6 + (int) ((v >> 1) % 20u) > kseg) ? 1u : 0u;
+            if (t < 32) glo |= flag << t; else ghi |= flag << (t - 32);
+        }
+        {
+            const unsigned nb = (unsigned) __shfl_down((int) (glo & 1u), 1);   /* call 43 = the next block's call 0 */
+            if (lane < 63) ghi |= nb << (B - 32);
+        }
+#pragma unroll
+        for (int r = 0; r < NB; r++) s_a[r * 64 + lane] = (signed char) abytes[r];
+        const unsigned long long G = ((unsigned long long) ghi << 32) | glo;
+
+        /* 2. speculative walks: entry offset e -> (samples, exit offset) */
+        unsigned res = 0;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            int pos = e, cnt = 0;
+#pragma unroll
+            for (int it = 0; it < (B + 1) / 2; it++) {
+                const bool in = pos < B;
+                const int step = 2 + (int) ((G >> (pos + 1)) & 1ull);
+                pos += in ? step : 0;
+                cnt += in ? 1 : 0;
+            }
+            res |= (unsigned) (cnt | (pos - B) << 5) << (8 * e);
+        }
+
+        /* 3. chain the blocks */
+        int e_in = 0, first = n_s;
+        {
+            int e = 0, cum = 0;
+            for (int b = 0; b < 64 && cum < n_s; b++) {
+                const unsigned r = (unsigned) __builtin_amdgcn_readlane((int) res, b) >> (8 * e);
+                if (lane == b) { e_in = e; first = cum; }
+                cum += (int) (r & 31u);
+                e = (int) ((r >> 5) & 3u);
+            }
+        }
+        __syncthreads();
+
+        /* 4. samples (crt_core.c:347-365) */
+        {
+            int pos = e_in;
+            for (int k = 0; k < (B + 1) / 2; k++) {
+                const int s = first + k;
+                const bool valid = pos < B && s < n_s;
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break;
+                if (valid) {
+                    const unsigned *yp = s_y + lane * B + pos;
+                    const unsigned rnv = yp[0] >> 1, r2 = yp[1] >> 1;
+                    const int i = seg_start + s;
+                    const int c1 = 6 + (int) (r2 % 20u) > kseg ? 1 : 0;
+                    int nn = noise;
+                    if (c1) {
+                        const unsigned r3 = yp[2] >> 1;
+                        if (i < N - H * (5 + ((int) (r3 & 7u) - 4))) {
+                            const int ln = (i * vhs_line) / H;
+                            nn = dev_cos14(ln * 8192 / 180) >> 8;
+                        }
+                    }
+                    const int sv = (int) s_a[s] + (((int) ((rnv >> 16) & 0xffu) - 0x7f) * nn >> 8);
+                    s_o[s] = (signed char) clampi(sv, -127, 127);
+                    pos += 2 + c1;
+                    if (s == n_s - 1) { s_misc[0] = (unsigned) (lane * B + pos); s_misc[1] = rnv; }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NB; r++) {
+            const int idx = r * 64 + lane;
+            if (idx < n_s) dst[seg_start + idx] = s_o[idx];
+        }
+        /* the next window starts at the first call after this segment's last sample */
+        const int pos_end = (int) s_misc[0];
+        unsigned hv = 0;
+        if (lane < 31) hv = s_y[pos_end - 31 + lane];
+        __syncthreads();
+        if (lane < 31) s_h[lane] = hv;
+        __syncthreads();
+        seg_start += n_s;
+    }
+    if (lane < 31) h[lane] = s_h[lane];                            /* the generator's state after the field */
+    if (lane == 0) {
+        state[f].rn = (int) s_misc[1];                             /* crt_core.c:367 */
+        signed char *tail = dst + N;
+        store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+    }
+}
+
+/* rn <- rn after INPUT_SIZE steps (crt_core.c:367) */
+__global__ void k_advance_rn(int n_fields, crthip_state *state, uint2 whole_field)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_fields) state[f].rn = (int) (whole_field.x * (unsigned) state[f].rn + whole_field.y);
+}
+
+
+int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state)
+{
+    hipLaunchKernelGGL(k_advance_rn, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_state, c->whole_field);
+    return CRTHIP_OK;
+}
+
+/* D1 for every field: VHS -> the rand() model (always produces rn); other systems -> LCG noise, and rn advanced
+ * by a whole field if advance_rn (the fused path lets k_vsync do that) */
+int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
+                  crthip_state *d_state, bool advance_rn)
+{
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+        if (!c->d_vhs_hist) return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
+        return dispatch_system(c->system, c->pattern, [&](auto tag) {
+            using S = decltype(tag);
+            ProfScope ps(c, CRTHIP_K_NOISE);
+            if constexpr (S::IS_VHS) {
+                /* the tail kernel rewrites the histories the parallel region reads: stream order keeps them apart */
+                hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, c->stream,
+                                   *p, n, d_analog, d_inp, c->fstride, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks);
+                hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
+                                   *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist,
+                                   c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
+            }
+            return CRTHIP_OK;
+        });
+    }
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
+        {
+            ProfScope ps(c, CRTHIP_K_NOISE);
+            hipLaunchKernelGGL((k_noise<S>), dim3((n * CHUNKS + 255) / 256), dim3(256), 0, c->stream,
+                               *p, n, d_analog, d_inp, c->fstride, d_state, c->d_jump16);
+        }
+        if (advance_rn) hipLaunchKernelGGL(k_advance_rn, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_state, c->whole_field);
+        return CRTHIP_OK;
+    });
+}
