@@ -132,8 +132,8 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * accesses are 32-bit: bank = (row + column) % 32, conflict-free for both access directions.
  * Workgroup = one wave, so __syncthreads() is only an ordering fence between the two phases.
  */
-#define IN_TILE_DW   16                    /* decoder input tile: 64 samples per row            */
-#define IN_STRIDE    (IN_TILE_DW + 1)
+/* decoder input tile: IN_TILE_DW dwords per row.  16 for narrow pictures (ALU bound: 4 waves per SIMD are
+ * enough and measured faster), 8 for wide ones (HBM-write bound: fewer VGPRs and less LDS -> 5 waves per SIMD) */
 /* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
@@ -149,6 +149,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
 {
     constexpr bool FAST = TIER <= 2;        /* tiers 0-2 use 24-bit multiplies outside the filter stages */
     constexpr bool LOSKIP = TIER == 0;
+    constexpr int IN_TILE_DW = PXT == 32 ? 8 : 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
     __shared__ unsigned s_in[64 * IN_STRIDE];
     constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
     __shared__ unsigned s_px[64 * PX_STRIDE];
@@ -202,12 +203,13 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     int px = 0;
     const int outw = P.outw;
 
-    /* cooperative input tile: piece = 16 bytes, 4 pieces per row, 16 rows per load instruction */
-    const int in_row = lane >> 2, in_piece = lane & 3;
-    v4i stage[4];
+    /* cooperative input tile: piece = 16 bytes, IN_PIECES pieces per row, 64 / IN_PIECES rows per load instruction */
+    const int in_row = lane / IN_PIECES, in_piece = lane % IN_PIECES;
+    constexpr int IN_ROWS = 64 / IN_PIECES;            /* rows covered by one load instruction */
+    v4i stage[IN_PIECES];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        stage[i] = gload16u(s_src[i * 16 + in_row] + in_piece * 16);
+    for (int i = 0; i < IN_PIECES; i++) {
+        stage[i] = gload16u(s_src[i * IN_ROWS + in_row] + in_piece * 16);
     }
     constexpr int NQ = (S::AV_LEN + 3) / 4;        /* dwords per line window; the last one may run past
                                                       AV_LEN: the filters are causal, the extra samples feed nothing */
@@ -216,15 +218,15 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
         /* stash tile t (already in registers), then start fetching tile t+1 */
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            unsigned *d = s_in + (i * 16 + in_row) * IN_STRIDE + in_piece * 4;
+        for (int i = 0; i < IN_PIECES; i++) {
+            unsigned *d = s_in + (i * IN_ROWS + in_row) * IN_STRIDE + in_piece * 4;
             d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
         }
         __syncthreads();
         if (t + 1 < NT) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                stage[i] = gload16u(s_src[i * 16 + in_row] + (t + 1) * (IN_TILE_DW * 4) + in_piece * 16);
+            for (int i = 0; i < IN_PIECES; i++) {
+                stage[i] = gload16u(s_src[i * IN_ROWS + in_row] + (t + 1) * (IN_TILE_DW * 4) + in_piece * 16);
             }
         }
         const int xq_end = (t + 1) * IN_TILE_DW < NQ ? (t + 1) * IN_TILE_DW : NQ;
