@@ -132,8 +132,8 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * accesses are 32-bit: bank = (row + column) % 32, conflict-free for both access directions.
  * Workgroup = one wave, so __syncthreads() is only an ordering fence between the two phases.
  */
-/* decoder input tile: IN_TILE_DW dwords per row.  16 for narrow pictures (ALU bound: 4 waves per SIMD are
- * enough and measured faster), 8 for wide ones (HBM-write bound: fewer VGPRs and less LDS -> 5 waves per SIMD) */
+/* decoder input tile: IN_TILE_DW dwords (64 samples) per row.  8 dwords would buy a fifth wave per SIMD (fewer
+ * VGPRs, less LDS) but measured slower for narrow and wide pictures alike (A/B on one box) */
 /* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
@@ -149,7 +149,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
 {
     constexpr bool FAST = TIER <= 2;        /* tiers 0-2 use 24-bit multiplies outside the filter stages */
     constexpr bool LOSKIP = TIER == 0;
-    constexpr int IN_TILE_DW = PXT == 32 ? 8 : 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
+    constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
     __shared__ unsigned s_in[64 * IN_STRIDE];
     constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
     __shared__ unsigned s_px[64 * PX_STRIDE];
