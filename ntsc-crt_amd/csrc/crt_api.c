@@ -192,45 +192,61 @@ monitor_params(crthip_params *p, const struct CRT *v)
     p->h = 1;
 }
 
-#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
 /*
- * The VHS decoder consumes the process's rand() stream (crt_core.c:344-351).  To stay in step with
- * the host program (video_convert.c seeds it, crt_modulate draws from it) the generator state is
- * borrowed from the C library, advanced on the GPU, and put back:
- *   setstate(scratch) returns the library's own state array; word 0 is the info word
- *   (5 * rear_index + type, refreshed by that very setstate call), words 1..31 the ring.  The ring is
- *   rewritten with the advanced history and re-installed with setstate(), which re-reads the info
- *   word.  glibc's default TYPE_3 generator only (the reference's platform); anything else aborts.
+ * The C library's rand() stream belongs to the host program (video_convert.c seeds it; the VHS build of the
+ * reference draws from it in crt_modulate and crt_demodulate, crt_core.c:344-351).  The ROCm runtime also draws
+ * from it while it initialises (seen on the first HIP call of a process: the stream came back shifted), so the
+ * program's generator is PARKED for the duration of every call into HIP:
+ *   setstate(scratch) makes libc use a scratch state and returns the program's own state array; word 0 of that
+ *   array is the info word (5 * rear_index + type, refreshed by that very setstate call), words 1..31 the ring.
+ * The VHS build reads the 31-value history out of the parked array, advances it on the GPU and writes it back
+ * before the array is re-installed with setstate(), which re-reads the info word.  glibc's default TYPE_3
+ * generator only (the reference's platform); anything else aborts.
  */
 extern char *setstate(char *state);        /* POSIX (stdlib.h hides it under -std=c89) */
 
-static unsigned *d_hist_buf;
-
 static int *
-borrow_libc_rand(unsigned hist[31])
+park_libc_rand(void)
 {
     static int scratch[34];
-    int *lib, info, rear, j;
+    int *lib;
 
     scratch[0] = 3;                                 /* TYPE_3, rear index 0 */
     lib = (int *) setstate((char *) scratch);
     if (lib == 0) {
         fatal("setstate", CRTHIP_E_ARG);
     }
+    return lib;
+}
+
+static void
+unpark_libc_rand(int *lib)
+{
+    setstate((char *) lib);
+}
+
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+static unsigned *d_hist_buf;
+
+/* the generator's history y[n-31 .. n-1] in logical order, out of the parked state array */
+static void
+read_libc_rand(int *lib, unsigned hist[31])
+{
+    int info, rear, j;
+
     info = lib[0];
     if (info % 5 != 3) {
-        setstate((char *) lib);
+        unpark_libc_rand(lib);
         fatal("rand() is not glibc's TYPE_3 generator", CRTHIP_E_ARG);
     }
     rear = info / 5;
     for (j = 0; j < 31; j++) {
         hist[j] = (unsigned) lib[1 + (rear + 3 + j) % 31];
     }
-    return lib;
 }
 
 static void
-return_libc_rand(int *lib, const unsigned hist[31])
+write_libc_rand(int *lib, const unsigned hist[31])
 {
     int j;
 
@@ -238,7 +254,6 @@ return_libc_rand(int *lib, const unsigned hist[31])
         lib[1 + (3 + j) % 31] = (int) hist[j];
     }
     lib[0] = 3;                                     /* rear index 0, TYPE_3 */
-    setstate((char *) lib);
 }
 #endif
 
@@ -296,6 +311,7 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     crthip_params p;
     size_t img_bytes;
     int field = 0, frame = 0, aux = 0;
+    int *lib;
 
     monitor_params(&p, v);
     p.w = s->w;
@@ -334,6 +350,7 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     }
     CHECK(crthip_params_finalize(&p));
 
+    lib = park_libc_rand();
     sl = get_slot(v);
     /* one spare row + slack: the encoder may address row h (reference quirk) */
     ensure(&sl->d_img, &sl->img_cap, img_bytes + img_bytes / (size_t) s->h + 256);
@@ -343,6 +360,7 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     CHECK(crthip_modulate(g_ctx, &p, 1, sl->d_img, 0, sl->d_analog, sl->d_state));
     CHECK(crthip_download(g_ctx, v->analog, sl->d_analog, CRT_INPUT_SIZE));
     state_from_device(sl, v, 0);
+    unpark_libc_rand(lib);
 }
 
 extern void
@@ -352,6 +370,7 @@ crt_demodulate(struct CRT *v, int noise)
     crthip_params p;
     size_t out_bytes;
     int bpp;
+    int *lib;
 
     bpp = crt_setup_bpp4fmt(v->out_format);
     if (bpp == 0) {
@@ -364,6 +383,7 @@ crt_demodulate(struct CRT *v, int noise)
     p.noise = noise;
     CHECK(crthip_params_finalize(&p));
 
+    lib = park_libc_rand();
     sl = get_slot(v);
     out_bytes = (size_t) v->outw * (size_t) v->outh * (size_t) bpp;
     ensure(&sl->d_out, &sl->out_cap, out_bytes + 256);
@@ -373,7 +393,7 @@ crt_demodulate(struct CRT *v, int noise)
 #if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
     {
         unsigned hist[32];
-        int *lib = borrow_libc_rand(hist);
+        read_libc_rand(lib, hist);
         if (d_hist_buf == 0) {
             d_hist_buf = (unsigned *) dev_alloc(32 * sizeof(unsigned));
         }
@@ -381,7 +401,7 @@ crt_demodulate(struct CRT *v, int noise)
         CHECK(crthip_vhs_bind_history(g_ctx, d_hist_buf));
         CHECK(crthip_noise(g_ctx, &p, 1, sl->d_analog, sl->d_inp, sl->d_state));
         CHECK(crthip_download(g_ctx, hist, d_hist_buf, 31 * sizeof(unsigned)));
-        return_libc_rand(lib, hist);
+        write_libc_rand(lib, hist);
     }
 #else
     CHECK(crthip_noise(g_ctx, &p, 1, sl->d_analog, sl->d_inp, sl->d_state));
@@ -391,4 +411,5 @@ crt_demodulate(struct CRT *v, int noise)
     CHECK(crthip_download(g_ctx, v->inp, sl->d_inp, CRT_INPUT_SIZE));
     CHECK(crthip_download(g_ctx, v->out, sl->d_out, out_bytes));
     state_from_device(sl, v, 1);
+    unpark_libc_rand(lib);
 }
