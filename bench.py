@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--system", default="ntsc", choices=["ntsc", "ntscp0", "vhs", "nes", "nesp0"],
                     help="non-default systems are extra measurements (BASELINE configs[3], [4]), not the headline")
+    ap.add_argument("--fir", type=int, default=0, choices=[0, 4, 5, 6, 7],
+                    help="decoder of a USE_CONVOLUTION build of the reference (FIR kernel of N taps) instead of the 3-band equaliser")
     ap.add_argument("--outw", type=int, default=0)
     ap.add_argument("--outh", type=int, default=0)
     ap.add_argument("--sequence", action="store_true", help="treat the batch as ONE video (crthip_sequence) instead of independent frames")
@@ -121,6 +123,7 @@ def main():
     outw, outh = args.outw or (640 if nes else w), args.outh or (480 if nes else h)
     crt = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, args.system, device=local)
     crt.scanlines = args.scanlines
+    crt.eq_fir = args.fir
     crt.reserve(n)
     crt.set_overlap(args.overlap)
     crt.set_pixel_tile(args.pixel_tile)
@@ -195,7 +198,7 @@ def main():
         achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        headline = (args.system, w, h, outw, outh, args.noise, args.scanlines) == ("ntsc", 640, 480, 640, 480, 24, 1)
+        headline = (args.system, w, h, outw, outh, args.noise, args.scanlines, args.fir) == ("ntsc", 640, 480, 640, 480, 24, 1, 0)
         if headline and os.path.exists(tpath):               # the PMC passes were made on the headline workload only
             try:
                 traffic = json.load(open(tpath)).get("k_" + dom + "_bytes_per_field")
@@ -207,7 +210,7 @@ def main():
         # ~46 VALU ~ 130 cycles per pixel with the measured issue costs (profiles/r01_valu_issue_rates.txt),
         # 3.75 waves per field, 1024 SIMDs
         valu = None
-        if dom == "decode" and (args.system, w, h, outw, outh) == ("ntsc", 640, 480, 640, 480):
+        if dom == "decode" and (args.system, w, h, outw, outh, args.fir) == ("ntsc", 640, 480, 640, 480, 0):
             cycles_per_field = 3.75 * (756 * 170 + 640 * 130)
             clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_final_sq_counters.json
             need_ms = cycles_per_field * n / 1024.0 / clk * 1e3
@@ -221,7 +224,8 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s %dx%d -> %dx%d BGRA, %s, full colour, noise %d, hue 0, scanlines %d%s"
                                    % (args.system.upper(), w, h, outw, outh, "progressive" if nes else "interlaced", args.noise,
-                                      args.scanlines, " (BASELINE configs[1])" if (args.system, w, h, outw, outh) == ("ntsc", 640, 480, 640, 480) else ""),
+                                      args.scanlines, " (BASELINE configs[1])" if (args.system, w, h, outw, outh, args.fir) == ("ntsc", 640, 480, 640, 480, 0)
+                                      else (", %d-tap FIR decoder (USE_CONVOLUTION build)" % args.fir if args.fir else "")),
                        "fields_per_gpu_per_step": n, "frames_per_step": world * n,
                        "sharding": "frames by rank, RCCL broadcast of settings only",
                        "mode": "one video per GPU (crthip_sequence)" if args.sequence else "independent frames (crthip_fieldpass)"},
@@ -236,7 +240,8 @@ def main():
                          "note": "640x480 is integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.system, w, h, outw, outh, args.noise, args.scanlines, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.system + ("fir%d" % args.fir if args.fir else ""), w, h, outw, outh,
+                                               args.noise, args.scanlines, args.cpu_seconds)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:

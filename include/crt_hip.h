@@ -64,6 +64,11 @@ extern "C" {
 /* crthip_params.flags */
 #define CRTHIP_F_NES_SETUP    2  /* crthip_modulate, NES: NTSC_SETTINGS.field_initialized == 0, i.e. also
                                     write the whole-field sync skeleton (setup_field, crt_nes.c:81-104) */
+/* Decoder filter of a USE_CONVOLUTION build of the reference (crt_core.c:85-147): a symmetric FIR kernel of
+ * 7 (USE_7_SAMPLE_KERNEL, weights 1 4 7 8 7 4 1), 6, 5 or 4 taps instead of the 3-band IIR equaliser.
+ * flags |= CRTHIP_F_EQ_FIR(7); 0 taps (the default) = the equaliser of the reference's stock build. */
+#define CRTHIP_F_EQ_FIR(taps)  ((taps) << 8)
+#define CRTHIP_F_EQ_FIR_MASK   (7 << 8)
 
 /*
  * Everything that is uniform over a batch of field-passes.  Plain old data, no
@@ -106,7 +111,8 @@ typedef struct crthip_params {
     int ire_base;                  /* BLACK_LEVEL + black_point, crt_ntsc.c:311 */
     int dx;                        /* crt_core.c:528                           */
     int ratio;                     /* crt_core.c:404-405                       */
-    int reserved[8];
+    int eq_kernel;                 /* 0 or the FIR taps from flags (validated)   */
+    int reserved[7];
 } crthip_params;
 
 /*

@@ -42,7 +42,7 @@ class Params(C.Structure):
         ("iir_c", C.c_int * 3), ("eq_lf", C.c_int * 3), ("eq_hf", C.c_int * 3),
         ("eq_g", (C.c_int * 3) * 3), ("huesn", C.c_int), ("huecs", C.c_int),
         ("bright", C.c_int), ("white", C.c_int), ("ire_base", C.c_int), ("dx", C.c_int),
-        ("ratio", C.c_int), ("reserved", C.c_int * 8)]
+        ("ratio", C.c_int), ("eq_kernel", C.c_int), ("reserved", C.c_int * 7)]
 
 
 def bpp4fmt(fmt):
@@ -160,6 +160,7 @@ class CRT:
         self.saturation, self.contrast, self.white_point = 10, 180, 100
         self.scanlines = self.blend = 0
         self.v_fac = 0
+        self.eq_fir = 0        # 0: the 3-band equaliser; 7/6/5/4: FIR kernel of a USE_CONVOLUTION build (crt_core.c:85-147)
         bpp = bpp4fmt(out_format) or 4
         self.out = out if out is not None else torch.zeros((n, outh, outw, bpp), dtype=torch.uint8, device=self.dev)
         self.state = torch.zeros((n, STATE_INTS), dtype=torch.int32, device=self.dev)
@@ -230,7 +231,7 @@ class CRT:
             h, w = int(d.shape[1]), int(d.shape[2])
         else:
             h, w = int(d.shape[1]), int(d.shape[2])
-        flags = 0
+        flags = self.eq_fir << 8                                   # CRTHIP_F_EQ_FIR(taps)
         if self.sysid == SYSTEM_NES and not s.initialized:
             flags |= F_NES_SETUP
         return make_params(self.system, w=w, h=h, format=s.format, raw=s.raw, as_color=s.as_color, hue=s.hue,
@@ -278,7 +279,7 @@ class CRT:
             self.system, w=1, h=1, outw=self.outw, outh=self.outh, out_format=self.out_format,
             mon_hue=self.hue, brightness=self.brightness, contrast=self.contrast, saturation=self.saturation,
             black_point=self.black_point, white_point=self.white_point, scanlines=self.scanlines,
-            blend=self.blend, v_fac=self.v_fac, noise=noise)
+            blend=self.blend, v_fac=self.v_fac, noise=noise, flags=self.eq_fir << 8)
         vp = C.c_void_p
         self._check(self.L.crthip_noise(self.ctx, C.byref(p), self.n, vp(self.analog.data_ptr()),
                                         vp(self.inp.data_ptr()), vp(self.state.data_ptr())), "crthip_noise")

@@ -109,6 +109,28 @@ __device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, 
     return r;
 }
 
+/* eqf of a USE_CONVOLUTION build of the reference (crt_core.c:119-147): a symmetric FIR kernel over a 7-deep
+ * input history.  The four kernels factor into running sums,
+ *     4 taps  1 1 1 1        = box4
+ *     5 taps  1 2 2 2 1      = box2 * box4
+ *     6 taps  1 3 4 4 3 1    = box2 * box2 * box4
+ *     7 taps  1 4 7 8 7 4 1  = box2 * box2 * box2 * box4          (then >> 2 + number of box2 stages)
+ * which is the same integer sum (adds only, no rounding before the final shift; histories start at 0 like the
+ * reference's): M box2 stages, each  t = x + prev, prev = x,  then the box4 as  acc += t - ring[n & 3]  with a
+ * ring of 4 that the 4-samples-per-dword unrolling indexes statically -- no history shifting at all. */
+struct Fir { int p1, p2, p3, acc, r0, r1, r2, r3; };
+template <int M>
+__device__ __forceinline__ int fir_step(Fir &f, int x, const int K /* sample index & 3: a constant after unrolling */)
+{
+    if (M >= 1) { const int t = x + f.p1; f.p1 = x; x = t; }
+    if (M >= 2) { const int t = x + f.p2; f.p2 = x; x = t; }
+    if (M >= 3) { const int t = x + f.p3; f.p3 = x; x = t; }
+    int &slot = K == 0 ? f.r0 : K == 1 ? f.r1 : K == 2 ? f.r2 : f.r3;
+    f.acc += x - slot;
+    slot = x;
+    return f.acc >> (2 + M);
+}
+
 /* byte selectors for v_perm_b32: 0xffRRGGBB (bytes B,G,R,ff) <-> the four 4-byte output formats,
  * crt_core.c:587-656 */
 __device__ __forceinline__ unsigned pack_selector(int format)
@@ -138,7 +160,8 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
 /* TIER: 0 = 64-bit-mad stages without the I/Q low cascades, 1 = 64-bit-mad stages, 2 = 24-bit mads,
- * 3 = exact 32-bit multiplies; a wave of 64 lines is decoded by the kernel
+ * 3 = exact 32-bit multiplies; 4 / 5 = the FIR kernels of a USE_CONVOLUTION build (P.eq_kernel taps; the whole
+ * batch) with 24-bit / exact 32-bit multiplies around them; a wave of 64 lines is decoded by the kernel
  * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
  * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES) */
 template <class S, int TIER, bool BPP3, int PXT>
@@ -147,8 +170,9 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
          int want_rank)
 {
-    constexpr bool FAST = TIER <= 2;        /* tiers 0-2 use 24-bit multiplies outside the filter stages */
+    constexpr bool FAST = TIER <= 2 || TIER == 4;   /* 24-bit multiplies outside the filter stages */
     constexpr bool LOSKIP = TIER == 0;
+    constexpr bool FIR = TIER >= 4;
     constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
     __shared__ unsigned s_in[64 * IN_STRIDE];
     constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
@@ -168,7 +192,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
      * runs once, not once per tier */
     int tier = __ballot(lp.nrows & CRTHIP_LINE_EXACT) ? 3 : __ballot(lp.nrows & CRTHIP_LINE_NOT64) ? 2
              : __ballot(lp.nrows & CRTHIP_LINE_WIDE) ? 1 : 0;
-    if (tier < min_tier) tier = min_tier;
+    if (min_tier >= 4) tier = (min_tier == 5 || tier == 3) ? 5 : 4;     /* FIR build: 24-bit envelope as for tier 2 */
+    else if (tier < min_tier) tier = min_tier;
     if (tier != TIER) return;
     int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
     const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
@@ -189,6 +214,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const bool rgb_order = P.out_format == CRTHIP_FMT_RGB;
     const bool blend = P.blend != 0;
     Eq3 ey = {}, ei = {}, eq = {};
+    Fir fy = {}, fi = {}, fq = {};
+    const int fir_m = P.eq_kernel - 4;             /* box2 stages of the FIR kernel (wave-uniform) */
     Eq64 wy, wi_, wq_;                             /* tier 0 state (register pairs) */
     eq64_reset(wy); eq64_reset(wi_); eq64_reset(wq_);
     /* tier 0 multipliers: luma coefficients are 2^16 + c', chroma ones < 2^15 (host-checked) */
@@ -245,6 +272,11 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
                     ci = eq_step64<false, 65536, 1311, LOSKIP>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
                     cq = eq_step64<false, 65536, 0, LOSKIP>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
+                } else if (FIR) {
+                    const int uy = s + bright, ui = mulq<FAST>(s, wi) >> 9, uq = mulq<FAST>(s, wq) >> 9;
+#define CRT_FIR3(M) do { cy = fir_step<M>(fy, uy, k) << 4; ci = fir_step<M>(fi, ui, k) >> 3; cq = fir_step<M>(fq, uq, k) >> 3; } while (0)
+                    if (fir_m == 3) CRT_FIR3(3); else if (fir_m == 2) CRT_FIR3(2); else if (fir_m == 1) CRT_FIR3(1); else CRT_FIR3(0);
+#undef CRT_FIR3
                 } else {
                     cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
                     ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
@@ -363,7 +395,9 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride)
 {
-    const int min_tier = decoder_min_tier(c, p);
+    /* FIR build: the filters only add, their outputs stay inside the hull of the inputs, so the 24-bit envelope
+     * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
+    const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
     const bool wide = c->px_tile ? c->px_tile == 32 : p->outw >= 1280;
     /* lines per output row when the picture is shorter than the raster: one pass per rank */
     const unsigned span = (unsigned) p->outh + p->v_fac;
@@ -383,12 +417,16 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
                 if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, true);
                 if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, true);
                 if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, true);
-                CRTHIP_LAUNCH_DECODE(3, true);
+                if (min_tier <= 3) CRTHIP_LAUNCH_DECODE(3, true);
+                if (min_tier == 4) CRTHIP_LAUNCH_DECODE(4, true);
+                if (min_tier >= 4) CRTHIP_LAUNCH_DECODE(5, true);
             } else {
                 if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, false);
                 if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, false);
                 if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, false);
-                CRTHIP_LAUNCH_DECODE(3, false);
+                if (min_tier <= 3) CRTHIP_LAUNCH_DECODE(3, false);
+                if (min_tier == 4) CRTHIP_LAUNCH_DECODE(4, false);
+                if (min_tier >= 4) CRTHIP_LAUNCH_DECODE(5, false);
             }
 #undef CRTHIP_LAUNCH_DECODE
         }

@@ -289,6 +289,10 @@ crthip_params_finalize(crthip_params *p)
     if (p->outw <= 0 || p->outh <= 0 || p->w <= 0 || p->h <= 0) {
         return CRTHIP_E_ARG;
     }
+    p->eq_kernel = (p->flags & CRTHIP_F_EQ_FIR_MASK) >> 8;      /* crt_core.c:85-88 */
+    if (p->eq_kernel != 0 && (p->eq_kernel < 4 || p->eq_kernel > 7)) {
+        return CRTHIP_E_ARG;
+    }
 
     memset(p->burst, 0, sizeof(p->burst));
     memset(p->modI, 0, sizeof(p->modI));

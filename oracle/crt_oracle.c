@@ -198,6 +198,7 @@ orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
         sys->eq_hf[k] = 2 * (sn << 1);
         for (b = 0; b < 3; b++) sys->eq_g[k][b] = gains[k][b];
     }
+    sys->eq_kernel = 0;
 }
 
 /* crt_core.c:241-289 crt_init = memset + crt_resize + crt_reset + rn seed */
@@ -516,7 +517,24 @@ found:
     *odd_field = j > sys->hres / 2;
 }
 
-struct eq_state { int lo[4], hi[4], hist[3]; };
+struct eq_state { int lo[4], hi[4], hist[7]; };
+
+/* eqf of a USE_CONVOLUTION build, crt_core.c:119-147: 7-deep input history, one of four symmetric kernels */
+static int
+eq_fir(int taps, struct eq_state *f, int s)
+{
+    int *h = f->hist;
+    int i;
+
+    for (i = 6; i > 0; i--) h[i] = h[i - 1];
+    h[0] = s;
+    switch (taps) {
+    case 7:  return (s + h[6] + ((h[1] + h[5]) * 4) + ((h[2] + h[4]) * 7) + (h[3] * 8)) >> 5;   /* 1 4 7 8 7 4 1 */
+    case 6:  return (s + h[5] + 3 * (h[1] + h[4]) + 4 * (h[2] + h[3])) >> 4;                    /* 1 3 4 4 3 1   */
+    case 5:  return (s + h[4] + ((h[1] + h[2] + h[3]) << 1)) >> 3;                              /* 1 2 2 2 1     */
+    default: return (s + h[3] + h[1] + h[2]) >> 2;                                              /* 1 1 1 1       */
+    }
+}
 
 /* eqf, crt_core.c:206-233 */
 static int
@@ -525,6 +543,8 @@ eq_step(const struct orc_sys *sys, int which, struct eq_state *f, int s)
     const int lf = sys->eq_lf[which], hf = sys->eq_hf[which];
     const int *g = sys->eq_g[which];
     int k, band0, band1, band2;
+
+    if (sys->eq_kernel) return eq_fir(sys->eq_kernel, f, s);
 
     f->lo[0] += (lf * (s - f->lo[0]) + 32768) >> 16;
     f->hi[0] += (hf * (s - f->hi[0]) + 32768) >> 16;

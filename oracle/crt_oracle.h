@@ -44,6 +44,9 @@ struct orc_sys {
     int white_level, burst_level, black_level, blank_level, sync_level;
     int iir_c[3];        /* encoder 1-pole coefficients Y,I,Q (Q11) */
     int eq_lf[3], eq_hf[3], eq_g[3][3]; /* decoder equaliser, Y,I,Q */
+    int eq_kernel;       /* 0: the 3-band IIR equaliser (the reference's default build); 7/6/5/4: the FIR
+                          * kernels of a USE_CONVOLUTION build (crt_core.c:85-147).  Set by the caller
+                          * after orc_sys_init. */
 };
 
 struct orc_crt {

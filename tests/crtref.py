@@ -29,7 +29,13 @@ SYSTEMS = {
     "nes": (SYS_NES, 2, "libref_nes.so"),
     "nesp0": (SYS_NES, 0, "libref_nesp0.so"),
     "ntscp0": (SYS_NTSC, 0, "libref_ntscp0.so"),
+    # USE_CONVOLUTION builds of the decoder (crt_core.c:85-147): FIR kernels instead of the 3-band equaliser
+    "ntscfir7": (SYS_NTSC, 1, "libref_ntscfir7.so"),
+    "ntscfir6": (SYS_NTSC, 1, "libref_ntscfir6.so"),
+    "ntscfir5": (SYS_NTSC, 1, "libref_ntscfir5.so"),
+    "ntscfir4": (SYS_NTSC, 1, "libref_ntscfir4.so"),
 }
+EQ_KERNEL = {"ntscfir7": 7, "ntscfir6": 6, "ntscfir5": 5, "ntscfir4": 4}      # everything else: 0 (IIR)
 
 
 def bpp4fmt(fmt):
@@ -273,7 +279,7 @@ class OrcSys(C.Structure):
         "sync_beg", "bw_beg", "cb_beg", "av_beg", "av_len", "lav_beg", "vs_sep_end",
         "white_level", "burst_level", "black_level", "blank_level", "sync_level")] + [
         ("iir_c", C.c_int * 3), ("eq_lf", C.c_int * 3), ("eq_hf", C.c_int * 3),
-        ("eq_g", (C.c_int * 3) * 3)]
+        ("eq_g", (C.c_int * 3) * 3), ("eq_kernel", C.c_int)]
 
 
 class OrcCrt(C.Structure):
@@ -313,6 +319,7 @@ class Oracle:
         L = self.lib
         self.sys = OrcSys()
         L.orc_sys_init(C.byref(self.sys), self.system, self.pattern)
+        self.sys.eq_kernel = EQ_KERNEL.get(name, 0)
         for n in ("hres", "vres", "input_size", "top", "bot", "av_beg", "av_len"):
             setattr(self, n, getattr(self.sys, n))
         self.vper = self.sys.cc_vper

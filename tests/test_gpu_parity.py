@@ -88,7 +88,8 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False):
     imgs = np.stack([R.synth_image(w, h, bpp, 777 + 13 * k, "random" if k % 2 == 0 else "bars") for k in range(n)])
     dimgs = _padded(imgs)
     orc, ocrts = _oracle_batch(name, n, outw, outh, ofmt, knobs)
-    g = crtlib.CRT(n, outw, outh, ofmt, name, device=0)
+    g = crtlib.CRT(n, outw, outh, ofmt, name[:4] if name.startswith("ntscfir") else name, device=0)
+    g.eq_fir = R.EQ_KERNEL.get(name, 0)              # "ntscfir7": the FIR decoder of a USE_CONVOLUTION build
     g.set_exact(exact)
     for k, v in knobs.items():
         setattr(g, k, v)
@@ -150,6 +151,23 @@ def test_stagewise_parity(crtlib, case):
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_fused_fieldpass_parity(crtlib, case):
     _run_case(crtlib, CASES[case], fused=True)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("taps", [7, 6, 5, 4])
+@pytest.mark.parametrize("case", [1, 2, 4, 8])
+def test_fir_decoder_parity(crtlib, case, taps, fused):
+    """the decoder of a USE_CONVOLUTION build of the reference (crt_core.c:85-147, symmetric FIR
+    kernels of 7/6/5/4 taps instead of the 3-band equaliser), selected per launch with CRTHIP_F_EQ_FIR(taps).
+    The oracle's FIR mode is pinned against those builds of the reference in tests/test_oracle_vs_ref.py."""
+    c = CASES[case]
+    _run_case(crtlib, ("ntscfir%d" % taps,) + tuple(c[1:]), fused=fused, steps=2)
+
+
+@pytest.mark.parametrize("knobs", [dict(saturation=900, contrast=300), dict(brightness=200000, contrast=9000000, white_point=9000000)])
+def test_fir_decoder_outside_the_24bit_envelope(crtlib, knobs):
+    """huge carrier amplitude (lines flagged by k_hsync) / huge brightness (host-side floor): the exact FIR tier"""
+    _run_case(crtlib, ("ntscfir7", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1), knobs), fused=True, steps=2)
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])

@@ -76,8 +76,10 @@ NTSC_CASES = [
 
 @needs_ref
 @pytest.mark.parametrize("case", range(len(NTSC_CASES)))
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "ntscp0"])
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "ntscp0", "ntscfir7", "ntscfir6", "ntscfir5", "ntscfir4"])
 def test_fieldpass_sequence_matches_reference(name, case):
+    if name.startswith("ntscfir") and case not in (0, 1, 3, 8, 10):
+        pytest.skip("the FIR builds (USE_CONVOLUTION) are pinned on a subset of the cases")
     outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = NTSC_CASES[case]
     pair = _pair(name, outw, outh, ofmt)
     img = R.synth_image(w, h, R.bpp4fmt(ifmt), 12345 + case, "random" if case % 2 == 0 else "bars")
