@@ -224,9 +224,15 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     int py = 0, pi = 0, pq = 0;                    /* yiq of the previous sample */
 
     /* wave-uniform output pixel schedule, crt_core.c:528-531,555-562 */
+    /* pixel px sits at ppos = px * dx and is emitted after sample (ppos >> 12) + 1; both loop conditions of
+     * crt_core.c:555 (px < outw, pos < scan_r) fold into one bound on ppos (64-bit product: dx * outw < 2^32 only
+     * just) */
+    const unsigned long long ppos_all = (unsigned long long) (unsigned) P.dx * (unsigned) P.outw;
     const unsigned scan_r = (unsigned) (S::AV_LEN - 1) << 12;
+    const unsigned ppos_end = ppos_all < scan_r ? (unsigned) ppos_all : scan_r;
     const unsigned dx = (unsigned) P.dx;
     unsigned ppos = 0;
+    int next_x = 1;                                /* sample after which pixel px becomes computable */
     int px = 0;
     const int outw = P.outw;
 
@@ -283,7 +289,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
                 }
                 /* D9: every output pixel whose left tap is sample x-1 is now computable */
-                while (px < outw && ppos < scan_r && (int) (ppos >> 12) == x - 1) {
+                while (x == next_x && ppos < ppos_end) {
                     const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
                     int yy;
                     if (TIER <= 1) {
@@ -370,6 +376,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                         __syncthreads();
                     }
                     ppos += dx;
+                    next_x = (int) (ppos >> 12) + 1;
                     px++;
                 }
                 py = cy; pi = ci; pq = cq;
@@ -395,6 +402,8 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride)
 {
+    if (p->dx <= 0)     /* more than 4096 output pixels per sample: the resampler's step (crt_core.c:528) rounds to 0 */
+        return set_err(c, CRTHIP_E_ARG, "outw too large for the 12-bit resampler (dx == 0)", hipSuccess);
     /* FIR build: the filters only add, their outputs stay inside the hull of the inputs, so the 24-bit envelope
      * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
     const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
