@@ -190,6 +190,10 @@ monitor_params(crthip_params *p, const struct CRT *v)
     p->v_fac = v->v_fac;
     p->w = 1;
     p->h = 1;
+#ifdef CRT_EQ_FIR_TAPS
+    /* stand-in for a USE_CONVOLUTION build of the reference (crt_core.c:85-88): 7, 6, 5 or 4 */
+    p->flags |= CRTHIP_F_EQ_FIR(CRT_EQ_FIR_TAPS);
+#endif
 }
 
 /*

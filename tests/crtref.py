@@ -55,7 +55,8 @@ DROPIN = {"ntsc": ("libntsccrt_hip_ntsc.so", ["-DCRT_SYSTEM=0"]),
           "vhs": ("libntsccrt_hip_vhs.so", ["-DCRT_SYSTEM=5"]),
           "nes": ("libntsccrt_hip_nes.so", ["-DCRT_SYSTEM=1"]),
           "nesp0": ("libntsccrt_hip_nesp0.so", ["-DCRT_SYSTEM=1", "-DCRT_CHROMA_PATTERN=0"]),
-          "ntscp0": ("libntsccrt_hip_ntscp0.so", ["-DCRT_SYSTEM=0", "-DCRT_CHROMA_PATTERN=0"])}
+          "ntscp0": ("libntsccrt_hip_ntscp0.so", ["-DCRT_SYSTEM=0", "-DCRT_CHROMA_PATTERN=0"]),
+          "ntscfir7": ("libntsccrt_hip_ntsc_fir7.so", ["-DCRT_SYSTEM=0"])}
 
 
 def build_dropin_probe(name):

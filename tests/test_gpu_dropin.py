@@ -239,3 +239,21 @@ def test_unchanged_video_convert_driver(tmp_path, flags, noise):
         a = np.frombuffer(outs[0][k][54:], dtype=np.uint8).reshape(312, 416 * 4)[::-1]
         b = np.frombuffer(outs[1][k][54:], dtype=np.uint8).reshape(312, 416 * 4)[::-1]
         np.testing.assert_array_equal(a[:300], b[:300], err_msg="video_convert %s: frame %d" % (flags, k + 1))
+
+
+def test_fir_dropin_matches_a_use_convolution_build_of_the_reference():
+    """libntsccrt_hip_ntsc_fir7.so stands in for crt_core.c compiled with USE_CONVOLUTION 1 (7-sample kernel)"""
+    hip = R.RefLib("ntscfir7", dropin=True)
+    chk = _checker("ntscfir7")
+    img = R.synth_image(640, 480, 4, 21)
+    pad = np.concatenate([img, img[-1:]])
+    a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+    for c in (a, b):
+        c.set("scanlines", 1)
+        c.settings(pad, format=R.FMT_BGRA, w=640, h=480, as_color=1, hue=10)
+    for step in range(4):
+        for c in (a, b):
+            c.modulate()
+            c.demodulate(24)
+            c.sset("field", c.sget("field") ^ 1)
+        R.compare_state(a, b, "fir7 step %d" % step)
