@@ -341,7 +341,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                         const unsigned long long dd = d + (size_t) dup * pitch;
                                         if (have >= 4) {
                                             v4i o; o.x = (int) v[0]; o.y = (int) v[1]; o.z = (int) v[2]; o.w = (int) v[3];
-                                            gstore16u(dd, o);
+                                            gstore16u_nt(dd, o);
                                         } else {
                                             gstore32(dd, v[0]);
                                             if (have > 1) gstore32(dd + 4, v[1]);
