@@ -93,6 +93,14 @@ k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, s
     }
 }
 
+/* 16 bytes of the input image.  Wide tiles (32 pixels = whole 128-byte lines per row) stream past the caches:
+ * the image is read exactly once.  Narrow tiles fetch a line in two halves at different times, and the second
+ * half must still find it in L2 (measured: streaming loads cost +35 % there). */
+template <int ACT> __device__ __forceinline__ v4i image_piece(unsigned long long a)
+{
+    return ACT == 32 ? gload16u_nt(a) : gload16u(a);
+}
+
 /* ------------------------------------------------------------------------- */
 /* M5: active video, one lane per destination row                              */
 /* ------------------------------------------------------------------------- */
@@ -274,7 +282,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         auto fetch = [&](int tile) {
             const int off = piece_offset(tile);
 #pragma unroll
-            for (int i = 0; i < AC_PIECES; i++) stage[i] = gload16u(s_src[i * AC_ROWS + prow_] + off);
+            for (int i = 0; i < AC_PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * AC_ROWS + prow_] + off);
         };
         auto stash = [&](int tile) {
             /* dword index inside the tile where my (possibly moved-back) piece belongs; moved-back
@@ -443,7 +451,7 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     auto fetch = [&](int tile) {
         const int off = piece_offset(tile);
 #pragma unroll
-        for (int i = 0; i < AC_PIECES; i++) stage[i] = gload16u(s_src[i * AC_ROWS + prow_] + off);
+        for (int i = 0; i < AC_PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * AC_ROWS + prow_] + off);
     };
     auto stash = [&](int tile) {
         const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;
