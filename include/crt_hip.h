@@ -67,6 +67,9 @@ extern "C" {
 /* Decoder filter of a USE_CONVOLUTION build of the reference (crt_core.c:85-147): a symmetric FIR kernel of
  * 7 (USE_7_SAMPLE_KERNEL, weights 1 4 7 8 7 4 1), 6, 5 or 4 taps instead of the 3-band IIR equaliser.
  * flags |= CRTHIP_F_EQ_FIR(7); 0 taps (the default) = the equaliser of the reference's stock build. */
+#define CRTHIP_F_VHS_DRAW_ABERRATION 4  /* crthip_sequence, VHS: draw every field's aberration height (state.aux)
+                                           from the rand() stream like crt_modulate does with do_aberration
+                                           (crt_ntscvhs.c:205-207) instead of taking state.aux from the caller */
 #define CRTHIP_F_EQ_FIR(taps)  ((taps) << 8)
 #define CRTHIP_F_EQ_FIR_MASK   (7 << 8)
 
@@ -206,8 +209,12 @@ int  crthip_fieldpass(crthip_ctx *ctx, const crthip_params *p, int n,
  *   set's state before field 0; on return d_state[k] holds the state after field k.
  *   d_out image k = the (single) output buffer as it stands after field k; d_out_init = its content
  *   before field 0 (NULL = zeros, i.e. calloc as in the drivers).
- * Requires blend == 0 (video_convert.c:239) and a non-VHS system; *passes (optional) receives the
- * number of sync fixed-point passes that were needed.
+ * Requires blend == 0 (video_convert.c:239); *passes (optional) receives the number of sync fixed-point
+ * passes that were needed.
+ * VHS build: the fields also share ONE rand() stream.  Entry 0 of the bound history array
+ * (crthip_vhs_bind_history) is the generator before field 0; a serial pre-pass walks the stream's
+ * data-dependent part for all fields (about 0.15 ms per field) and on return entry k is the generator after
+ * field k.  With CRTHIP_F_VHS_DRAW_ABERRATION the aberration heights are drawn from the stream as well.
  */
 int  crthip_sequence(crthip_ctx *ctx, const crthip_params *p, int n,
                      const void *d_images, size_t image_stride,

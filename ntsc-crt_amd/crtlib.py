@@ -232,6 +232,8 @@ class CRT:
         else:
             h, w = int(d.shape[1]), int(d.shape[2])
         flags = self.eq_fir << 8                                   # CRTHIP_F_EQ_FIR(taps)
+        if getattr(s, "draw_aberration", 0):
+            flags |= 4                                             # CRTHIP_F_VHS_DRAW_ABERRATION (sequence mode)
         if self.sysid == SYSTEM_NES and not s.initialized:
             flags |= F_NES_SETUP
         return make_params(self.system, w=w, h=h, format=s.format, raw=s.raw, as_color=s.as_color, hue=s.hue,

@@ -316,6 +316,7 @@ int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_s
 int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
                   crthip_state *d_state, bool advance_rn);
 int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
+int crt_run_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration);
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
                  crthip_line *d_lines, int advance_rn);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,

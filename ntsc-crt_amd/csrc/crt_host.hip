@@ -450,8 +450,9 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     int rc = check_params(c, p, n);
     if (rc) return rc;
     if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS)
-        return set_err(c, CRTHIP_E_ARG, "sequence mode: the VHS rand() stream is a chain over fields, use crthip_fieldpass per field", hipSuccess);
+    const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS;
+    if (vhs && !c->d_vhs_hist)
+        return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
     if (p->blend) return set_err(c, CRTHIP_E_ARG, "sequence mode needs blend == 0 (blend is a recurrence over fields)", hipSuccess);
     if (p->out_bpp == 0) return CRTHIP_OK;
     int enc = check_encoder(c, p);
@@ -480,10 +481,24 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     crthip_state first;
     HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipLaunchKernelGGL(k_seq_rn, gn, b64, 0, c->stream, n, d_state, c->whole_field);
-    /* encode every field (noise fused), ccf presets */
-    rc = crt_run_encoder(c, p, n, d_images, istride, c->d_inp, d_state, true, 1, false);
-    if (rc) return rc;
+    if (vhs) {
+        /* the fields share one rand() stream: run the chain ahead (k_vhs_chain: hist[k] = generator at the start
+         * of field k, aberration heights drawn in-stream if asked), after which every field is independent;
+         * then clean encode -> rand() noise (which also leaves rn), as in crthip_fieldpass */
+        rc = crt_run_vhs_chain(c, n, d_state, (p->flags & CRTHIP_F_VHS_DRAW_ABERRATION) != 0);
+        if (rc) return rc;
+        crthip_params clean = *p;
+        clean.noise = 0;
+        rc = crt_run_encoder(c, &clean, n, d_images, istride, c->d_analog, d_state, true, 1, false);
+        if (rc) return rc;
+        rc = crt_run_noise(c, p, n, c->d_analog, c->d_inp, d_state, false);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_seq_rn, gn, b64, 0, c->stream, n, d_state, c->whole_field);
+        /* encode every field (noise fused), ccf presets */
+        rc = crt_run_encoder(c, p, n, d_images, istride, c->d_inp, d_state, true, 1, false);
+        if (rc) return rc;
+    }
     /* first guess: nobody's sync state moves */
     {
         int2 *h = (int2 *) malloc(sizeof(int2) * (size_t) n);
@@ -511,7 +526,7 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     }
     if (passes_out) *passes_out = passes;
     /* rn after each field, decode, weave */
-    crt_run_advance_rn(c, n, d_state);
+    if (!vhs) crt_run_advance_rn(c, n, d_state);
     rc = crt_run_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(owner, 0, (size_t) n * outh, c->stream));

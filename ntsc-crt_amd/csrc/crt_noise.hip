@@ -340,6 +340,148 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
     }
 }
 
+/*
+ * Sequence mode of the VHS build (crthip_sequence): the fields of ONE video share ONE rand() stream, field k+1
+ * starts where field k stopped, and where it stops depends on the values drawn in its last 25 lines.  Those
+ * decisions do not depend on the picture, only on the stream, so the chain can be run ahead of everything else:
+ * one wave walks the fields in order with the same speculative block walk as k_vhs_tail minus the samples, and
+ * leaves in hist[k] the generator history at the start of field k's crt_demodulate (and, if asked to, draws the
+ * aberration height of crt_modulate, crt_ntscvhs.c:205-207, from the stream: one call per field, before it).
+ * Afterwards every field is independent again.  Serial by nature: ~0.15 ms per field.
+ */
+template <class S>
+__global__ void __launch_bounds__(64)
+k_vhs_chain(int n_fields, crthip_state *__restrict__ state, unsigned *__restrict__ hist,
+            const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows, int draw_aberration)
+{
+    constexpr int N = S::INPUT_SIZE, H = S::HRES, B = VHS_BLK;
+    constexpr int T0 = vhs_tail_start(N, H);
+    __shared__ unsigned s_y[64 * B + 8];
+    __shared__ unsigned s_h[64];
+    __shared__ unsigned s_cur[32];                                 /* the generator's history between fields */
+    __shared__ unsigned s_misc[2];
+    const int lane = threadIdx.x;
+    unsigned cb[31];
+#pragma unroll
+    for (int m = 0; m < 31; m++) cb[m] = blk_rows[m * 64 + lane];
+    if (lane < 31) s_cur[lane] = hist[lane];
+    __syncthreads();
+
+    for (int f = 0; f < n_fields; f++) {
+        if (draw_aberration) {
+            /* one call: y = y[n-31] + y[n-3]; the history slides by one */
+            const unsigned y = s_cur[0] + s_cur[28];
+            const unsigned nxt = lane < 30 ? s_cur[lane + 1] : y;
+            __syncthreads();
+            if (lane < 31) s_cur[lane] = nxt;
+            if (lane == 0) state[f].aux = (int) ((y >> 1) % 12u) - 8 + 14;
+            __syncthreads();
+        }
+        if (lane < 31) hist[(size_t) f * 32 + lane] = s_cur[lane];  /* start of field f's crt_demodulate */
+        /* history in front of call 1 + 2*T0 (call #0 and the parallel region make a fixed number of calls) */
+        {
+            unsigned zf[61];
+#pragma unroll
+            for (int j = 0; j < 31; j++) zf[j] = s_cur[j];
+#pragma unroll
+            for (int j = 31; j < 61; j++) zf[j] = zf[j - 31] + zf[j - 3];
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 61; j++) s_y[j] = zf[j];
+            }
+            __syncthreads();
+            unsigned acc = 0;
+            const int j = lane < 31 ? lane : 0;
+            for (int m = 0; m < 31; m++) acc += tail_row[m] * s_y[m + j];
+            __syncthreads();
+            if (lane < 31) s_h[lane] = acc;
+            __syncthreads();
+        }
+        int seg_start = T0;
+        while (seg_start < N) {
+            const int kseg = (N - seg_start) / H;
+            int seg_end = N - H * kseg;
+            if (seg_end > N - 1) seg_end = N - 1;
+            const int n_s = seg_end - seg_start + 1;
+            unsigned z[61];
+#pragma unroll
+            for (int j = 0; j < 31; j++) z[j] = s_h[j];
+#pragma unroll
+            for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
+            unsigned w[31];
+#pragma unroll
+            for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+            for (int m = 0; m < 31; m++) {
+#pragma unroll
+                for (int j = 0; j < 31; j++) w[j] += cb[m] * z[m + j];
+            }
+            unsigned glo = 0, ghi = 0;
+#pragma unroll
+            for (int t = 0; t < B; t++) {
+                const unsigned v = w[t % 31] + w[(t + 28) % 31];
+                w[t % 31] = v;
+                s_y[lane * B + t] = v;
+                const unsigned flag = (6 + (int) ((v >> 1) % 20u) > kseg) ? 1u : 0u;
+                if (t < 32) glo |= flag << t; else ghi |= flag << (t - 32);
+            }
+            {
+                const unsigned nb = (unsigned) __shfl_down((int) (glo & 1u), 1);
+                if (lane < 63) ghi |= nb << (B - 32);
+            }
+            const unsigned long long G = ((unsigned long long) ghi << 32) | glo;
+            unsigned res = 0;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                int pos = e, cnt = 0;
+#pragma unroll
+                for (int it = 0; it < (B + 1) / 2; it++) {
+                    const bool in = pos < B;
+                    const int step = 2 + (int) ((G >> (pos + 1)) & 1ull);
+                    pos += in ? step : 0;
+                    cnt += in ? 1 : 0;
+                }
+                res |= (unsigned) (cnt | (pos - B) << 5) << (8 * e);
+            }
+            int e_in = 0, first = n_s;
+            {
+                int e = 0, cum = 0;
+                for (int b = 0; b < 64 && cum < n_s; b++) {
+                    const unsigned r = (unsigned) __builtin_amdgcn_readlane((int) res, b) >> (8 * e);
+                    if (lane == b) { e_in = e; first = cum; }
+                    cum += (int) (r & 31u);
+                    e = (int) ((r >> 5) & 3u);
+                }
+            }
+            __syncthreads();
+            /* only the positions: where does the call after the segment's last sample sit? */
+            {
+                int pos = e_in;
+                for (int k = 0; k < (B + 1) / 2; k++) {
+                    const int sidx = first + k;
+                    const bool valid = pos < B && sidx < n_s;
+                    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break;
+                    if (valid) {
+                        pos += 2 + (int) ((G >> (pos + 1)) & 1ull);
+                        if (sidx == n_s - 1) s_misc[0] = (unsigned) (lane * B + pos);
+                    }
+                }
+            }
+            __syncthreads();
+            const int pos_end = (int) s_misc[0];
+            unsigned hv = 0;
+            if (lane < 31) hv = s_y[pos_end - 31 + lane];
+            __syncthreads();
+            if (lane < 31) s_h[lane] = hv;
+            __syncthreads();
+            seg_start += n_s;
+        }
+        if (lane < 31) s_cur[lane] = s_h[lane];
+        __syncthreads();
+    }
+}
+
 /* rn <- rn after INPUT_SIZE steps (crt_core.c:367) */
 __global__ void k_advance_rn(int n_fields, crthip_state *state, uint2 whole_field)
 {
@@ -384,6 +526,21 @@ int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed cha
                                *p, n, d_analog, d_inp, c->fstride, d_state, c->d_jump16);
         }
         if (advance_rn) hipLaunchKernelGGL(k_advance_rn, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_state, c->whole_field);
+        return CRTHIP_OK;
+    });
+}
+
+/* VHS sequence mode: hist[0] = the generator before field 0 -> hist[k] for every field (see k_vhs_chain) */
+int crt_run_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration)
+{
+    if (!c->d_vhs_hist) return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        if constexpr (S::IS_VHS) {
+            hipLaunchKernelGGL((k_vhs_chain<S>), dim3(1), dim3(64), 0, c->stream, n, d_state, c->d_vhs_hist,
+                               c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31,
+                               draw_aberration);
+        }
         return CRTHIP_OK;
     });
 }

@@ -430,6 +430,53 @@ def test_sequence_mode_equals_sequential_processing(crtlib, name, noise, scanlin
     g.close()
 
 
+@pytest.mark.parametrize("aberration", [0, 1])
+@pytest.mark.parametrize("noise", [0, 12])
+def test_vhs_sequence_mode_equals_sequential_processing(crtlib, noise, aberration):
+    """extra/video_convert.c built for CRT_SYSTEM_NTSCVHS: besides hsync/vsync and the output buffer the fields
+    share the process's rand() stream (aberration height in crt_modulate, noise in crt_demodulate).
+    crthip_sequence walks the stream's data-dependent part ahead of time (k_vhs_chain) and then treats the
+    fields in parallel; checked against the oracle doing one field after the other under one srand()."""
+    import ctypes as C
+    import shard
+    libc = C.CDLL(None)
+    n, w, h, outw, outh, seed = 7, 400, 300, 416, 312, 20260924
+    orc = R.Oracle("vhs")
+    c = orc.new_crt(outw, outh, R.FMT_BGRA)
+    c.set("scanlines", 0)
+    frames = np.stack([R.synth_image(w, h, 4, 500 + k, "random" if k % 3 else "bars") for k in range(n)])
+    libc.srand(seed)
+    want = []
+    for k in range(n):
+        field, frame = shard.field_parity(k)
+        pad = np.concatenate([frames[k], frames[k][-1:]], axis=0)
+        c.settings(pad, format=R.FMT_BGRA, w=w, h=h, as_color=1, field=field, frame=frame, do_aberration=aberration)
+        c.modulate()
+        c.demodulate(noise)
+        want.append((c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn")))
+    next_rand = libc.rand()
+    g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, "vhs", device=0)
+    g.scanlines = 0
+    g.srand([seed] * n)                                   # entry 0 is the one that counts
+    par = [shard.field_parity(k) for k in range(n)]
+    s = crtlib.Settings(_padded(frames), format=crtlib.FMT_BGRA, field=[a for a, _ in par], frame=[b for _, b in par])
+    s.draw_aberration = aberration
+    passes = g.sequence(s, noise)
+    g.synchronize()
+    out = g.out.cpu().numpy()
+    # with the aberration band the last lines lose their sync pulse and their filter windows run past inp[] (UB in
+    # the reference, DESIGN.md section 2): their rows are not part of the contract
+    keep = outh - 12 if aberration else outh
+    for k in range(n):
+        o, hs, vs, rn = want[k]
+        assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), "field %d state" % k
+        np.testing.assert_array_equal(out[k][:keep], o.reshape(outh, outw, 4)[:keep], err_msg="vhs sequence field %d" % k)
+    hist = g.vhs_hist.cpu().numpy().view(np.uint32)
+    got_next = ((int(hist[n - 1, 0]) + int(hist[n - 1, 28])) & 0xffffffff) >> 1
+    assert got_next == next_rand, "the generator after the last field is not where libc's is"
+    g.close()
+
+
 @pytest.mark.parametrize("overlap,tile", [(2, 0), (4, 32), (3, 16)])
 def test_tuning_switches_do_not_change_results(crtlib, overlap, tile):
     """crthip_set_overlap (two-stream chunking) and crthip_set_pixel_tile only re-arrange the work"""
