@@ -540,6 +540,44 @@ def test_random_configurations(crtlib, seed):
     _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2)
 
 
+def test_fieldpass_is_graph_capturable(crtlib):
+    """crthip_fieldpass only enqueues kernels on the context's stream (no allocation, no synchronisation once the
+    workspace is reserved), so a caller can capture the launch sequence into a HIP graph and replay it."""
+    import torch
+    n, w, h = 6, 640, 480
+    imgs = np.stack([R.synth_image(w, h, 4, 40 + k) for k in range(n)])
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+    g.scanlines = 1
+    s = crtlib.Settings(_padded(imgs), format=crtlib.FMT_BGRA, field=[k & 1 for k in range(n)], frame=0)
+    p = g.params(s, 24)
+    g.reserve(n)
+    side = torch.cuda.Stream()
+    g.use_stream(side)
+    # eager: two consecutive field-passes (state carries over)
+    g._load_field_state(s)
+    torch.cuda.synchronize()
+    state0 = g.state.clone()
+    eager = []
+    for _ in range(2):
+        g.fieldpass(s, 24, params=p)
+        g.synchronize()
+        eager.append((g.out.clone(), g.state.clone()))
+    # captured: the same launch sequence, replayed twice from the same initial state
+    g.state.copy_(state0)
+    g.out.zero_()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        g.fieldpass(s, 24, params=p)
+    for k in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g.out, eager[k][0]), "replay %d: picture differs from the eager launch sequence" % k
+        assert torch.equal(g.state, eager[k][1]), "replay %d: state differs" % k
+    g.use_stream(None)
+    g.close()
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
