@@ -72,6 +72,16 @@ def test_host_setup_matches_oracle(lib, name):
     assert p.dx == ((orc.av_len - 1) << 12) // 832
 
 
+def test_fir_flag_is_validated_by_finalize(lib):
+    """CRTHIP_F_EQ_FIR(taps): 0 (stock equaliser) and the four kernels of crt_core.c:130-147 only"""
+    for taps in (0, 4, 5, 6, 7):
+        p = lib.make_params("ntsc", w=64, h=48, outw=64, outh=48, flags=taps << 8)
+        assert p.eq_kernel == taps
+    for taps in (1, 2, 3):
+        with pytest.raises(ValueError):
+            lib.make_params("ntsc", w=64, h=48, outw=64, outh=48, flags=taps << 8)
+
+
 def test_sincos14_host_matches_oracle(lib):
     L = lib.load_library()
     orc = R.Oracle("ntsc")
