@@ -23,4 +23,20 @@ for seed in range(first, first + count):
     except Exception as e:
         bad += 1
         print("SEED", seed, case[:8], "FAILED:", str(e).splitlines()[0][:200])
-print("soak: %d cases, %d failures" % (count, bad))
+# NES: random output sizes / knobs through the NES parity test (table encoder, 3-line chroma period, dot crawl)
+nes_bad = 0
+nes_count = max(1, count // 10)
+for seed in range(first, first + nes_count):
+    rng = np.random.default_rng(seed ^ 0x5e5)
+    knobs = dict(hue=int(rng.integers(-360, 720)), brightness=int(rng.integers(-40, 40)), contrast=int(rng.integers(0, 400)),
+                 saturation=int(rng.integers(-5, 40)), black_point=int(rng.integers(-10, 10)), white_point=int(rng.integers(50, 150)),
+                 scanlines=int(rng.integers(0, 2)), blend=int(rng.integers(0, 2)))
+    case = (str(rng.choice(["nes", "nesp0"])), int(rng.choice([1, 33, 256, 640, 768, 1283])), int(rng.choice([240, 241, 480, 500, 720])),
+            int(rng.choice([0, 1, 24, 77, 300])), knobs)
+    T.NES_CASES.append(case)
+    try:
+        T.test_nes_parity(crtlib, len(T.NES_CASES) - 1, bool(seed & 1))
+    except Exception as e:
+        nes_bad += 1
+        print("NES SEED", seed, case, "FAILED:", str(e).splitlines()[0][:200])
+print("soak: %d NTSC-family cases, %d failures; %d NES cases, %d failures" % (count, bad, nes_count, nes_bad))
