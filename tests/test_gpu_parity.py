@@ -540,6 +540,43 @@ def test_random_configurations(crtlib, seed):
     _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2)
 
 
+def test_full_size_batch_properties(crtlib):
+    """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24): (a) replication -- fields
+    that carry the same image, parity and state produce the same picture and state wherever they sit in the batch;
+    (b) a checksum over all pictures is reproducible from run to run; (c) sampled fields equal the oracle."""
+    import torch
+    n, w, h, uniq = 4096, 640, 480, 8
+    base = np.stack([R.synth_image(w, h, 4, 7000 + k) for k in range(uniq)])
+    imgs = torch.from_numpy(np.concatenate([base, base[:, -1:]], axis=1)).to("cuda:0")       # + the spare row
+    data = imgs.repeat(n // uniq, 1, 1, 1)[:, :h]
+    fields = [(k // uniq) & 1 for k in range(n)]                  # parity changes every 8 fields
+    sums = []
+    for run in range(2):
+        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+        g.scanlines = 1
+        s = crtlib.Settings(data, format=crtlib.FMT_BGRA, field=list(fields), frame=0)
+        g.fieldpass(s, 24)
+        g.synchronize()
+        out, st = g.out, g.state
+        # (a) field k and field k + 16 share image (k % 8) and parity ((k // 8) & 1)
+        assert torch.equal(out[:-16], out[16:]), "replicated fields differ"
+        assert torch.equal(st[:-16], st[16:])
+        sums.append(int(out.to(torch.int64).sum().item()) ^ int(st.to(torch.int64).sum().item()))
+        if run == 0:
+            host = out[[0, 9, 2055, 4095]].cpu().numpy()
+        g.close()
+    assert sums[0] == sums[1]
+    orc = R.Oracle("ntsc")
+    for j, k in enumerate((0, 9, 2055, 4095)):
+        c = orc.new_crt(w, h, R.FMT_BGRA)
+        c.set("scanlines", 1)
+        c.settings(np.concatenate([base[k % uniq], base[k % uniq][-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1,
+                   field=fields[k], frame=0)
+        c.modulate()
+        c.demodulate(24)
+        np.testing.assert_array_equal(host[j].reshape(-1), c.out, err_msg="field %d of the full batch" % k)
+
+
 def test_fieldpass_is_graph_capturable(crtlib):
     """crthip_fieldpass only enqueues kernels on the context's stream (no allocation, no synchronisation once the
     workspace is reserved), so a caller can capture the launch sequence into a HIP graph and replay it."""
