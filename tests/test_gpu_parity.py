@@ -540,40 +540,42 @@ def test_random_configurations(crtlib, seed):
     _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2)
 
 
-def test_full_size_batch_properties(crtlib):
-    """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24): (a) replication -- fields
-    that carry the same image, parity and state produce the same picture and state wherever they sit in the batch;
-    (b) a checksum over all pictures is reproducible from run to run; (c) sampled fields equal the oracle."""
+@pytest.mark.parametrize("n,w,h,noise", [(4096, 640, 480, 24), (64, 1920, 1080, 0)])
+def test_full_size_batch_properties(crtlib, n, w, h, noise):
+    """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24) and configs[2]'s per-GPU
+    share (512 frames of 1920x1080 over 8 GPUs = 64, noise 0): (a) replication -- fields that carry the same image,
+    parity and state produce the same picture and state wherever they sit in the batch; (b) a checksum over all
+    pictures is reproducible from run to run; (c) sampled fields equal the oracle."""
     import torch
-    n, w, h, uniq = 4096, 640, 480, 8
+    uniq = 8 if w <= 640 else 2                           # (synthesising 1080p images on the host is slow)
     base = np.stack([R.synth_image(w, h, 4, 7000 + k) for k in range(uniq)])
     imgs = torch.from_numpy(np.concatenate([base, base[:, -1:]], axis=1)).to("cuda:0")       # + the spare row
     data = imgs.repeat(n // uniq, 1, 1, 1)[:, :h]
-    fields = [(k // uniq) & 1 for k in range(n)]                  # parity changes every 8 fields
+    fields = [(k // uniq) & 1 for k in range(n)]                  # parity changes every `uniq` fields
     sums = []
     for run in range(2):
         g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
         g.scanlines = 1
         s = crtlib.Settings(data, format=crtlib.FMT_BGRA, field=list(fields), frame=0)
-        g.fieldpass(s, 24)
+        g.fieldpass(s, noise)
         g.synchronize()
         out, st = g.out, g.state
-        # (a) field k and field k + 16 share image (k % 8) and parity ((k // 8) & 1)
-        assert torch.equal(out[:-16], out[16:]), "replicated fields differ"
-        assert torch.equal(st[:-16], st[16:])
+        # (a) field k and field k + 2 * uniq share image (k % uniq) and parity ((k // uniq) & 1)
+        assert torch.equal(out[:-2 * uniq], out[2 * uniq:]), "replicated fields differ"
+        assert torch.equal(st[:-2 * uniq], st[2 * uniq:])
         sums.append(int(out.to(torch.int64).sum().item()) ^ int(st.to(torch.int64).sum().item()))
         if run == 0:
-            host = out[[0, 9, 2055, 4095]].cpu().numpy()
+            host = out[[0, 9, n // 2 + 7, n - 1]].cpu().numpy()
         g.close()
     assert sums[0] == sums[1]
     orc = R.Oracle("ntsc")
-    for j, k in enumerate((0, 9, 2055, 4095)):
+    for j, k in enumerate((0, 9, n // 2 + 7, n - 1)):
         c = orc.new_crt(w, h, R.FMT_BGRA)
         c.set("scanlines", 1)
         c.settings(np.concatenate([base[k % uniq], base[k % uniq][-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1,
                    field=fields[k], frame=0)
         c.modulate()
-        c.demodulate(24)
+        c.demodulate(noise)
         np.testing.assert_array_equal(host[j].reshape(-1), c.out, err_msg="field %d of the full batch" % k)
 
 
