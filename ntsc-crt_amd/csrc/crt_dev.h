@@ -290,14 +290,15 @@ struct ProfScope {
     ProfScope(crthip_ctx *ctx, int kernel) : c(ctx), k(kernel), on(ctx->prof)
     {
         if (on) {
-            hipEventCreate(&a); hipEventCreate(&b);
-            hipEventRecord(a, c->stream);
+            /* profiling is best effort: a failed event simply drops this sample (crthip_profile_read checks) */
+            (void) hipEventCreate(&a); (void) hipEventCreate(&b);
+            (void) hipEventRecord(a, c->stream);
         }
     }
     ~ProfScope()
     {
         if (!on) return;
-        hipEventRecord(b, c->stream);
+        (void) hipEventRecord(b, c->stream);
         if (c->npend == c->cappend) {
             int ncap = c->cappend ? c->cappend * 2 : 64;
             c->pend = (crthip_ctx::Pending *) realloc(c->pend, sizeof(*c->pend) * (size_t) ncap);
