@@ -205,7 +205,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     s_src[lane] = (unsigned long long) (inp + (size_t) f * fstride + (act ? lp.pos : 0));
     s_dst[lane] = (unsigned long long) (outp + (size_t) f * ostride + (size_t) (act ? lp.beg : 0) * pitch);
     s_nrows[lane] = nrows;
-    __syncthreads();
+    wave_lds_fence();
 
     const int w0 = lp.wave0, w1 = lp.wave1, nw0 = -lp.wave0, nw1 = -lp.wave1;
     const int bright = P.bright, contrast = P.contrast;
@@ -249,13 +249,13 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     constexpr int NT = (NQ + IN_TILE_DW - 1) / IN_TILE_DW;
     for (int t = 0; t < NT; t++) {
         /* stash tile t (already in registers), then start fetching tile t+1 */
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < IN_PIECES; i++) {
             unsigned *d = s_in + (i * IN_ROWS + in_row) * IN_STRIDE + in_piece * 4;
             d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
         }
-        __syncthreads();
+        wave_lds_fence();
         if (t + 1 < NT) {
 #pragma unroll
             for (int i = 0; i < IN_PIECES; i++) {
@@ -310,7 +310,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                         /* drain the pixel tile: pixels [px0, px0+cnt) of every row, + D10 duplicates (:661-664) */
                         const int px0 = px & ~(PX_TILE - 1);
                         const int cnt = px - px0 + 1;
-                        __syncthreads();
+                        wave_lds_fence();
                         if (!BPP3) {
                             const int orow_ = lane / PX_PIECES, piece = lane % PX_PIECES;  /* 4 pixels = 16 bytes per piece */
                             const int have = cnt - piece * 4;                      /* pixels of this piece that exist */
@@ -373,7 +373,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                 }
                             }
                         }
-                        __syncthreads();
+                        wave_lds_fence();
                     }
                     ppos += dx;
                     next_x = (int) (ppos >> 12) + 1;

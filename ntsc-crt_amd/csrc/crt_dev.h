@@ -132,6 +132,18 @@ __device__ __forceinline__ void store16u(void *p, v4i v) { ((unaligned16 *) p)->
 __device__ __forceinline__ int load4u(const void *p) { return ((const unaligned4 *) p)->v; }
 __device__ __forceinline__ void store4u(void *p, int v) { ((unaligned4 *) p)->v = v; }
 
+/* Ordering point between the two phases of an LDS tile in a kernel whose workgroup is ONE wave.  The LDS unit
+ * executes a wave's ds_* instructions in order, so lane A's write is visible to lane B's later read without any
+ * barrier; what is needed is only that the compiler keeps the program order.  __syncthreads() would do, but it
+ * also emits s_waitcnt vmcnt(0): every tile hand-over then waits for ALL outstanding global memory operations,
+ * in the decoder the stores of the previous drain. */
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int posmod(int x, int n) { return ((x % n) + n) % n; }  /* crt_core.c:17 */
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
