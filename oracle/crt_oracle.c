@@ -121,30 +121,37 @@ iir_coef(int freq, int limit)
 void
 orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
 {
-    static const int khz[3][2] = { {1500, 3000}, {80, 1150}, {80, 1000} }; /* crt_core.c:278-280 */
-    static const int gains[3][3] = { {65536, 8192, 9175}, {65536, 65536, 1311}, {65536, 65536, 0} };
+    static const int khz[3][2] = { {1500, 3000}, {80, 1150}, {80, 1000} }; /* crt_core.c:272-286 */
+    static const int gains4[3][3] = { {65536, 8192, 9175}, {65536, 65536, 1311}, {65536, 65536, 0} };
+    static const int gains5[3][3] = { {65536, 12192, 7775}, {65536, 65536, 1311}, {65536, 65536, 0} };
     const int l_freq = 1431818;
     int cc_line, k, b, sn, cs;
+    int yf = 420000, ifr = 150000, qf = 55000;       /* crt_ntsc.h:99-102 and every other RGB header */
 
     memset(sys, 0, sizeof(*sys));
     sys->system = system;
     sys->chroma_pattern = chroma_pattern;
     sys->vres = 262;
-    if (system == ORC_SYS_NES) {
-        /* crt_nes.h:30-64, 94-126 */
+    sys->cc_samples = 4;
+    sys->cb_len = 40;                                /* CB_CYCLES 10 * CRT_CB_FREQ 4 */
+    if (system == ORC_SYS_NES || system == ORC_SYS_NESRGB || system == ORC_SYS_SNES) {
+        /* crt_nes.h:30-126, crt_nesrgb.h (same timing, WHITE_LEVEL 100), crt_snes.h:24-116 (same PPU-pixel timing,
+         * NTSC levels): positions in PPU pixels on a 341 px line */
         const int line_px = 9 + 25 + 4 + 15 + 5 + 1 + 15 + 256 + 11; /* 341 */
-        cc_line = chroma_pattern == 1 ? 2275 : (chroma_pattern == 2 ? 2273 : 2280);
+        cc_line = system == ORC_SYS_SNES ? 2273 : (chroma_pattern == 1 ? 2275 : (chroma_pattern == 2 ? 2273 : 2280));
         sys->hres = cc_line * 4 / 10;
         sys->top = 15;
         sys->bot = 255;
         sys->cc_vper = 3;
         sys->hsync_window = 6;
         sys->vsync_window = 6;
-        sys->white_level = 110;
-        sys->burst_level = 30;
-        sys->black_level = 0;
+        if (system == ORC_SYS_SNES) {
+            sys->white_level = 100; sys->burst_level = 20; sys->black_level = 7; sys->sync_level = -40;
+        } else {
+            sys->white_level = system == ORC_SYS_NES ? 110 : 100;
+            sys->burst_level = 30; sys->black_level = 0; sys->sync_level = -37;
+        }
         sys->blank_level = 0;
-        sys->sync_level = -37;
 #define PPU2POS(p) ((p) * sys->hres / line_px)
         sys->sync_beg = PPU2POS(9);
         sys->bw_beg = PPU2POS(9 + 25);
@@ -154,15 +161,34 @@ orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
         sys->av_len = PPU2POS(256);
         sys->vs_sep_end = PPU2POS(327);  /* crt_nes.c:95 */
 #undef PPU2POS
+    } else if (system == ORC_SYS_PV1K) {
+        /* crt_pv1k.h:24-98: 5 samples per chroma cycle, times in units of 4 dots (892 ns) */
+        const int d4 = 892;
+        const int line_ns = (3 + 3 + 2 + 4 + 4 + 55) * d4;
+        sys->hres = 2304 * 5 / 6;
+        sys->top = 21;
+        sys->bot = 261;
+        sys->cc_vper = 5;
+        sys->cc_samples = 5;
+        sys->cb_len = 50;
+        sys->hsync_window = 8;
+        sys->vsync_window = 8;
+        sys->white_level = 100; sys->burst_level = 20; sys->black_level = 7; sys->blank_level = 0; sys->sync_level = -40;
+#define NS2POS(ns) ((ns) * sys->hres / line_ns)
+        sys->sync_beg = NS2POS(3 * d4);
+        sys->bw_beg = NS2POS(6 * d4);
+        sys->cb_beg = NS2POS(8 * d4);
+        sys->av_beg = NS2POS(16 * d4);
+        sys->av_len = NS2POS(55 * d4);
+#undef NS2POS
     } else {
-        /* crt_ntsc.h:25-109 (crt_ntscvhs.h identical except Y/I/Q_FREQ) */
+        /* crt_ntsc.h:25-109 (crt_ntscvhs.h identical except Y/I/Q_FREQ; crt_template.h: CC_LINE 2275, VPER 2) */
         const int line_ns = 1500 + 4700 + 600 + 2500 + 1600 + 52600; /* 63500 */
-        int yf, ifr, qf;
-        cc_line = chroma_pattern == 1 ? 2275 : 2280;
+        cc_line = (system == ORC_SYS_TEMP || chroma_pattern == 1) ? 2275 : 2280;
         sys->hres = cc_line * 4 / 10;
         sys->top = 21;
         sys->bot = 261;
-        sys->cc_vper = 1;
+        sys->cc_vper = system == ORC_SYS_TEMP ? 2 : 1;
         sys->hsync_window = 8;
         sys->vsync_window = 8;
         sys->white_level = 100;
@@ -178,7 +204,28 @@ orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
         sys->av_len = NS2POS(52600);
 #undef NS2POS
         if (system == ORC_SYS_VHS) { yf = 300000; ifr = 62700; qf = 62700; } /* VHS_SP, crt_ntscvhs.h:109-113 */
-        else { yf = 420000; ifr = 150000; qf = 55000; }                        /* crt_ntsc.h:99-102 */
+    }
+    /* what differs between the RGB encoders (crt_ntsc.c / crt_ntscvhs.c / crt_snes.c / crt_template.c / crt_pv1k.c /
+     * crt_nesrgb.c) */
+    sys->enc_bandlimit = system == ORC_SYS_NTSC || system == ORC_SYS_VHS || system == ORC_SYS_TEMP || system == ORC_SYS_PV1K;
+    sys->enc_field_rows = sys->enc_bandlimit;        /* the same four systems: crt_ntsc.c:258, crt_template.c:255, crt_pv1k.c:243 */
+    sys->enc_line_rows = system == ORC_SYS_SNES || system == ORC_SYS_TEMP || system == ORC_SYS_PV1K || system == ORC_SYS_NESRGB;
+    sys->vert_step = sys->cc_vper > 1 ? 360 / sys->cc_vper : 0;
+    if (system == ORC_SYS_PV1K) sys->vert_step = 360 * 2 / 5;                 /* crt_pv1k.c:168 */
+    sys->burst_off = 33; sys->q_off = -90;                                     /* crt_ntsc.c:177-182 */
+    if (system == ORC_SYS_SNES) { sys->burst_off = 210 - 90; sys->q_off = -90; }   /* crt_snes.c:176-181: n - step + HUE_OFFSET */
+    if (system == ORC_SYS_TEMP) { sys->burst_off = -60 - 90; sys->q_off = -90; }   /* crt_template.c:176-181 */
+    if (system == ORC_SYS_PV1K) { sys->burst_off = -72; sys->q_off = 90; }         /* crt_pv1k.c:172-177 */
+    if (system == ORC_SYS_NESRGB) { sys->burst_off = 90 + 33; sys->q_off = -90; }  /* crt_nesrgb.c:72-77 */
+    sys->equ_a_lo = 0; sys->equ_a_hi = 3; sys->equ_b_lo = 7; sys->equ_b_hi = 9;   /* crt_ntsc.c:211 */
+    sys->vs_lo = 4; sys->vs_hi = 6; sys->vs_by_field = 1;                          /* crt_ntsc.c:217-223 */
+    if (system == ORC_SYS_SNES || system == ORC_SYS_TEMP) {                        /* crt_snes.h:137-146 */
+        sys->equ_a_hi = 2; sys->vs_lo = 3; sys->vs_by_field = system == ORC_SYS_TEMP;
+    }
+    if (system == ORC_SYS_PV1K) {                                                  /* crt_pv1k.c:197,204 */
+        sys->equ_a_lo = 0; sys->equ_a_hi = -1; sys->vs_lo = 258; sys->vs_hi = 260;
+    }
+    if (sys->enc_bandlimit) {
         sys->iir_c[0] = iir_coef(l_freq, yf);
         sys->iir_c[1] = iir_coef(l_freq, ifr);
         sys->iir_c[2] = iir_coef(l_freq, qf);
@@ -188,7 +235,7 @@ orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
     sys->hsync_thresh = 4 * sys->sync_level;
     sys->vsync_thresh = 94 * sys->sync_level;
 
-    /* crt_core.c:171-196 init_eq with EQ_P 16, called from crt_init :272-280 */
+    /* crt_core.c:171-196 init_eq with EQ_P 16, called from crt_init :272-286 */
     for (k = 0; k < 3; k++) {
         int f_lo = sys->hres * (khz[k][0] * 100) / l_freq;
         int f_hi = sys->hres * (khz[k][1] * 100) / l_freq;
@@ -196,9 +243,10 @@ orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
         sys->eq_lf[k] = 2 * (sn << 1);
         orc_sincos14(&sn, &cs, 8192 * f_hi / sys->hres);
         sys->eq_hf[k] = 2 * (sn << 1);
-        for (b = 0; b < 3; b++) sys->eq_g[k][b] = gains[k][b];
+        for (b = 0; b < 3; b++) sys->eq_g[k][b] = sys->cc_samples == 5 ? gains5[k][b] : gains4[k][b];
     }
     sys->eq_kernel = 0;
+    sys->do_bloom = 0;
 }
 
 /* crt_core.c:241-289 crt_init = memset + crt_resize + crt_reset + rn seed */
@@ -245,61 +293,89 @@ fetch_rgb(const uint8_t *p, int format, int *r, int *g, int *b)
     }
 }
 
-/* crt_ntsc.c:128-330 and crt_ntscvhs.c:129-338 */
+/* RGB -> YIQ, Q14 (crt_ntsc.c:306-310, identical in every RGB encoder) */
+static void
+rgb_to_yiq(int r, int g, int b, int *fy, int *fi, int *fq)
+{
+    *fy = (19595 * r + 38470 * g + 7471 * b) >> 14;
+    *fi = (39059 * r - 18022 * g - 21103 * b) >> 14;
+    *fq = (13894 * r - 34275 * g + 20382 * b) >> 14;
+}
+
+/* The RGB encoders: crt_ntsc.c:128-330, crt_ntscvhs.c:129-338, crt_snes.c:125-327, crt_template.c:125-337,
+ * crt_pv1k.c:121-321.  They are one routine with the per-system switches of struct orc_sys. */
 static void
 modulate_rgb(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *s)
 {
-    const int hres = sys->hres;
+    const int hres = sys->hres, ccs = sys->cc_samples, vper = sys->cc_vper;
     int destw = sys->av_len;
     int desth = (sys->lines * 64500) >> 16;
-    int burst[4], modI[4], modQ[4], preset[4] = { 0, 0, 0, 0 };
-    int x, y, n, k, xo, yo, bpp, inv_phase, ph, sn, cs, aberration = 0;
+    int burst[ORC_MAX_VPER][ORC_MAX_CCS], modI[ORC_MAX_VPER][ORC_MAX_CCS], modQ[ORC_MAX_VPER][ORC_MAX_CCS];
+    int preset[ORC_MAX_VPER][ORC_MAX_CCS];
+    int x, y, n, k, xo, yo, bpp, inv_phase = 0, ph = 1, sn, cs, aberration = 0;
     int white;
     const uint8_t *data = (const uint8_t *) s->data;
 
-    s->initialized = 1;                              /* M0, :142-147 (coefs live in sys) */
-    if (s->raw) {                                    /* M1, :163-172 */
+    memset(preset, 0, sizeof(preset));
+    s->initialized = 1;                              /* M0, crt_ntsc.c:142-147 (coefs live in sys) */
+    if (sys->do_bloom) {                             /* M1, crt_ntsc.c:148-161 */
+        destw = (sys->av_len * 55500) >> 16;
+        desth = (sys->lines * 63500) >> 16;
+        if (s->raw) {
+            destw = s->w < destw ? s->w : destw;
+            desth = s->h < desth ? s->h : desth;
+        }
+    } else if (s->raw) {                             /* crt_ntsc.c:163-172 */
         destw = s->w < sys->av_len ? s->w : sys->av_len;
         desth = s->h < desth ? s->h : desth;
     }
-    for (k = 0; k < 4; k++) {                        /* M2, :174-188 */
-        if (s->as_color) {
-            int ang = s->hue + k * 90;
-            orc_sincos14(&sn, &cs, (ang + 33) * 8192 / 180);
-            burst[k] = sn >> 10;
-            orc_sincos14(&sn, &cs, ang * 8192 / 180);
-            modI[k] = sn >> 10;
-            orc_sincos14(&sn, &cs, (ang - 90) * 8192 / 180);
-            modQ[k] = sn >> 10;
-        } else {
-            burst[k] = modI[k] = modQ[k] = 0;
+    memset(burst, 0, sizeof(burst));
+    memset(modI, 0, sizeof(modI));
+    memset(modQ, 0, sizeof(modQ));
+    if (s->as_color) {                               /* M2 */
+        const int step = 360 / ccs;
+        for (y = 0; y < vper; y++) {
+            /* crt_ntsc.c:174-188 (one row);  crt_snes.c:171-183, crt_pv1k.c:167-179 (one row per line class) */
+            int vert = sys->enc_line_rows ? (y + s->dot_crawl_offset) * sys->vert_step : 0;
+            for (k = 0; k < ccs; k++) {
+                int ang = vert + s->hue + k * step;
+                orc_sincos14(&sn, &cs, (ang + sys->burst_off) * 8192 / 180);
+                burst[y][k] = sn >> 10;
+                orc_sincos14(&sn, &cs, ang * 8192 / 180);
+                modI[y][k] = sn >> 10;
+                orc_sincos14(&sn, &cs, (ang + sys->q_off) * 8192 / 180);
+                modQ[y][k] = sn >> 10;
+            }
         }
     }
     bpp = orc_bpp4fmt(s->format);
-    if (bpp == 0) return;                            /* :190-193 */
+    if (bpp == 0) return;                            /* crt_ntsc.c:190-193 */
 
-    xo = sys->av_beg + s->xoffset + (sys->av_len - destw) / 2;   /* M3, :194-203 */
+    xo = sys->av_beg + s->xoffset + (sys->av_len - destw) / 2;   /* M3, crt_ntsc.c:194-203 */
     yo = sys->top + s->yoffset + (sys->lines - desth) / 2;
     s->field &= 1;
     s->frame &= 1;
-    inv_phase = (s->field == s->frame);
-    if (sys->chroma_pattern == 1) ph = (inv_phase & 1) ? -1 : 1;
-    else ph = 1;
-    xo &= ~3;
+    if (!sys->enc_line_rows) {
+        inv_phase = (s->field == s->frame);
+        if (sys->chroma_pattern == 1) ph = (inv_phase & 1) ? -1 : 1;
+        xo &= ~3;
+    } else {
+        xo = xo - (xo % ccs);                        /* crt_snes.c:201 */
+    }
 
     if (sys->system == ORC_SYS_VHS && s->do_aberration) {         /* crt_ntscvhs.c:205-207 */
         aberration = ((rand() % 12) - 8) + 14;
     }
 
-    for (n = 0; n < sys->vres; n++) {                /* M4, :205-252 */
+    for (n = 0; n < sys->vres; n++) {                /* M4, crt_ntsc.c:205-252 */
         int8_t *line = v->analog + n * hres;
-        if (n <= 3 || (n >= 7 && n <= 9)) {          /* equalising pulses */
+        if ((n >= sys->equ_a_lo && n <= sys->equ_a_hi) || (n >= sys->equ_b_lo && n <= sys->equ_b_hi)) {   /* equalising pulses */
             fill_run(line, 0, 4 * hres / 100, sys->sync_level);
             fill_run(line, 4 * hres / 100, 50 * hres / 100, sys->blank_level);
             fill_run(line, 50 * hres / 100, 54 * hres / 100, sys->sync_level);
             fill_run(line, 54 * hres / 100, hres, sys->blank_level);
-        } else if (n >= 4 && n <= 6) {               /* vertical sync, field-dependent */
-            int a = (s->field == 1 ? 4 : 46) * hres / 100;
+        } else if (n >= sys->vs_lo && n <= sys->vs_hi) {   /* vertical sync, field-dependent where the system says so */
+            int a = ((sys->vs_by_field && s->field == 1) ? 4 : 46) * hres / 100;
             fill_run(line, 0, a, sys->sync_level);
             fill_run(line, a, 50 * hres / 100, sys->blank_level);
             fill_run(line, 50 * hres / 100, 96 * hres / 100, sys->sync_level);
@@ -313,44 +389,133 @@ modulate_rgb(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *
             }
             fill_run(line, t0, sys->av_beg, sys->blank_level);
             if (n < sys->top) fill_run(line, sys->av_beg, hres, sys->blank_level);
-            for (k = sys->cb_beg; k < sys->cb_beg + 40; k++) {
-                int cb = sys->chroma_pattern == 1 ? burst[(k + inv_phase * 2) % 4] : burst[k % 4];
+            for (k = sys->cb_beg; k < sys->cb_beg + sys->cb_len; k++) {
+                int cb;
+                if (sys->enc_line_rows) cb = burst[n % vper][k % ccs];                     /* crt_snes.c:238 */
+                else cb = sys->chroma_pattern == 1 ? burst[0][(k + inv_phase * 2) % 4] : burst[0][k % 4];
                 line[k] = (int8_t) ((sys->blank_level + cb * sys->burst_level) >> 5);
-                preset[k % 4] = line[k];
+                if (sys->enc_line_rows) preset[(n + 3) % vper][k % ccs] = line[k];        /* crt_snes.c:240 */
+                else preset[0][k % 4] = line[k];
             }
         }
     }
     if (sys->system == ORC_SYS_VHS) v->hsync = 0;   /* crt_ntscvhs.c:258-259 */
 
     white = sys->white_level * v->white_point / 100;
-    for (y = 0; y < desth; y++) {                    /* M5, :254-324 */
+    for (y = 0; y < desth; y++) {                    /* M5, crt_ntsc.c:254-324 */
         int hy = 0, hi = 0, hq = 0;                  /* the three 1-pole states, reset per line */
-        int field_offset = (s->field * s->h + desth) / desth / 2;
+        int field_offset = sys->enc_field_rows ? (s->field * s->h + desth) / desth / 2 : 0;
         int sy = (y * s->h) / desth + field_offset;
-        if (sy >= s->h) sy = s->h;                   /* (sic) :263 */
+        int row = sys->enc_line_rows ? (y + yo) % vper : 0;       /* crt_snes.c:258 */
+        if (sy >= s->h) sy = s->h;                   /* (sic) crt_ntsc.c:263 */
         sy *= s->w;
         for (x = 0; x < destw; x++) {
             int r, g, b, fy, fi, fq, ire, xoff;
             fetch_rgb(data + (((x * s->w) / destw) + sy) * bpp, s->format, &r, &g, &b);
-            fy = (19595 * r + 38470 * g + 7471 * b) >> 14;
-            fi = (39059 * r - 18022 * g - 21103 * b) >> 14;
-            fq = (13894 * r - 34275 * g + 20382 * b) >> 14;
+            rgb_to_yiq(r, g, b, &fy, &fi, &fq);
             ire = sys->black_level + v->black_point;
-            xoff = (x + xo) % 4;
-            hy += ((fy - hy) * sys->iir_c[0]) >> 11; /* iirf, :117-126 */
-            hi += ((fi - hi) * sys->iir_c[1]) >> 11;
-            hq += ((fq - hq) * sys->iir_c[2]) >> 11;
+            xoff = (x + xo) % ccs;
+            if (sys->enc_bandlimit) {                /* iirf, crt_ntsc.c:117-126 */
+                hy += ((fy - hy) * sys->iir_c[0]) >> 11;
+                hi += ((fi - hi) * sys->iir_c[1]) >> 11;
+                hq += ((fq - hq) * sys->iir_c[2]) >> 11;
+            } else {                                 /* crt_snes.c:113-122 with CRT_DO_BANDLIMITING 0 */
+                hy = fy; hi = fi; hq = fq;
+            }
             fy = hy;
-            fi = hi * ph * modI[xoff] >> 4;
-            fq = hq * ph * modQ[xoff] >> 4;
+            if (sys->enc_line_rows) {
+                fi = hi * modI[row][xoff] >> 4;
+                fq = hq * modQ[row][xoff] >> 4;
+            } else {
+                fi = hi * ph * modI[0][xoff] >> 4;
+                fq = hq * ph * modQ[0][xoff] >> 4;
+            }
             ire += (fy + fi + fq) * white >> 10;
             if (ire < 0) ire = 0;
             if (ire > 110) ire = 110;
             v->analog[(x + xo) + (y + yo) * hres] = (int8_t) ire;
         }
     }
-    for (k = 0; k < 4; k++) {                        /* M6, :325-329 / vhs :332-336 */
-        v->ccf[0][k] = sys->system == ORC_SYS_VHS ? 0 : preset[k] << 7;
+    for (n = 0; n < vper; n++) {                     /* M6, crt_ntsc.c:325-329 / vhs :332-336 / crt_snes.c:321-325 */
+        for (k = 0; k < ccs; k++) v->ccf[n][k] = sys->system == ORC_SYS_VHS ? 0 : preset[n][k] << 7;
+    }
+}
+
+/* sync skeleton of the NES-timed systems, crt_nes.c:81-104 / crt_nesrgb.c:24-46 (setup_field) */
+static void
+nes_setup_field(const struct orc_sys *sys, struct orc_crt *v)
+{
+    int n;
+    for (n = 0; n < sys->vres; n++) {
+        int8_t *line = v->analog + n * sys->hres;
+        fill_run(line, 0, sys->sync_beg, sys->blank_level);
+        fill_run(line, sys->sync_beg, n >= 259 ? sys->vs_sep_end : sys->bw_beg, sys->sync_level);
+        fill_run(line, n >= 259 ? sys->vs_sep_end : sys->bw_beg, sys->hres, sys->blank_level);
+    }
+}
+
+/* crt_nesrgb.c:48-170: an RGB image encoded with the NES's line timing; no band limit, progressive */
+static void
+modulate_nesrgb(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *s)
+{
+    const int hres = sys->hres;
+    const uint8_t *data = (const uint8_t *) s->data;
+    int burst[3][4], modI[3][4], modQ[3][4], preset[3][4];
+    int x, y, n, k, xo, yo, sn, cs, bpp, white;
+
+    memset(preset, 0, sizeof(preset));
+    if (!s->initialized) {
+        nes_setup_field(sys, v);
+        s->initialized = 1;
+    }
+    for (y = 0; y < 3; y++) {                        /* :67-78: the hue only rotates the burst */
+        int rot = (y + s->dot_crawl_offset) * 120;
+        for (k = 0; k < 4; k++) {
+            n = rot + k * 90;
+            orc_sincos14(&sn, &cs, (s->hue + 90 + n + 33) * 8192 / 180);
+            burst[y][k] = sn >> 10;
+            orc_sincos14(&sn, &cs, n * 8192 / 180);
+            modI[y][k] = sn >> 10;
+            orc_sincos14(&sn, &cs, (n - 90) * 8192 / 180);
+            modQ[y][k] = sn >> 10;
+        }
+    }
+    bpp = orc_bpp4fmt(s->format);
+    if (bpp == 0) return;                            /* :80-83 */
+    xo = (sys->av_beg + s->xoffset) & ~3;            /* :85-89 */
+    yo = sys->top + s->yoffset;
+    white = sys->white_level * v->white_point / 100;
+
+    for (y = 0; y < sys->lines; y++) {               /* :91-163 */
+        int sy = (y * s->h) / sys->lines;
+        int8_t *line;
+        if (sy >= s->h) sy = s->h;
+        if (sy < 0) sy = 0;
+        n = y + yo;
+        line = v->analog + n * hres;
+        n %= 3;
+        for (k = sys->cb_beg; k < sys->cb_beg + sys->cb_len; k++) {
+            int cb = burst[n][k % 4];
+            line[k] = (int8_t) ((sys->blank_level + cb * sys->burst_level) >> 5);
+            preset[n][k % 4] = line[k];
+        }
+        sy *= s->w;
+        for (x = 0; x < sys->av_len; x++) {
+            int r, g, b, fy, fi, fq, ire, xoff;
+            fetch_rgb(data + (((x * s->w) / sys->av_len) + sy) * bpp, s->format, &r, &g, &b);
+            rgb_to_yiq(r, g, b, &fy, &fi, &fq);
+            ire = sys->black_level + v->black_point;
+            xoff = (x + xo) % 4;
+            fi = fi * modI[n][xoff] >> 4;
+            fq = fq * modQ[n][xoff] >> 4;
+            ire += (fy + fi + fq) * white >> 10;
+            if (ire < 0) ire = 0;
+            if (ire > 110) ire = 110;
+            v->analog[(x + xo) + (y + yo) * hres] = (int8_t) ire;
+        }
+    }
+    for (n = 0; n < 3; n++) {                        /* :165-169 */
+        for (k = 0; k < 4; k++) v->ccf[n][k] = preset[n][k] << 7;
     }
 }
 
@@ -388,12 +553,7 @@ modulate_nes(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *
 
     memset(preset, 0, sizeof(preset));
     if (!s->initialized) {                           /* setup_field, :81-104 */
-        for (n = 0; n < sys->vres; n++) {
-            int8_t *line = v->analog + n * hres;
-            fill_run(line, 0, sys->sync_beg, sys->blank_level);
-            fill_run(line, sys->sync_beg, n >= 259 ? sys->vs_sep_end : sys->bw_beg, sys->sync_level);
-            fill_run(line, n >= 259 ? sys->vs_sep_end : sys->bw_beg, hres, sys->blank_level);
-        }
+        nes_setup_field(sys, v);
         s->initialized = 1;
     }
     for (y = 0; y < 3; y++) {                        /* :123-130 */
@@ -443,6 +603,7 @@ void
 orc_modulate(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *s)
 {
     if (sys->system == ORC_SYS_NES) modulate_nes(sys, v, s);
+    else if (sys->system == ORC_SYS_NESRGB) modulate_nesrgb(sys, v, s);
     else modulate_rgb(sys, v, s);
 }
 
@@ -592,10 +753,14 @@ store_px(uint8_t *p, int format, int rgb)
 void
 orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, struct orc_line *trace)
 {
-    /* never read past index av_len: crt_core.c:295-297 keeps one spare entry */
+    /* crt_core.c:295-297: function-static, AV_LEN + 1 entries, zero until written.  With CRT_DO_BLOOM the filter
+     * loop stops one sample early (:518, R = scanR >> 12 = AV_LEN - 1), so entry AV_LEN - 1 is never written in a
+     * bloom build and stays 0 -- the array is cleared per call here to model exactly that (entries below the
+     * line's first sample are stale in the reference but never read: the resampler starts at scanL) */
     static int yq[3][2048];
-    const int hres = sys->hres, av_len = sys->av_len;
+    const int hres = sys->hres, av_len = sys->av_len, ccs = sys->cc_samples;
     int bpp, pitch, huesn, huecs, bright, odd_field, ratio, field_rows, line;
+    int max_e = 0, prev_e = 0;
 
     bpp = orc_bpp4fmt(v->out_format);
     if (bpp == 0) return;                                                    /* :312-315 */
@@ -614,6 +779,11 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
     v->rn = orc_stage_noise(sys, v->analog, v->inp, v->rn, noise);           /* D1 */
     stage_vsync(sys, v->inp, &v->vsync, &odd_field);                         /* D2 */
 
+    if (sys->do_bloom) {                                                     /* :399-402 */
+        max_e = (128 + (noise / 2)) * av_len;
+        prev_e = 16384 / 8;
+        memset(yq, 0, sizeof(yq));
+    }
     ratio = (v->outh << 16) / sys->lines;                                    /* D3, :403-407 */
     ratio = (ratio + 32768) >> 16;
     field_rows = odd_field * (ratio / 2);
@@ -622,9 +792,11 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
         struct orc_line *tr = trace ? &trace[line - sys->top] : 0;
         struct eq_state ey, ei, eq;
         const int8_t *sig;
-        int beg, end, ln, acc, i, xpos, ypos, pos, *ccr, align, dci, dcq, wave[4];
-        int dx, npx, px, row;
-        uint8_t *dst;
+        int beg, end, ln, acc, i, xpos, ypos, pos, *ccr, align, dci, dcq;
+        int wave_i[ORC_MAX_CCS], wave_q[ORC_MAX_CCS];
+        int dx, scanl, first, last, row;
+        unsigned upos, scanr;
+        uint8_t *dst, *dst_end;
 
         if (tr) memset(tr, 0, sizeof(*tr));
         /* D4, :428-432.  v_fac is `unsigned`, so the reference evaluates these in
@@ -649,41 +821,76 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
         ypos = POSMOD(line + v->vsync + 3, sys->vres);
         pos = xpos + ypos * hres;
         ccr = v->ccf[ypos % sys->cc_vper];
-        sig = v->inp + ln + (v->hsync & ~3);
-        for (i = sys->cb_beg; i < sys->cb_beg + 40; i++) {
-            ccr[i % 4] = ccr[i % 4] * 127 / 128 + sig[i];
+        sig = v->inp + ln + (ccs == 4 ? (v->hsync & ~3) : v->hsync - (v->hsync % ccs));
+        for (i = sys->cb_beg; i < sys->cb_beg + sys->cb_len; i++) {
+            ccr[i % ccs] = ccr[i % ccs] * 127 / 128 + sig[i];
         }
 
-        align = POSMOD(v->hsync, 4);                                         /* D7, :469-479 */
-        dci = ccr[(align + 1) & 3] - ccr[(align + 3) & 3];
-        dcq = ccr[(align + 2) & 3] - ccr[(align + 0) & 3];
-        wave[0] = ((dci * huecs - dcq * huesn) >> 4) * v->saturation;
-        wave[1] = ((dcq * huecs + dci * huesn) >> 4) * v->saturation;
-        wave[2] = -wave[0];
-        wave[3] = -wave[1];
+        align = POSMOD(v->hsync, ccs);                                       /* D7 */
+        if (ccs == 4) {                                                      /* :471-479 */
+            dci = ccr[(align + 1) & 3] - ccr[(align + 3) & 3];
+            dcq = ccr[(align + 2) & 3] - ccr[(align + 0) & 3];
+            wave_i[0] = ((dci * huecs - dcq * huesn) >> 4) * v->saturation;
+            wave_i[1] = ((dcq * huecs + dci * huesn) >> 4) * v->saturation;
+            wave_i[2] = -wave_i[0];
+            wave_i[3] = -wave_i[1];
+            for (i = 0; i < 4; i++) wave_q[i] = wave_i[(i + 3) & 3];         /* :541-542: Q reads wave[(i + 3) & 3] */
+            if (tr) { tr->wave0 = wave_i[0]; tr->wave1 = wave_i[1]; }
+        } else {                                                             /* :480-510, 5 samples per cycle */
+            int ang = v->hue % 360;
+            int peak_a = align + ccs / 4, peak_b = align, sn, cs;
+            int dci_a = ccr[peak_a % ccs];
+            int dci_b = (ccr[(peak_a + ccs / 2) % ccs] + ccr[(peak_a + ccs / 2 + 1) % ccs]) / 2;
+            int dcq_a = ccr[(peak_b + ccs / 2) % ccs];
+            int dcq_b = ccr[peak_b % ccs];
+            dci = dci_a - dci_b;
+            dcq = dcq_a - dcq_b;
+            for (i = 0; i < ccs; i++) {
+                orc_sincos14(&sn, &cs, ang * 8192 / 180);
+                wave_i[i] = ((dci * cs + dcq * sn) >> 15) * v->saturation;
+                orc_sincos14(&sn, &cs, (ang + 90) * 8192 / 180);
+                wave_q[i] = ((dci * cs + dcq * sn) >> 15) * v->saturation;
+                ang += 360 / ccs;
+            }
+            if (tr) { tr->wave0 = dci; tr->wave1 = dcq; }
+        }
 
+        sig = v->inp + pos;
+        if (sys->do_bloom) {                                                 /* :512-526 */
+            int sum = 0, line_w;
+            for (i = 0; i < av_len; i++) sum += sig[i];
+            prev_e = (prev_e * 123 / 128) + ((((max_e >> 1) - sum) << 10) / max_e);
+            line_w = (av_len * 112 / 128) + (prev_e >> 9);
+            dx = (line_w << 12) / v->outw;
+            scanl = ((av_len / 2) - (line_w >> 1) + 8) << 12;
+            scanr = (unsigned) (av_len - 1) << 12;
+            first = scanl >> 12;
+            last = (int) (scanr >> 12);
+        } else {                                                             /* :528-532 */
+            dx = ((av_len - 1) << 12) / v->outw;
+            scanl = 0;
+            scanr = (unsigned) (av_len - 1) << 12;
+            first = 0;
+            last = av_len;
+        }
         if (tr) {
-            tr->valid = 1; tr->pos = pos; tr->wave0 = wave[0]; tr->wave1 = wave[1];
-            tr->beg = beg; tr->end = end; tr->hsync = v->hsync;
+            tr->valid = 1; tr->pos = pos; tr->beg = beg; tr->end = end; tr->hsync = v->hsync;
+            tr->dx = dx; tr->scanl = scanl;
         }
 
-        sig = v->inp + pos;                                                  /* D8, :534-543 */
-        memset(&ey, 0, sizeof(ey));
+        memset(&ey, 0, sizeof(ey));                                          /* D8, :534-549 */
         memset(&ei, 0, sizeof(ei));
         memset(&eq, 0, sizeof(eq));
-        for (i = 0; i < av_len; i++) {
+        for (i = first; i < last; i++) {
             yq[0][i] = eq_step(sys, 0, &ey, sig[i] + bright) << 4;
-            yq[1][i] = eq_step(sys, 1, &ei, sig[i] * wave[(i + 0) & 3] >> 9) >> 3;
-            yq[2][i] = eq_step(sys, 2, &eq, sig[i] * wave[(i + 3) & 3] >> 9) >> 3;
+            yq[1][i] = eq_step(sys, 1, &ei, sig[i] * wave_i[i % ccs] >> 9) >> 3;
+            yq[2][i] = eq_step(sys, 2, &eq, sig[i] * wave_q[i % ccs] >> 9) >> 3;
         }
 
-        dx = ((av_len - 1) << 12) / v->outw;                                 /* D9, :528-659 */
-        dst = v->out + beg * pitch;
-        npx = v->outw;
-        for (px = 0; px < npx; px++) {
-            unsigned upos = (unsigned) px * (unsigned) dx;
+        dst = v->out + beg * pitch;                                          /* D9, :552-659 */
+        dst_end = dst + pitch;
+        for (upos = (unsigned) scanl; upos < scanr && dst < dst_end; upos += (unsigned) dx, dst += bpp) {
             int R, L, sidx, y, ci, cq, r, g, b, rgb;
-            if (!(upos < (unsigned) ((av_len - 1) << 12))) break;
             R = (int) (upos & 0xfff);
             L = 0xfff - R;
             sidx = (int) (upos >> 12);
@@ -698,10 +905,10 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
             b = b < 0 ? 0 : (b > 255 ? 255 : b);
             rgb = r << 16 | g << 8 | b;
             if (v->blend) {                                                  /* :584-609 */
-                int old = load_px(dst + px * bpp, v->out_format);
+                int old = load_px(dst, v->out_format);
                 rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
             }
-            store_px(dst + px * bpp, v->out_format, rgb);
+            store_px(dst, v->out_format, rgb);
         }
         for (row = beg + 1; row < end - v->scanlines; row++) {               /* D10, :661-664 */
             memcpy(v->out + row * pitch, v->out + (row - 1) * pitch, (size_t) pitch);
@@ -726,7 +933,7 @@ orc_time_fieldpasses(const struct orc_sys *sys, struct orc_crt *v, struct orc_se
     for (k = 0; k < reps; k++) {
         orc_modulate(sys, v, s);
         orc_demodulate(sys, v, noise);
-        if (interlaced && sys->system != ORC_SYS_NES) {
+        if (interlaced && sys->system != ORC_SYS_NES && sys->system != ORC_SYS_NESRGB) {
             s->field ^= 1;
             if ((k & 1) == 0) s->frame ^= 1;
         }

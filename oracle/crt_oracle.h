@@ -12,7 +12,8 @@
  * (the reference itself ships no tests or golden vectors).
  *
  * Unlike the reference, the "system" (crt_core.h:30-59) is a run-time table
- * (struct orc_sys) so one library covers NTSC, VHS and NES (pattern 0 and 2).
+ * (struct orc_sys) so one library covers all seven systems of crt_core.h:30-36 (+ the build-time
+ * variants CRT_CHROMA_PATTERN, USE_CONVOLUTION, CRT_DO_BLOOM).
  */
 #ifndef CRT_ORACLE_H
 #define CRT_ORACLE_H
@@ -23,7 +24,11 @@
 extern "C" {
 #endif
 
-enum { ORC_SYS_NTSC = 0, ORC_SYS_NES = 1, ORC_SYS_VHS = 5 };
+/* CRT_SYSTEM_* of crt_core.h:30-36 */
+enum { ORC_SYS_NTSC = 0, ORC_SYS_NES = 1, ORC_SYS_PV1K = 2, ORC_SYS_SNES = 3, ORC_SYS_TEMP = 4,
+       ORC_SYS_VHS = 5, ORC_SYS_NESRGB = 6 };
+#define ORC_MAX_VPER 5
+#define ORC_MAX_CCS  5
 
 /* bytes of the reference's struct CRT that follow inp[] and that the decoder can
  * over-read deterministically (outw, outh, out_format, 4 bytes of zeroed padding):
@@ -47,6 +52,20 @@ struct orc_sys {
     int eq_kernel;       /* 0: the 3-band IIR equaliser (the reference's default build); 7/6/5/4: the FIR
                           * kernels of a USE_CONVOLUTION build (crt_core.c:85-147).  Set by the caller
                           * after orc_sys_init. */
+    int do_bloom;        /* CRT_DO_BLOOM (crt_core.h:70), a build-time switch of the reference: set by the
+                          * caller after orc_sys_init */
+    int cc_samples;      /* CRT_CC_SAMPLES: 4, or 5 (PV-1000) */
+    int cb_len;          /* CB_CYCLES * CRT_CB_FREQ: burst samples per line (40 / 50) */
+    /* encoder family switches (what differs between crt_ntsc.c, crt_snes.c, crt_template.c, crt_pv1k.c) */
+    int enc_bandlimit;   /* CRT_DO_BANDLIMITING: the three 1-pole low-passes are active */
+    int enc_field_rows;  /* source row offset by field parity (crt_ntsc.c:258; absent in crt_snes.c) */
+    int enc_line_rows;   /* carrier tables per line class ((y + dot_crawl_offset) rows, crt_snes.c:171-183)
+                          * instead of one row + the +-1 line phase of crt_ntsc.c:199-200 */
+    int vert_step;       /* degrees per line class: 360/VPER (2*360/VPER for PV-1000, crt_pv1k.c:168) */
+    int burst_off, q_off;/* burst / Q carrier angle offsets relative to the I carrier, degrees */
+    int equ_a_lo, equ_a_hi, equ_b_lo, equ_b_hi;   /* equalising-pulse lines (inclusive) */
+    int vs_lo, vs_hi;    /* vertical sync lines (inclusive) */
+    int vs_by_field;     /* odd fields use the {4,50,96,100} % pattern (crt_ntsc.c:219-223) */
 };
 
 struct orc_crt {
@@ -58,7 +77,7 @@ struct orc_crt {
     int black_point, white_point;
     int scanlines, blend;
     unsigned v_fac;
-    int ccf[3][4];
+    int ccf[ORC_MAX_VPER][ORC_MAX_CCS];   /* rows >= cc_vper / columns >= cc_samples unused */
     int hsync, vsync, rn;
 };
 
@@ -69,7 +88,7 @@ struct orc_settings {
     int raw, as_color, field, frame, hue, xoffset, yoffset;
     int do_aberration;            /* VHS */
     unsigned border_color;        /* NES */
-    int dot_crawl_offset;         /* NES */
+    int dot_crawl_offset;         /* NES, NES-RGB, SNES, PV-1000, template */
     int initialized;              /* iirs_initialized / field_initialized */
 };
 
@@ -77,9 +96,10 @@ struct orc_settings {
 struct orc_line {
     int valid;           /* 0: line skipped (beg >= outh), nothing else set */
     int pos;             /* first sample of the active window in inp[] */
-    int wave0, wave1;    /* demodulation carrier (wave[2],wave[3] are negations) */
+    int wave0, wave1;    /* demodulation carrier (wave[2],wave[3] are negations); 5-sample systems: dci, dcq */
     int beg, end;        /* output rows [beg, end) owned by this line */
     int hsync;           /* hsync after this line */
+    int dx, scanl;       /* resampler step and start (12-bit fraction), crt_core.c:512-531 (per line with bloom) */
 };
 
 void orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern);

@@ -71,6 +71,10 @@ SOFF(yoffset, yoffset)
 SOFF(border_color, border_color)
 SOFF(dot_crawl_offset, dot_crawl_offset)
 SOFF(field_initialized, field_initialized)
+#elif (CRT_SYSTEM == CRT_SYSTEM_NESRGB)
+SOFF(format, format)
+SOFF(dot_crawl_offset, dot_crawl_offset)
+SOFF(field_initialized, field_initialized)
 #else
 SOFF(format, format)
 SOFF(raw, raw)
@@ -82,6 +86,11 @@ SOFF(iirs_initialized, iirs_initialized)
 #if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
 SOFF(do_aberration, do_aberration)
 #endif
+#if (CRT_SYSTEM == CRT_SYSTEM_SNES) || (CRT_SYSTEM == CRT_SYSTEM_PV1K) || (CRT_SYSTEM == CRT_SYSTEM_TEMP)
+SOFF(dot_crawl_offset, dot_crawl_offset)
+#endif
+int refp_cc_samples(void)        { return CRT_CC_SAMPLES; }
+int refp_do_bloom(void)          { return CRT_DO_BLOOM; }
 
 void refp_srand(unsigned seed) { srand(seed); }
 
@@ -105,7 +114,7 @@ refp_time_fieldpasses(struct CRT *v, struct NTSC_SETTINGS *s, int noise,
         clock_gettime(CLOCK_MONOTONIC, &c);
         tm += (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
         td += (double) (c.tv_sec - b.tv_sec) + 1e-9 * (double) (c.tv_nsec - b.tv_nsec);
-#if (CRT_SYSTEM != CRT_SYSTEM_NES)
+#if (CRT_SYSTEM != CRT_SYSTEM_NES) && (CRT_SYSTEM != CRT_SYSTEM_NESRGB)
         if (interlaced) {
             s->field ^= 1;
             if ((k & 1) == 0) {

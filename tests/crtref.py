@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_DIR = os.path.join(ORACLE_DIR, "_ref")
 
-SYS_NTSC, SYS_NES, SYS_VHS = 0, 1, 5
+SYS_NTSC, SYS_NES, SYS_PV1K, SYS_SNES, SYS_TEMP, SYS_VHS, SYS_NESRGB = 0, 1, 2, 3, 4, 5, 6
 FMT_RGB, FMT_BGR, FMT_ARGB, FMT_RGBA, FMT_ABGR, FMT_BGRA = range(6)
 ORC_TAIL = 16
 
@@ -34,8 +34,24 @@ SYSTEMS = {
     "ntscfir6": (SYS_NTSC, 1, "libref_ntscfir6.so"),
     "ntscfir5": (SYS_NTSC, 1, "libref_ntscfir5.so"),
     "ntscfir4": (SYS_NTSC, 1, "libref_ntscfir4.so"),
+    # the remaining systems of crt_core.h:30-36
+    "snes": (SYS_SNES, 1, "libref_snes.so"),
+    "pv1k": (SYS_PV1K, 1, "libref_pv1k.so"),
+    "temp": (SYS_TEMP, 1, "libref_temp.so"),
+    "nesrgb": (SYS_NESRGB, 2, "libref_nesrgb.so"),
+    # CRT_DO_BLOOM builds (crt_core.h:70 patched to 1)
+    "ntscbloom": (SYS_NTSC, 1, "libref_ntscbloom.so"),
+    "vhsbloom": (SYS_VHS, 1, "libref_vhsbloom.so"),
+    "pv1kbloom": (SYS_PV1K, 1, "libref_pv1kbloom.so"),
+    "snesbloom": (SYS_SNES, 1, "libref_snesbloom.so"),
 }
 EQ_KERNEL = {"ntscfir7": 7, "ntscfir6": 6, "ntscfir5": 5, "ntscfir4": 4}      # everything else: 0 (IIR)
+DOT_CRAWL_SYSTEMS = (SYS_NES, SYS_NESRGB, SYS_SNES, SYS_PV1K, SYS_TEMP)       # NTSC_SETTINGS has dot_crawl_offset
+PROGRESSIVE_SYSTEMS = (SYS_NES, SYS_NESRGB)                                   # no field / frame members
+
+
+def is_bloom(name):
+    return name.endswith("bloom")
 
 
 def bpp4fmt(fmt):
@@ -163,10 +179,14 @@ class RefLib:
         names = ["data", "w", "h", "hue", "xoffset", "yoffset"]
         if self.system == SYS_NES:
             names += ["border_color", "dot_crawl_offset", "field_initialized"]
+        elif self.system == SYS_NESRGB:
+            names += ["format", "dot_crawl_offset", "field_initialized"]
         else:
             names += ["format", "raw", "as_color", "field", "frame", "iirs_initialized"]
         if self.system == SYS_VHS:
             names += ["do_aberration"]
+        if self.system in (SYS_SNES, SYS_PV1K, SYS_TEMP):
+            names += ["dot_crawl_offset"]
         for f in names:
             fn = getattr(L, "refp_soff_" + f)
             fn.restype = C.c_long
@@ -178,6 +198,7 @@ class RefLib:
         self.input_size = L.refp_input_size()
         self.top, self.bot = L.refp_top(), L.refp_bot()
         self.vper = L.refp_cc_vper()
+        self.ccs = L.refp_cc_samples()
         self.av_beg, self.av_len = L.refp_av_beg(), L.refp_av_len()
         L.refp_time_fieldpasses.restype = C.c_double
         L.refp_time_fieldpasses.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -233,7 +254,7 @@ class RefCRT:
 
     @property
     def ccf(self):
-        return self._i32("ccf", self.ref.vper * 4).reshape(self.ref.vper, 4)
+        return self._i32("ccf", self.ref.vper * self.ref.ccs).reshape(self.ref.vper, self.ref.ccs)
 
     # --- settings ----------------------------------------------------------------
     def settings(self, img, **kw):
@@ -280,7 +301,11 @@ class OrcSys(C.Structure):
         "sync_beg", "bw_beg", "cb_beg", "av_beg", "av_len", "lav_beg", "vs_sep_end",
         "white_level", "burst_level", "black_level", "blank_level", "sync_level")] + [
         ("iir_c", C.c_int * 3), ("eq_lf", C.c_int * 3), ("eq_hf", C.c_int * 3),
-        ("eq_g", (C.c_int * 3) * 3), ("eq_kernel", C.c_int)]
+        ("eq_g", (C.c_int * 3) * 3), ("eq_kernel", C.c_int), ("do_bloom", C.c_int),
+        ("cc_samples", C.c_int), ("cb_len", C.c_int), ("enc_bandlimit", C.c_int), ("enc_field_rows", C.c_int),
+        ("enc_line_rows", C.c_int), ("vert_step", C.c_int), ("burst_off", C.c_int), ("q_off", C.c_int),
+        ("equ_a_lo", C.c_int), ("equ_a_hi", C.c_int), ("equ_b_lo", C.c_int), ("equ_b_hi", C.c_int),
+        ("vs_lo", C.c_int), ("vs_hi", C.c_int), ("vs_by_field", C.c_int)]
 
 
 class OrcCrt(C.Structure):
@@ -290,7 +315,7 @@ class OrcCrt(C.Structure):
                 ("hue", C.c_int), ("brightness", C.c_int), ("contrast", C.c_int),
                 ("saturation", C.c_int), ("black_point", C.c_int), ("white_point", C.c_int),
                 ("scanlines", C.c_int), ("blend", C.c_int), ("v_fac", C.c_uint),
-                ("ccf", (C.c_int * 4) * 3), ("hsync", C.c_int), ("vsync", C.c_int),
+                ("ccf", (C.c_int * 5) * 5), ("hsync", C.c_int), ("vsync", C.c_int),
                 ("rn", C.c_int)]
 
 
@@ -303,7 +328,10 @@ class OrcSettings(C.Structure):
 
 
 class OrcLine(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("valid", "pos", "wave0", "wave1", "beg", "end", "hsync")]
+    _fields_ = [(n, C.c_int) for n in ("valid", "pos", "wave0", "wave1", "beg", "end", "hsync", "dx", "scanl")]
+
+
+ORC_LINE_INTS = 9
 
 
 _SET_ALIAS = {"iirs_initialized": "initialized", "field_initialized": "initialized"}
@@ -321,9 +349,11 @@ class Oracle:
         self.sys = OrcSys()
         L.orc_sys_init(C.byref(self.sys), self.system, self.pattern)
         self.sys.eq_kernel = EQ_KERNEL.get(name, 0)
+        self.sys.do_bloom = int(is_bloom(name))
         for n in ("hres", "vres", "input_size", "top", "bot", "av_beg", "av_len"):
             setattr(self, n, getattr(self.sys, n))
         self.vper = self.sys.cc_vper
+        self.ccs = self.sys.cc_samples
         L.orc_time_fieldpasses.restype = C.c_double
         L.orc_stage_noise.restype = C.c_int
 
@@ -375,7 +405,7 @@ class OracleCRT:
 
     @property
     def ccf(self):
-        return np.array([[self.v.ccf[r][k] for k in range(4)] for r in range(self.ref.vper)],
+        return np.array([[self.v.ccf[r][k] for k in range(self.ref.ccs)] for r in range(self.ref.vper)],
                         dtype=np.int32)
 
     def settings(self, img, **kw):
@@ -398,7 +428,7 @@ class OracleCRT:
             n = self.ref.bot - self.ref.top
             arr = (OrcLine * n)()
             self.ref.lib.orc_demodulate_trace(C.byref(self.ref.sys), C.byref(self.v), noise, arr)
-            self.trace = np.frombuffer(arr, dtype=np.int32).reshape(n, 7).copy()
+            self.trace = np.frombuffer(arr, dtype=np.int32).reshape(n, ORC_LINE_INTS).copy()
         else:
             self.ref.lib.orc_demodulate(C.byref(self.ref.sys), C.byref(self.v), noise)
 

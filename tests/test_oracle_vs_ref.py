@@ -130,7 +130,7 @@ def test_vhs_aberration_matches_reference():
         ao = a.out.reshape(624, -1).copy()
         bo = b.out.reshape(624, -1).copy()
         masked = 0
-        for valid, pos, _, _, beg, end, _ in b.trace:
+        for valid, pos, _, _, beg, end, _, _, _ in b.trace:
             if valid and pos + orc.av_len > orc.input_size + R.ORC_TAIL:
                 ao[beg:end] = 0
                 bo[beg:end] = 0
@@ -157,6 +157,81 @@ def test_nes_sequence_matches_reference(name, outsz):
         noise = [0, 0, 12, 24, 50, 3][step]
         _both(pair, lambda lib, c: (c.modulate(), c.demodulate(noise)))
         R.compare_state(pair[0][1], pair[1][1], "%s step %d" % (name, step))
+
+
+# SURVEY 8(f4) + 8(f3): the remaining systems and the CRT_DO_BLOOM builds, same case table as NTSC
+F4_NAMES = ["snes", "pv1k", "temp", "ntscbloom", "vhsbloom", "pv1kbloom", "snesbloom"]
+
+
+@needs_ref
+@pytest.mark.parametrize("case", range(len(NTSC_CASES)))
+@pytest.mark.parametrize("name", F4_NAMES)
+def test_f4_and_bloom_sequences_match_reference(name, case):
+    if not R.have_ref(name):
+        pytest.skip("oracle/_ref/%s not built" % name)
+    outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = NTSC_CASES[case]
+    if R.is_bloom(name) and case in (9, 10, 11):
+        pytest.skip("bloom: outh < 240 / tiny outputs are pinned without bloom only")
+    pair = _pair(name, outw, outh, ofmt)
+    img = R.synth_image(w, h, R.bpp4fmt(ifmt), 4321 + case, "random" if case % 2 == 0 else "bars")
+    pad = np.concatenate([img, img[-1:]], axis=0)
+    _both(pair, lambda lib, c: c.settings(pad, format=ifmt, w=w, h=h, **skw))
+    for k, v in knobs.items():
+        _both(pair, lambda lib, c: c.set(k, v))
+    for step in range(6):
+        if pair[0][0].system in R.DOT_CRAWL_SYSTEMS:
+            _both(pair, lambda lib, c: c.sset("dot_crawl_offset", (step * 2 + case) % 6 if name.startswith(("pv1k", "temp")) else step % 3))
+        if name.startswith("vhs"):
+            for lib, c in pair:
+                lib.srand(1000 + step)
+                c.modulate()
+                c.demodulate(noise)
+        else:
+            _both(pair, lambda lib, c: (c.modulate(), c.demodulate(noise)))
+        R.compare_state(pair[0][1], pair[1][1], "%s case %d step %d" % (name, case, step))
+        for lib, c in pair:
+            c.sset("field", c.sget("field") ^ 1)
+            if step % 2 == 0:
+                c.sset("frame", c.sget("frame") ^ 1)
+
+
+@needs_ref
+@pytest.mark.parametrize("outsz", [(640, 480), (256, 240), (512, 720)])
+def test_nesrgb_sequence_matches_reference(outsz):
+    outw, outh = outsz
+    pair = _pair("nesrgb", outw, outh, R.FMT_BGRA)
+    for step in range(6):
+        ifmt = [R.FMT_BGRA, R.FMT_RGB, R.FMT_ARGB, R.FMT_BGR, R.FMT_RGBA, R.FMT_ABGR][step]
+        img = R.synth_image(256, 240, R.bpp4fmt(ifmt), 77 + step, "random" if step % 2 else "bars")
+        pad = np.concatenate([img, img[-1:]], axis=0)
+        _both(pair, lambda lib, c: c.settings(pad, format=ifmt, w=256, h=240, dot_crawl_offset=step % 3,
+                                              hue=(step * 50) % 360))
+        noise = [0, 0, 12, 24, 50, 3][step]
+        _both(pair, lambda lib, c: (c.modulate(), c.demodulate(noise)))
+        R.compare_state(pair[0][1], pair[1][1], "nesrgb step %d" % step)
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["nes", "nesp0", "snes", "pv1k", "temp", "nesrgb"])
+def test_negative_hue_and_dot_crawl_match_reference(name):
+    """Angles that go negative: C's truncating % and / make (hue + ...) % 360 and the 14-bit angle differ by one
+    from the reduced form (NES burst at hue -42/-57/-79 with y + dot_crawl_offset >= 3)."""
+    pair = _pair(name, 320, 240, R.FMT_BGRA)
+    nes = name.startswith("nes") and name != "nesrgb"
+    for step, hue in enumerate([-42, -57, -79, -200, -359, -721]):
+        if nes:
+            ppu = R.synth_ppu(256, 240, 5 + step)
+            pad = np.concatenate([ppu, ppu[-1:]], axis=0)
+            _both(pair, lambda lib, c: c.settings(pad, w=256, h=240, dot_crawl_offset=step % 3, hue=hue))
+        else:
+            img = R.synth_image(256, 240, 4, 5 + step)
+            pad = np.concatenate([img, img[-1:]], axis=0)
+            kw = dict(format=R.FMT_BGRA, w=256, h=240, dot_crawl_offset=step % 3, hue=hue)
+            if name != "nesrgb":
+                kw.update(as_color=1)
+            _both(pair, lambda lib, c: c.settings(pad, **kw))
+        _both(pair, lambda lib, c: (c.modulate(), c.demodulate(8)))
+        R.compare_state(pair[0][1], pair[1][1], "%s hue %d" % (name, hue))
 
 
 @needs_ref
