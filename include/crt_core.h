@@ -10,9 +10,10 @@
  * The layouts are pinned by _Static_assert-style checks in ntsc-crt_amd/csrc/crt_api.c and by
  * tests/test_dropin_layout.py against the reference compiled in oracle/_ref.
  *
- * As in the reference, the emulated system is a compile-time choice (-DCRT_SYSTEM=n) and each
- * system is a separate library.  Systems outside this build's scope (SURVEY.md section 8:
- * PV-1000, SNES, template, NES-RGB) are rejected at compile time.
+ * As in the reference, the emulated system is a compile-time choice (-DCRT_SYSTEM=n, all seven systems of the
+ * reference) and each system is a separate library: libntsccrt_hip_{ntsc,nes,pv1k,snes,temp,vhs,nesrgb}.so.
+ * CRT_DO_BLOOM, an unguarded #define in the reference (crt_core.h:70), is a -D option here; the bloom builds are
+ * libntsccrt_hip_<system>_bloom.so.
  */
 #ifndef _CRT_CORE_H_
 #define _CRT_CORE_H_
@@ -45,8 +46,16 @@ extern "C" {
 #include "crt_ntscvhs.h"
 #elif (CRT_SYSTEM == CRT_SYSTEM_NES)
 #include "crt_nes.h"
+#elif (CRT_SYSTEM == CRT_SYSTEM_SNES)
+#include "crt_snes.h"
+#elif (CRT_SYSTEM == CRT_SYSTEM_PV1K)
+#include "crt_pv1k.h"
+#elif (CRT_SYSTEM == CRT_SYSTEM_TEMP)
+#include "crt_template.h"
+#elif (CRT_SYSTEM == CRT_SYSTEM_NESRGB)
+#include "crt_nesrgb.h"
 #else
-#error "this HIP build provides CRT_SYSTEM_NTSC (0), CRT_SYSTEM_NES (1) and CRT_SYSTEM_NTSCVHS (5) only"
+#error "No system defined: CRT_SYSTEM must be one of CRT_SYSTEM_NTSC .. CRT_SYSTEM_NESRGB (0-6)"
 #endif
 
 /* pixel byte orders; alpha is written as 0xff and never read */
@@ -57,8 +66,11 @@ extern "C" {
 #define CRT_PIX_FORMAT_ABGR 4
 #define CRT_PIX_FORMAT_BGRA 5
 
-/* decoder features, fixed like in the shipped reference build */
+/* decoder features.  CRT_DO_BLOOM (beam-energy dependent line width; black borders; not for the NES systems) is
+ * 0 in the shipped reference; build with -DCRT_DO_BLOOM=1 and link libntsccrt_hip_<system>_bloom.so for the other one */
+#ifndef CRT_DO_BLOOM
 #define CRT_DO_BLOOM    0
+#endif
 #define CRT_DO_VSYNC    1
 #define CRT_DO_HSYNC    1
 

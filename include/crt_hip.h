@@ -31,12 +31,21 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 1
+#define CRTHIP_ABI_VERSION 2
 
-/* CRT_SYSTEM_* of crt_core.h:30-36 (only the systems in scope) */
+/* CRT_SYSTEM_* of crt_core.h:30-36 */
 #define CRTHIP_SYSTEM_NTSC    0
 #define CRTHIP_SYSTEM_NES     1
+#define CRTHIP_SYSTEM_PV1K    2   /* Casio PV-1000: 5 samples per chroma cycle (crt_pv1k.h, crt_core.c:480-510) */
+#define CRTHIP_SYSTEM_SNES    3
+#define CRTHIP_SYSTEM_TEMP    4   /* crt_template.c */
 #define CRTHIP_SYSTEM_NTSCVHS 5
+#define CRTHIP_SYSTEM_NESRGB  6
+
+#define CRTHIP_MAX_VPER  5    /* largest CRT_CC_VPER (PV-1000) */
+#define CRTHIP_MAX_CCS   5    /* largest CRT_CC_SAMPLES (PV-1000) */
+#define CRTHIP_DCO_MAX   5    /* dot_crawl_offset values 0..5 are tabulated exactly (the headers document 0-5) */
+#define CRTHIP_CARRIER_ROWS (CRTHIP_MAX_VPER + CRTHIP_DCO_MAX)   /* rows of the per-line-class carrier tables */
 
 /* CRT_PIX_FORMAT_* of crt_core.h:62-67 */
 #define CRTHIP_FMT_RGB  0
@@ -70,6 +79,13 @@ extern "C" {
 #define CRTHIP_F_VHS_DRAW_ABERRATION 4  /* crthip_sequence, VHS: draw every field's aberration height (state.aux)
                                            from the rand() stream like crt_modulate does with do_aberration
                                            (crt_ntscvhs.c:205-207) instead of taking state.aux from the caller */
+/* CRT_DO_BLOOM build of the reference (crt_core.h:70; crt_core.c:399-402,512-526; encoder geometry crt_ntsc.c:148-161) */
+#define CRTHIP_F_BLOOM        8
+/* Every image is followed by one more readable row (image_stride covers h + 1 rows, also behind the last image).
+ * The reference clamps the source row with `if (sy >= h) sy = h` (crt_ntsc.c:263, sic) and so reads row h -- one
+ * past the image -- for odd fields of raw images with h <= desth.  With this flag the kernels read that row like
+ * the reference does; without it they read row h - 1 instead and never touch memory behind an image. */
+#define CRTHIP_F_IMAGE_SPARE_ROW 16
 #define CRTHIP_F_EQ_FIR(taps)  ((taps) << 8)
 #define CRTHIP_F_EQ_FIR_MASK   (7 << 8)
 
@@ -103,8 +119,15 @@ typedef struct crthip_params {
     int finalized;        /* magic, set by crthip_params_finalize              */
     int in_bpp, out_bpp;
     int destw, desth, xo, yo;      /* crt_ntsc.c:132-133,163-173,194-203       */
-    int burst[3][4];               /* colour-burst samples per (line phase, t%4)*/
-    int modI[4], modQ[4];          /* crt_ntsc.c:174-188                       */
+    /* carrier tables [row][t % CC_SAMPLES] (crt_ntsc.c:174-188, crt_snes.c:171-183, crt_nes.c:123-130).
+     * row = (line % CC_VPER) + dot_crawl_offset for the systems whose carriers depend on the line class (NES,
+     * NES-RGB, SNES, template, PV-1000; the unreduced sum, so that negative angles truncate exactly like the
+     * reference's); NTSC / VHS: row = (field == frame), row 1 carrying the inverted line phase of crt_ntsc.c:199-200 */
+    int burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
+    int modI[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
+    int modQ[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
+    int dem_cs[2][CRTHIP_MAX_CCS]; /* 5-sample demodulator: cos / sin of hue + i*72 (I) and + 90 (Q), crt_core.c:497-505 */
+    int dem_sn[2][CRTHIP_MAX_CCS];
     int iir_c[3];                  /* crt_ntsc.c:98-106, Q11                   */
     int eq_lf[3], eq_hf[3];        /* crt_core.c:171-196, Q16                  */
     int eq_g[3][3];                /* crt_core.c:278-280                       */
@@ -115,7 +138,9 @@ typedef struct crthip_params {
     int dx;                        /* crt_core.c:528                           */
     int ratio;                     /* crt_core.c:404-405                       */
     int eq_kernel;                 /* 0 or the FIR taps from flags (validated)   */
-    int reserved[7];
+    int bloom;                     /* flags & CRTHIP_F_BLOOM                     */
+    int bloom_max_e;               /* crt_core.c:400                             */
+    int reserved[6];
 } crthip_params;
 
 /*
@@ -125,23 +150,24 @@ typedef struct crthip_params {
  */
 typedef struct crthip_state {
     int field, frame;     /* in : NTSC_SETTINGS.field / .frame (NTSC, VHS)     */
-    int aux;              /* in : NES dot_crawl_offset; VHS aberration lines    */
+    int aux;              /* in : dot_crawl_offset (NES, NES-RGB, SNES, template, PV-1000); VHS aberration lines */
     int hsync, vsync;     /* i/o: crt_core.h:89                                */
     int rn;               /* i/o: crt_core.h:91                                */
-    int ccf[3][4];        /* i/o: crt_core.h:88 (rows >= CRT_CC_VPER unused)   */
+    int ccf[CRTHIP_MAX_VPER][CRTHIP_MAX_CCS];   /* i/o: crt_core.h:88 (rows >= CRT_CC_VPER, columns >= CRT_CC_SAMPLES unused) */
     int odd_field;        /* out: field parity found by the vsync search        */
-    int reserved;
-} crthip_state;           /* 80 bytes */
+    int reserved[4];
+} crthip_state;           /* 144 bytes */
 
 /* What the serial sync chain (crt_core.c:428-479) hands to the filter stage, per
  * decoded line (CRT_TOP..CRT_BOT-1), device resident. */
 typedef struct crthip_line {
     int pos;              /* first sample of the active window in inp[] (:454) */
-    int wave0, wave1;     /* wave[0], wave[1] (:476-477); [2],[3] = negations   */
+    int wave0, wave1;     /* wave[0], wave[1] (:476-477); [2],[3] = negations.  5-sample systems: dci, dcq (:493-494) */
     int beg;              /* first output row (:428)                            */
     int nrows;            /* rows written: 1 + duplicates (:661-664); 0 = line skipped (:431) */
     int hsync;            /* hsync after this line (diagnostic)                 */
-} crthip_line;            /* 24 bytes */
+    int dx, scanl;        /* resampler step / start, 12-bit fraction (:528-529; per line with bloom, :519-521) */
+} crthip_line;            /* 32 bytes */
 
 typedef struct crthip_ctx crthip_ctx;
 
@@ -246,6 +272,13 @@ int  crthip_decode(crthip_ctx *ctx, const crthip_params *p, int n,
  * stream and an internal stream (fenced by events on both sides), so that the latency-bound
  * kernels of one piece overlap the ALU-bound kernels of the next.  1 = off (default). */
 int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
+
+/* Kernel shape.  0 (default): chosen per launch -- lane-per-scanline kernels (64 scanlines per wavefront, the
+ * throughput shape) when the batch fills the chip, scanline-parallel kernels (a DPP row of 16 or 32 lanes per
+ * scanline: one filter stage per lane, samples handed on with row_shr, pixels emitted by the whole wavefront from
+ * LDS -- the latency shape) for small batches.  1 / 2 force the throughput / latency shape (tests, tuning).
+ * Bloom and the 5-sample system always decode with the latency shape (its resampler is per scanline). */
+int  crthip_set_shape(crthip_ctx *ctx, int shape);
 
 /* Decoder output tile: 16 or 32 pixels per row and flush (0 = choose by output width, default). */
 int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);

@@ -16,17 +16,29 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDIR = os.path.join(HERE, "lib")
 
-SYSTEM_NTSC, SYSTEM_NES, SYSTEM_VHS = 0, 1, 5
+SYSTEM_NTSC, SYSTEM_NES, SYSTEM_PV1K, SYSTEM_SNES, SYSTEM_TEMP, SYSTEM_VHS, SYSTEM_NESRGB = 0, 1, 2, 3, 4, 5, 6
 FMT_RGB, FMT_BGR, FMT_ARGB, FMT_RGBA, FMT_ABGR, FMT_BGRA = range(6)
-F_NES_SETUP = 2
+F_NES_SETUP, F_VHS_DRAW_ABERRATION, F_BLOOM, F_IMAGE_SPARE_ROW = 2, 4, 8, 16
 K_NAMES = ("template", "active", "noise", "sync", "decode")
-STATE_INTS = 20      # sizeof(crthip_state) / 4
-LINE_INTS = 6        # sizeof(crthip_line) / 4
+MAX_VPER, MAX_CCS, CARRIER_ROWS = 5, 5, 10
+STATE_INTS = 36      # sizeof(crthip_state) / 4
+LINE_INTS = 8        # sizeof(crthip_line) / 4
 # columns of the state tensor
-ST_FIELD, ST_FRAME, ST_AUX, ST_HSYNC, ST_VSYNC, ST_RN, ST_CCF, ST_ODD = 0, 1, 2, 3, 4, 5, 6, 18
+ST_FIELD, ST_FRAME, ST_AUX, ST_HSYNC, ST_VSYNC, ST_RN, ST_CCF, ST_ODD = 0, 1, 2, 3, 4, 5, 6, 31
+SHAPE_AUTO, SHAPE_LANE_PER_SCANLINE, SHAPE_SCANLINE_PARALLEL = 0, 1, 2
 
+# name -> (CRT_SYSTEM, CRT_CHROMA_PATTERN); a "bloom" suffix selects the CRT_DO_BLOOM build (crt_core.h:70)
 SYSTEMS = {"ntsc": (SYSTEM_NTSC, 1), "vhs": (SYSTEM_VHS, 1), "nes": (SYSTEM_NES, 2), "nesp0": (SYSTEM_NES, 0),
-           "ntscp0": (SYSTEM_NTSC, 0)}
+           "ntscp0": (SYSTEM_NTSC, 0), "snes": (SYSTEM_SNES, 1), "pv1k": (SYSTEM_PV1K, 1), "temp": (SYSTEM_TEMP, 1),
+           "nesrgb": (SYSTEM_NESRGB, 2)}
+DOT_CRAWL_SYSTEMS = (SYSTEM_NES, SYSTEM_NESRGB, SYSTEM_SNES, SYSTEM_PV1K, SYSTEM_TEMP)
+
+
+def split_system(name):
+    """'ntscbloom' -> ('ntsc', True)"""
+    if name.endswith("bloom"):
+        return name[:-5], True
+    return name, False
 
 
 class Params(C.Structure):
@@ -38,11 +50,14 @@ class Params(C.Structure):
         ("v_fac", C.c_uint), ("noise", C.c_int), ("flags", C.c_int),
         ("finalized", C.c_int), ("in_bpp", C.c_int), ("out_bpp", C.c_int),
         ("destw", C.c_int), ("desth", C.c_int), ("xo", C.c_int), ("yo", C.c_int),
-        ("burst", (C.c_int * 4) * 3), ("modI", C.c_int * 4), ("modQ", C.c_int * 4),
+        ("burst", (C.c_int * MAX_CCS) * CARRIER_ROWS), ("modI", (C.c_int * MAX_CCS) * CARRIER_ROWS),
+        ("modQ", (C.c_int * MAX_CCS) * CARRIER_ROWS),
+        ("dem_cs", (C.c_int * MAX_CCS) * 2), ("dem_sn", (C.c_int * MAX_CCS) * 2),
         ("iir_c", C.c_int * 3), ("eq_lf", C.c_int * 3), ("eq_hf", C.c_int * 3),
         ("eq_g", (C.c_int * 3) * 3), ("huesn", C.c_int), ("huecs", C.c_int),
         ("bright", C.c_int), ("white", C.c_int), ("ire_base", C.c_int), ("dx", C.c_int),
-        ("ratio", C.c_int), ("eq_kernel", C.c_int), ("reserved", C.c_int * 7)]
+        ("ratio", C.c_int), ("eq_kernel", C.c_int), ("bloom", C.c_int), ("bloom_max_e", C.c_int),
+        ("reserved", C.c_int * 6)]
 
 
 def bpp4fmt(fmt):
@@ -91,6 +106,7 @@ def load_library():
     L.crthip_vhs_history_from_seed.argtypes = [C.c_uint, C.POINTER(C.c_uint)]
     L.crthip_vhs_bind_history.argtypes = [vp, vp]
     L.crthip_set_overlap.argtypes = [vp, ci]
+    L.crthip_set_shape.argtypes = [vp, ci]
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
     L.crthip_set_pixel_tile.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
@@ -101,7 +117,10 @@ def load_library():
 def make_params(system="ntsc", **kw):
     """crthip_params_default + user fields + crthip_params_finalize (host only, no GPU needed)."""
     L = load_library()
+    system, bloom = split_system(system)
     sysid, pattern = SYSTEMS[system]
+    if bloom:
+        kw["flags"] = kw.get("flags", 0) | F_BLOOM
     p = Params()
     rc = L.crthip_params_default(C.byref(p), sysid, pattern)
     if rc:
@@ -122,8 +141,11 @@ class Settings:
     ``frame`` (or ``dot_crawl_offset`` for NES) may be ints or per-image sequences."""
 
     def __init__(self, data, format=FMT_BGRA, raw=0, as_color=1, field=0, frame=0, hue=0,
-                 xoffset=0, yoffset=0, dot_crawl_offset=0, aberration=0):
+                 xoffset=0, yoffset=0, dot_crawl_offset=0, aberration=0, spare_row=None):
         self.data = data
+        # CRTHIP_F_IMAGE_SPARE_ROW: every image is followed by one more readable row (the reference reads row h,
+        # crt_ntsc.c:263).  None = detect from the tensor: stride(0) and the storage behind the last image cover it.
+        self.spare_row = spare_row
         self.format, self.raw, self.as_color = format, raw, as_color
         self.field, self.frame, self.hue = field, frame, hue
         self.xoffset, self.yoffset = xoffset, yoffset
@@ -142,7 +164,8 @@ class CRT:
         self.torch = torch
         self.L = load_library()
         self.system = system
-        self.sysid, self.pattern = SYSTEMS[system]
+        self.base_system, self.bloom = split_system(system)
+        self.sysid, self.pattern = SYSTEMS[self.base_system]
         self.dev = torch.device("cuda", device)
         self.n = n
         ctx = C.c_void_p()
@@ -233,8 +256,10 @@ class CRT:
             h, w = int(d.shape[1]), int(d.shape[2])
         flags = self.eq_fir << 8                                   # CRTHIP_F_EQ_FIR(taps)
         if getattr(s, "draw_aberration", 0):
-            flags |= 4                                             # CRTHIP_F_VHS_DRAW_ABERRATION (sequence mode)
-        if self.sysid == SYSTEM_NES and not s.initialized:
+            flags |= F_VHS_DRAW_ABERRATION                         # sequence mode
+        if self._has_spare_row(s):
+            flags |= F_IMAGE_SPARE_ROW
+        if self.sysid in (SYSTEM_NES, SYSTEM_NESRGB) and not s.initialized:
             flags |= F_NES_SETUP
         return make_params(self.system, w=w, h=h, format=s.format, raw=s.raw, as_color=s.as_color, hue=s.hue,
                            xoffset=s.xoffset, yoffset=s.yoffset, outw=self.outw, outh=self.outh,
@@ -243,6 +268,17 @@ class CRT:
                            white_point=self.white_point, scanlines=self.scanlines, blend=self.blend,
                            v_fac=self.v_fac, noise=noise, flags=flags)
 
+    def _has_spare_row(self, s):
+        if s.spare_row is not None:
+            return bool(s.spare_row)
+        d = s.data
+        row = d.stride(1) * d.element_size()
+        need = (int(d.shape[1]) + 1) * row
+        if d.shape[0] > 1 and d.stride(0) * d.element_size() < need:
+            return False
+        last = (d.storage_offset() + (int(d.shape[0]) - 1) * d.stride(0)) * d.element_size() + need
+        return d.untyped_storage().nbytes() >= last
+
     def _load_field_state(self, s):
         torch = self.torch
 
@@ -250,12 +286,10 @@ class CRT:
             if isinstance(v, int):
                 return torch.full((self.n,), v, dtype=torch.int32, device=self.dev)
             return torch.as_tensor(list(v), dtype=torch.int32, device=self.dev)
-        if self.sysid == SYSTEM_NES:
-            self.state[:, ST_AUX] = col(s.dot_crawl_offset)
-        else:
+        if self.sysid not in (SYSTEM_NES, SYSTEM_NESRGB):
             self.state[:, ST_FIELD] = col(s.field)
             self.state[:, ST_FRAME] = col(s.frame)
-            self.state[:, ST_AUX] = col(s.aberration)
+        self.state[:, ST_AUX] = col(s.dot_crawl_offset if self.sysid in DOT_CRAWL_SYSTEMS else s.aberration)
 
     def _image_stride(self, s):
         d = s.data
@@ -335,6 +369,11 @@ class CRT:
         by proven operand range."""
         self._check(self.L.crthip_set_exact(self.ctx, int(on)), "crthip_set_exact")
 
+    def set_shape(self, shape):
+        """Kernel shape: SHAPE_AUTO (by batch size), SHAPE_LANE_PER_SCANLINE (throughput), SHAPE_SCANLINE_PARALLEL
+        (latency; a DPP row of lanes per scanline)."""
+        self._check(self.L.crthip_set_shape(self.ctx, int(shape)), "crthip_set_shape")
+
     def set_overlap(self, chunks):
         """fieldpass(): split the batch into `chunks` pieces alternating between two streams."""
         self._check(self.L.crthip_set_overlap(self.ctx, int(chunks)), "crthip_set_overlap")
@@ -358,4 +397,4 @@ class CRT:
 
     @property
     def ccf(self):
-        return self.state[:, ST_CCF:ST_CCF + 12].reshape(self.n, 3, 4).cpu().numpy()
+        return self.state[:, ST_CCF:ST_CCF + MAX_VPER * MAX_CCS].reshape(self.n, MAX_VPER, MAX_CCS).cpu().numpy()

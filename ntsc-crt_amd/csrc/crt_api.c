@@ -36,13 +36,18 @@ PIN(ntsc_sizeof_settings, sizeof(void *) != 8 || sizeof(struct NTSC_SETTINGS) ==
 PIN(ntsc_hres, CRT_HRES == 910 && AV_LEN == 753 && AV_BEG == 156);
 #endif
 
-#if (CRT_SYSTEM == CRT_SYSTEM_NES)
-#define SYS_ID CRTHIP_SYSTEM_NES
-#elif (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
-#define SYS_ID CRTHIP_SYSTEM_NTSCVHS
-#else
-#define SYS_ID CRTHIP_SYSTEM_NTSC
+/* CRT_SYSTEM_* and CRTHIP_SYSTEM_* share their values (crt_core.h:30-36) */
+#define SYS_ID CRT_SYSTEM
+PIN(system_ids, CRT_SYSTEM_NTSC == CRTHIP_SYSTEM_NTSC && CRT_SYSTEM_NES == CRTHIP_SYSTEM_NES &&
+                CRT_SYSTEM_PV1K == CRTHIP_SYSTEM_PV1K && CRT_SYSTEM_SNES == CRTHIP_SYSTEM_SNES &&
+                CRT_SYSTEM_TEMP == CRTHIP_SYSTEM_TEMP && CRT_SYSTEM_NTSCVHS == CRTHIP_SYSTEM_NTSCVHS &&
+                CRT_SYSTEM_NESRGB == CRTHIP_SYSTEM_NESRGB);
+/* the headers of SNES / PV-1000 / template have no CRT_CHROMA_PATTERN (crt_snes.h:24): one raster each */
+#ifndef CRT_CHROMA_PATTERN
+#define CRT_CHROMA_PATTERN 1
 #endif
+#define HAS_DOT_CRAWL ((CRT_SYSTEM == CRT_SYSTEM_NES) || (CRT_SYSTEM == CRT_SYSTEM_NESRGB) || (CRT_SYSTEM == CRT_SYSTEM_SNES) || \
+                       (CRT_SYSTEM == CRT_SYSTEM_PV1K) || (CRT_SYSTEM == CRT_SYSTEM_TEMP))
 
 /* ---- device-side cache, one slot per struct CRT ------------------------------------------- */
 #define MAX_SLOTS 32
@@ -194,6 +199,9 @@ monitor_params(crthip_params *p, const struct CRT *v)
     /* stand-in for a USE_CONVOLUTION build of the reference (crt_core.c:85-88): 7, 6, 5 or 4 */
     p->flags |= CRTHIP_F_EQ_FIR(CRT_EQ_FIR_TAPS);
 #endif
+#if CRT_DO_BLOOM
+    p->flags |= CRTHIP_F_BLOOM;                     /* crt_core.h:70 */
+#endif
 }
 
 /*
@@ -313,7 +321,9 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
 {
     struct slot *sl;
     crthip_params p;
+    struct crt_sysdef sd;
     size_t img_bytes;
+    long end;
     int field = 0, frame = 0, aux = 0;
     int *lib;
 
@@ -323,25 +333,34 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     p.hue = s->hue;
     p.xoffset = s->xoffset;
     p.yoffset = s->yoffset;
-#if (CRT_SYSTEM == CRT_SYSTEM_NES)
+#if HAS_DOT_CRAWL
+    aux = s->dot_crawl_offset;
+#endif
+#if (CRT_SYSTEM == CRT_SYSTEM_NES) || (CRT_SYSTEM == CRT_SYSTEM_NESRGB)
+    /* crt_nes.c:118-121, crt_nesrgb.c:63-66: the sync skeleton is only written on the first call */
     if (!s->field_initialized) {
         p.flags |= CRTHIP_F_NES_SETUP;
     }
     s->field_initialized = 1;
-    aux = s->dot_crawl_offset;
+#endif
+#if (CRT_SYSTEM == CRT_SYSTEM_NES)
     img_bytes = (size_t) s->w * (size_t) s->h * 2;
 #else
     p.format = s->format;
+#if (CRT_SYSTEM != CRT_SYSTEM_NESRGB)
     p.raw = s->raw;
     p.as_color = s->as_color;
     s->iirs_initialized = 1;
+#endif
     if (crt_setup_bpp4fmt(s->format) == 0) {
         return;     /* like the reference: nothing else happens for an unknown pixel format */
     }
+#if (CRT_SYSTEM != CRT_SYSTEM_NESRGB)
     s->field &= 1;
     s->frame &= 1;
     field = s->field;
     frame = s->frame;
+#endif
 #if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
     if (s->do_aberration) {
         aux = ((rand() % 12) - 8) + 14;     /* same libc stream as the reference consumes */
@@ -353,11 +372,28 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
         return;
     }
     CHECK(crthip_params_finalize(&p));
+    /* The reference writes analog[(x + xo) + (y + yo) * CRT_HRES] whatever the offsets are.  Rectangles that merely
+     * run over the end of a line are reproduced (flat index); what would leave analog[] -- the reference then
+     * scribbles over inp[] and the rest of the struct, e.g. with video_convert.c's uninitialised xoffset/yoffset
+     * (extra/video_convert.c:153) -- is refused: warn once, leave analog[] alone. */
+    CHECK(crt_sysdef_get(&sd, SYS_ID, CRT_CHROMA_PATTERN));
+    end = (long) p.yo * sd.hres + p.xo + (long) (p.desth - 1) * sd.hres + p.destw;
+    if (p.xo < 0 || p.yo < 0 || p.destw <= 0 || p.desth <= 0 || end > (long) sd.input_size) {
+        static int warned;
+        if (!warned) {
+            fprintf(stderr, "ntsc-crt (HIP/gfx950): crt_modulate: xoffset %d / yoffset %d put the picture outside "
+                            "analog[] -- field left unchanged (the reference would write out of bounds)\n",
+                    s->xoffset, s->yoffset);
+            warned = 1;
+        }
+        return;
+    }
 
     lib = park_libc_rand();
     sl = get_slot(v);
-    /* one spare row + slack: the encoder may address row h (reference quirk) */
-    ensure(&sl->d_img, &sl->img_cap, img_bytes + img_bytes / (size_t) s->h + 256);
+    /* the kernels never read behind the image (no CRTHIP_F_IMAGE_SPARE_ROW): row h - 1 stands in for the
+     * reference's out-of-bounds row h (crt_ntsc.c:263) */
+    ensure(&sl->d_img, &sl->img_cap, img_bytes + 256);
     CHECK(crthip_upload(g_ctx, sl->d_img, s->data, img_bytes));
     CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
     state_to_device(sl, v, field, frame, aux);

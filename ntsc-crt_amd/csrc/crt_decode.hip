@@ -399,11 +399,20 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
     return c->no_loskip ? 1 : 0;
 }
 
+/* fields per launch below which the scanline-parallel shape (crt_decode2.hip) is used: lane-per-scanline needs
+ * n * 240 / 64 wavefronts >= a few per SIMD (1024 SIMDs) to hide its 60-instruction-per-sample serial chains */
+#define ROWS_SHAPE_MAX_FIELDS 256
+
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride)
 {
     if (p->dx <= 0)     /* more than 4096 output pixels per sample: the resampler's step (crt_core.c:528) rounds to 0 */
         return set_err(c, CRTHIP_E_ARG, "outw too large for the 12-bit resampler (dx == 0)", hipSuccess);
+    /* kernel shape (crthip_set_shape): bloom and the 5-sample system have per-scanline resampler geometry / carrier
+     * tables and only exist in the scanline-parallel shape; the FIR build only in the lane-per-scanline shape */
+    const bool rows_only = p->bloom || c->sd.cc_samples != 4;
+    const bool rows_shape = rows_only || (!p->eq_kernel && (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS)));
+    if (rows_shape) return crt_run_decode_rows(c, p, n, d_inp, d_lines, d_out, ostride);
     /* FIR build: the filters only add, their outputs stay inside the hull of the inputs, so the 24-bit envelope
      * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
     const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
@@ -413,6 +422,9 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
     const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
+        if constexpr (S::CCS != 4) {
+            return CRTHIP_E_ARG;                      /* unreachable: rows_only above */
+        } else {
         const int total = n * S::LINES;
         const dim3 grid((total + 63) / 64), block(64);
         unsigned char *o = (unsigned char *) d_out;
@@ -440,6 +452,7 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
 #undef CRTHIP_LAUNCH_DECODE
         }
         return CRTHIP_OK;
+        }
     });
 }
 

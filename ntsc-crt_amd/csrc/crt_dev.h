@@ -42,10 +42,26 @@
 /* compile-time system tables (device side); cross-checked against the C89    */
 /* host table crt_sysdef_get() when a context is created                      */
 /* ------------------------------------------------------------------------- */
-template <int CC_LINE>
-struct RgbTiming {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h */
-    static constexpr int HRES = CC_LINE * 4 / 10;
+/* defaults shared by every system; the per-system structs below override what differs */
+struct SysCommon {
     static constexpr int VRES = 262;
+    static constexpr int CCS = 4, CB_LEN = 40;          /* CRT_CC_SAMPLES; CB_CYCLES * CRT_CB_FREQ */
+    static constexpr int VS_SEP_END = 0;
+    static constexpr bool IS_NES = false;               /* PPU-pixel input (crt_nes.c) */
+    static constexpr bool NES_TIMING = false;           /* setup_field skeleton, burst on the active lines only */
+    static constexpr bool IS_VHS = false;
+    static constexpr bool LINE_ROWS = false;            /* carrier row = line class + dot_crawl_offset */
+    static constexpr bool BANDLIMIT = true;             /* CRT_DO_BANDLIMITING */
+    static constexpr bool FIELD_ROWS = true;            /* source row offset by field parity, crt_ntsc.c:258 */
+    static constexpr int EQU_A_LO = 0, EQU_A_HI = 3, EQU_B_LO = 7, EQU_B_HI = 9;   /* crt_ntsc.c:211 */
+    static constexpr int VS_LO = 4, VS_HI = 6;          /* crt_ntsc.c:217 */
+    static constexpr bool VS_BY_FIELD = true;
+    static constexpr int CCF_SHIFT = 0;                 /* ccf preset row = (line + CCF_SHIFT) % VPER */
+    static constexpr int SYNC_WIN = 256;                /* bytes of a line's parked sync/burst window (k_hsync) */
+};
+template <int CC_LINE>
+struct RgbTiming : SysCommon {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h / crt_template.h */
+    static constexpr int HRES = CC_LINE * 4 / 10;
     static constexpr int INPUT_SIZE = HRES * VRES;
     static constexpr int TOP = 21, BOT = 261, LINES = BOT - TOP;
     static constexpr int VPER = 1;
@@ -57,13 +73,10 @@ struct RgbTiming {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h */
     static constexpr int CB_BEG = 6800 * HRES / 63500;
     static constexpr int AV_BEG = 10900 * HRES / 63500;
     static constexpr int AV_LEN = 52600 * HRES / 63500;
-    static constexpr int VS_SEP_END = 0;
-    static constexpr bool IS_NES = false;
 };
 template <int CC_LINE>
-struct NesTiming {   /* crt_nes.h:30-126 */
+struct NesTiming : SysCommon {   /* crt_nes.h:30-126, crt_nesrgb.h, crt_snes.h (PPU pixels on a 341 px line) */
     static constexpr int HRES = CC_LINE * 4 / 10;
-    static constexpr int VRES = 262;
     static constexpr int INPUT_SIZE = HRES * VRES;
     static constexpr int TOP = 15, BOT = 255, LINES = BOT - TOP;
     static constexpr int VPER = 3;
@@ -76,20 +89,80 @@ struct NesTiming {   /* crt_nes.h:30-126 */
     static constexpr int AV_BEG = 74 * HRES / 341;
     static constexpr int AV_LEN = 256 * HRES / 341;
     static constexpr int VS_SEP_END = 327 * HRES / 341;
-    static constexpr bool IS_NES = true;
+    static constexpr bool IS_NES = true, NES_TIMING = true, LINE_ROWS = true, BANDLIMIT = false, FIELD_ROWS = false;
 };
-struct SysNTSC : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 1; static constexpr bool IS_VHS = false; };
-struct SysNTSC0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 0; static constexpr bool IS_VHS = false; };
+struct SysNTSC : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 1; };
+struct SysNTSC0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 0; };
 struct SysVHS : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 1; static constexpr bool IS_VHS = true; };
 struct SysVHS0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 0; static constexpr bool IS_VHS = true; };
-struct SysNES2 : NesTiming<2273> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 2; static constexpr bool IS_VHS = false; };
-struct SysNES1 : NesTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 1; static constexpr bool IS_VHS = false; };
-struct SysNES0 : NesTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 0; static constexpr bool IS_VHS = false; };
+struct SysNES2 : NesTiming<2273> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 2; };
+struct SysNES1 : NesTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 1; };
+struct SysNES0 : NesTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 0; };
+/* SURVEY.md 8(f4).  NES-RGB (crt_nesrgb.c): the NES's timing and skeleton around an RGB image, WHITE_LEVEL 100 */
+template <int CC_LINE> struct NesRgbTiming : NesTiming<CC_LINE> { static constexpr int WHITE = 100; static constexpr bool IS_NES = false; };
+struct SysNESRGB2 : NesRgbTiming<2273> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NESRGB, PATTERN = 2; };
+struct SysNESRGB1 : NesRgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NESRGB, PATTERN = 1; };
+struct SysNESRGB0 : NesRgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NESRGB, PATTERN = 0; };
+/* SNES (crt_snes.c/h): PPU-pixel line timing, NTSC levels and the NTSC-style skeleton, carriers per line class */
+struct SysSNES : NesTiming<2273> {
+    static constexpr int SYSTEM = CRTHIP_SYSTEM_SNES, PATTERN = 1;
+    static constexpr int WHITE = 100, BURST = 20, BLACK = 7, BLANK = 0, SYNC = -40;
+    static constexpr int HTHR = 4 * SYNC, VTHR = 94 * SYNC;
+    static constexpr bool IS_NES = false, NES_TIMING = false;
+    static constexpr int EQU_A_HI = 2, VS_LO = 3;       /* crt_snes.h:137-146 */
+    static constexpr bool VS_BY_FIELD = false;          /* crt_snes.c:216-218 */
+    static constexpr int CCF_SHIFT = 3;                 /* crt_snes.c:240 */
+};
+/* template system (crt_template.c/h): NTSC timing, two line classes, band limit on */
+struct SysTEMP : RgbTiming<2275> {
+    static constexpr int SYSTEM = CRTHIP_SYSTEM_TEMP, PATTERN = 1;
+    static constexpr int VPER = 2;
+    static constexpr bool LINE_ROWS = true;
+    static constexpr int EQU_A_HI = 2, VS_LO = 3;
+    static constexpr int CCF_SHIFT = 3;
+};
+/* Casio PV-1000 (crt_pv1k.c/h): 5 samples per chroma cycle, 1920 samples per line, 5 line classes */
+struct SysPV1K : SysCommon {
+    static constexpr int SYSTEM = CRTHIP_SYSTEM_PV1K, PATTERN = 1;
+    static constexpr int HRES = 2304 * 5 / 6;
+    static constexpr int INPUT_SIZE = HRES * VRES;
+    static constexpr int TOP = 21, BOT = 261, LINES = BOT - TOP;
+    static constexpr int VPER = 5, CCS = 5, CB_LEN = 50;
+    static constexpr int HWIN = 8, VWIN = 8;
+    static constexpr int WHITE = 100, BURST = 20, BLACK = 7, BLANK = 0, SYNC = -40;
+    static constexpr int HTHR = 4 * SYNC, VTHR = 94 * SYNC;
+    static constexpr int LINE_NS = 71 * 892;
+    static constexpr int SYNC_BEG = 3 * 892 * HRES / LINE_NS;
+    static constexpr int BW_BEG = 6 * 892 * HRES / LINE_NS;
+    static constexpr int CB_BEG = 8 * 892 * HRES / LINE_NS;
+    static constexpr int AV_BEG = 16 * 892 * HRES / LINE_NS;
+    static constexpr int AV_LEN = 55 * 892 * HRES / LINE_NS;
+    static constexpr bool LINE_ROWS = true;
+    static constexpr int EQU_A_HI = -1;                 /* crt_pv1k.c:197: only lines 7..9 */
+    static constexpr int VS_LO = 258, VS_HI = 260;      /* crt_pv1k.c:204 */
+    static constexpr int CCF_SHIFT = 3;
+    static constexpr int SYNC_WIN = 512;                /* the burst ends 266 samples into the line */
+};
 
 static_assert(SysNTSC::HRES == 910 && SysNTSC::AV_BEG == 156 && SysNTSC::AV_LEN == 753 &&
               SysNTSC::SYNC_BEG == 21 && SysNTSC::CB_BEG == 97, "NTSC timing (SURVEY.md section 8)");
 static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES == 912 &&
               SysNES0::AV_LEN == 684, "NES timing (SURVEY.md section 8)");
+static_assert(SysPV1K::HRES == 1920 && SysPV1K::CB_BEG + SysPV1K::CB_LEN + 48 <= SysPV1K::SYNC_WIN, "PV-1000 timing");
+
+/* carrier-table row of analog line n of a field (crthip_params.burst / modI / modQ):
+ * line class + dot_crawl_offset (kept unreduced inside 0..CRTHIP_DCO_MAX, else reduced mod VPER), or the
+ * field==frame flag of the NTSC / VHS encoder */
+template <class S> __device__ __forceinline__ int carrier_row(int n, int field, int frame, int aux)
+{
+    if constexpr (S::LINE_ROWS) {
+        int dco = aux;
+        if (dco < 0 || dco > CRTHIP_DCO_MAX) dco = ((dco % S::VPER) + S::VPER) % S::VPER;
+        return n % S::VPER + dco;
+    } else {
+        return (field & 1) == (frame & 1);
+    }
+}
 
 #define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
 #define CRTHIP_LINE_NROWS_MASK 0xffff     /* crthip_line.nrows bits 0-15: rows written              */
@@ -102,7 +175,6 @@ static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES ==
 #define T0_BRIGHT_MAX     2600            /* |bright| bound of decoder tiers 0 and 1  */
 #define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
 #define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
-#define CB_SAMPLES 40            /* CB_CYCLES * CRT_CB_FREQ, crt_ntsc.h:89 */
 #define LCG_MUL 214019u          /* crt_core.c:359 */
 #define LCG_ADD 140327895u
 
@@ -202,7 +274,7 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
 
 /* sizes shared between kernels and the context */
 #define NES_TAB_SIZE (512 * 12)            /* NES composite-sample table: 9-bit pixel x phase mod 12 */
-#define SKEL_VARIANTS 4                    /* cached clean skeleton fields (k_skeleton) */
+#define SKEL_VARIANTS 12                   /* cached clean skeleton fields (k_skeleton): (field, frame) or field x dot_crawl_offset */
 #define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 (248: measured slower) */
 #define VHS_BLK   43                       /* calls per lane in the tail's window: 64 * 43 >= 3 * HRES + 3 */
 
@@ -233,8 +305,13 @@ struct crthip_ctx {
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
     bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tiers */
     bool no_loskip;             /* debug/test: never drop the I/Q low cascades */
-    signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table, rebuilt per encoder launch */
-    signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields, rebuilt per fused encoder launch */
+    signed char *d_nes_tab;     /* NES: 512 x 12 composite-sample table (cached: black / white point) */
+    bool nes_tab_valid;
+    int nes_tab_black, nes_tab_white;
+    signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields (cached: the burst table they were built from) */
+    bool skel_valid;
+    int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
+    int shape;                  /* crthip_set_shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel */
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
@@ -281,7 +358,12 @@ template <class S> static inline bool sysdef_matches(const struct crt_sysdef &d)
            d.hsync_thresh == S::HTHR && d.vsync_thresh == S::VTHR && d.sync_beg == S::SYNC_BEG &&
            d.bw_beg == S::BW_BEG && d.cb_beg == S::CB_BEG && d.av_beg == S::AV_BEG && d.av_len == S::AV_LEN &&
            d.vs_sep_end == S::VS_SEP_END && d.white_level == S::WHITE && d.burst_level == S::BURST &&
-           d.black_level == S::BLACK && d.blank_level == S::BLANK && d.sync_level == S::SYNC;
+           d.black_level == S::BLACK && d.blank_level == S::BLANK && d.sync_level == S::SYNC &&
+           d.cc_samples == S::CCS && d.cb_len == S::CB_LEN && (d.ppu_input != 0) == S::IS_NES &&
+           (d.nes_timing != 0) == S::NES_TIMING && (d.field_rows != 0) == S::FIELD_ROWS &&
+           (d.line_rows != 0) == S::LINE_ROWS && (d.y_freq != 0) == S::BANDLIMIT && d.equ_a_lo == S::EQU_A_LO &&
+           d.equ_a_hi == S::EQU_A_HI && d.equ_b_lo == S::EQU_B_LO && d.equ_b_hi == S::EQU_B_HI && d.vs_lo == S::VS_LO &&
+           d.vs_hi == S::VS_HI && (d.vs_by_field != 0) == S::VS_BY_FIELD && d.ccf_row_shift == S::CCF_SHIFT;
 }
 
 /* call fn(S{}) with the system table type S of (system, pattern); fn is a generic lambda */
@@ -294,6 +376,14 @@ template <class F> static int dispatch_system(int system, int pattern, F &&fn)
         if (pattern == 1) return fn(SysNES1{});
         return fn(SysNES0{});
     }
+    if (system == CRTHIP_SYSTEM_NESRGB) {
+        if (pattern == 2) return fn(SysNESRGB2{});
+        if (pattern == 1) return fn(SysNESRGB1{});
+        return fn(SysNESRGB0{});
+    }
+    if (system == CRTHIP_SYSTEM_SNES) return fn(SysSNES{});
+    if (system == CRTHIP_SYSTEM_TEMP) return fn(SysTEMP{});
+    if (system == CRTHIP_SYSTEM_PV1K) return fn(SysPV1K{});
     return CRTHIP_E_ARG;
 }
 
@@ -326,6 +416,7 @@ struct ProfScope {
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                     signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state);
 int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state);
+int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused);
 int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
                   crthip_state *d_state, bool advance_rn);
 int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
@@ -334,5 +425,7 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
                  crthip_line *d_lines, int advance_rn);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride);
+int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
+                        const crthip_line *d_lines, void *d_out, size_t ostride);
 
 #endif /* CRT_DEV_H */

@@ -5,28 +5,31 @@
 /* M4: blanking / sync / burst skeleton                                        */
 /* ------------------------------------------------------------------------- */
 /* value of skeleton sample (line n, column t) and whether crt_modulate writes it.
- * RGB systems: crt_ntsc.c:205-252 (+ crt_ntscvhs.c:234-238);  NES: crt_nes.c:81-104,173-178 */
+ * RGB systems: crt_ntsc.c:205-252 (+ crt_ntscvhs.c:234-238), crt_snes.c:203-243, crt_template.c, crt_pv1k.c:190-231;
+ * NES timing: crt_nes.c:81-104,173-178, crt_nesrgb.c:24-46,104-109 */
 template <class S>
 __device__ __forceinline__ bool
-skeleton(const crthip_params &P, int n, int t, int field, int inv_phase, int aux, bool nes_setup, int &val)
+skeleton(const crthip_params &P, int n, int t, int field, int frame, int aux, bool nes_setup, int &val)
 {
-    if constexpr (S::IS_NES) {
+    const int row = carrier_row<S>(n, field, frame, aux);
+    const int tc = S::CCS == 4 ? (t & 3) : t % S::CCS;
+    if constexpr (S::NES_TIMING) {
         bool written = nes_setup;
         val = S::BLANK;
         if (t >= S::SYNC_BEG && t < (n >= 259 ? S::VS_SEP_END : S::BW_BEG)) val = S::SYNC;
-        if (n >= P.yo && n < P.yo + S::LINES && t >= S::CB_BEG && t < S::CB_BEG + CB_SAMPLES) {
-            int cb = P.burst[(n % 3 + aux) % 3][t & 3];
+        if (n >= P.yo && n < P.yo + S::LINES && t >= S::CB_BEG && t < S::CB_BEG + S::CB_LEN) {
+            int cb = P.burst[row][tc];
             val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
             written = true;
         }
         return written;
     } else {
-        if (n <= 3 || (n >= 7 && n <= 9)) {            /* equalising pulses */
+        if ((n >= S::EQU_A_LO && n <= S::EQU_A_HI) || (n >= S::EQU_B_LO && n <= S::EQU_B_HI)) {   /* equalising pulses */
             val = (t < 4 * S::HRES / 100 || (t >= 50 * S::HRES / 100 && t < 54 * S::HRES / 100)) ? S::SYNC : S::BLANK;
             return true;
         }
-        if (n >= 4 && n <= 6) {                        /* vertical sync */
-            int a = (field == 1 ? 4 : 46) * S::HRES / 100;
+        if (n >= S::VS_LO && n <= S::VS_HI) {          /* vertical sync */
+            int a = ((S::VS_BY_FIELD && field == 1) ? 4 : 46) * S::HRES / 100;
             val = (t < a || (t >= 50 * S::HRES / 100 && t < 96 * S::HRES / 100)) ? S::SYNC : S::BLANK;
             return true;
         }
@@ -35,9 +38,9 @@ skeleton(const crthip_params &P, int n, int t, int field, int inv_phase, int aux
             return n < S::TOP;
         }
         val = S::BLANK;
-        if (t >= S::SYNC_BEG && t < S::BW_BEG && n < S::VRES - aux) val = S::SYNC;
-        if (t >= S::CB_BEG && t < S::CB_BEG + CB_SAMPLES) {
-            int cb = S::PATTERN == 1 ? P.burst[0][(t + inv_phase * 2) & 3] : P.burst[0][t & 3];
+        if (t >= S::SYNC_BEG && t < S::BW_BEG && (!S::IS_VHS || n < S::VRES - aux)) val = S::SYNC;
+        if (t >= S::CB_BEG && t < S::CB_BEG + S::CB_LEN) {
+            int cb = P.burst[row][tc];
             val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
         }
         return true;
@@ -59,7 +62,6 @@ k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, s
     const int idx0 = q * 16;
     const crthip_state st = state[f];
     const int field = st.field & 1;
-    const int inv_phase = (field == (st.frame & 1));
     int line = idx0 / S::HRES;
     int t = idx0 - line * S::HRES;
     signed char *out = dst + (size_t) f * fstride;
@@ -73,7 +75,7 @@ k_template(const crthip_params P, int n_fields, signed char *__restrict__ dst, s
         int v = 0;
         const bool in_field = idx0 + k < S::INPUT_SIZE;
         const bool active = t >= P.xo && t < P.xo + P.destw && line >= P.yo && line < P.yo + P.desth;
-        const bool wr = skeleton<S>(P, line, t, field, inv_phase, st.aux, nes_setup != 0, v);
+        const bool wr = skeleton<S>(P, line, t, field, st.frame & 1, st.aux, nes_setup != 0, v);
         if (wr && !active && in_field) wmask |= 1u << k;
         vals[k] = v;
         if (++t == S::HRES) { t = 0; line++; }
@@ -141,9 +143,127 @@ __device__ __forceinline__ int ppu_level(int p, int phase)
     return v;
 }
 
+/* Cooperative tile I/O of the lane-per-row encoders (see the comment above k_decode): the wave moves 64 rows x ACT
+ * dwords between global memory and LDS with row-contiguous 16-byte pieces; each lane then reads / writes only its
+ * own tile row.  Input side: `have` = tile in LDS, stage[] = tile have+1 in flight / in registers.  A piece that
+ * would run past the row end is moved back to the row's last 16 bytes, so nothing beyond the row is touched
+ * (row_bytes >= 16); moved-back pieces of several lanes overlap and carry identical bytes. */
+template <int ACT>
+struct RowTiles {
+    static constexpr int TILE = ACT, STRIDE = ACT + 1, PIECES = ACT / 4;     /* 16-byte pieces per tile row */
+    static constexpr int ROWS = 64 / PIECES;                                  /* rows per load instruction */
+    unsigned *s_pix, *s_out;
+    const unsigned long long *s_src, *s_dst;
+    int lane, prow, piece;
+    int row_bytes, last_tile, have;
+    v4i stage[PIECES];
+
+    __device__ __forceinline__ void init(unsigned *pix, unsigned *out, const unsigned long long *src,
+                                         const unsigned long long *dst, int lane_, int row_bytes_)
+    {
+        s_pix = pix; s_out = out; s_src = src; s_dst = dst;
+        lane = lane_; prow = lane_ / PIECES; piece = lane_ % PIECES;
+        row_bytes = row_bytes_;
+        last_tile = (row_bytes_ - 1) / (TILE * 4);
+        have = 0;
+    }
+    __device__ __forceinline__ int piece_offset(int tile) const
+    {
+        const int off = tile * (TILE * 4) + piece * 16;
+        return off > row_bytes - 16 ? row_bytes - 16 : off;
+    }
+    __device__ __forceinline__ void fetch(int tile)
+    {
+        const int off = piece_offset(tile);
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * ROWS + prow] + off);
+    }
+    __device__ __forceinline__ void stash(int tile)
+    {
+        /* dword index inside the tile where my (possibly moved-back) piece belongs; may be negative then */
+        const int dw0 = (piece_offset(tile) - tile * (TILE * 4)) >> 2;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) {
+            unsigned *d = s_pix + (i * ROWS + prow) * STRIDE;
+            if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
+            if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
+            if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
+            if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void start()
+    {
+        fetch(0);
+        stash(0);
+        if (last_tile > 0) fetch(1);
+    }
+    /* make tile `need` (wave-uniform) the resident one */
+    __device__ __forceinline__ void want(int need)
+    {
+        if (need != have) {
+            if (need != have + 1) fetch(need);          /* only when the source is more than TILE x wider than the line */
+            stash(need);
+            have = need;
+            if (need < last_tile) fetch(need + 1);
+        }
+    }
+    __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[lane * STRIDE + (idx & (TILE - 1))]; }
+    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[lane * STRIDE + (g & (TILE - 1))] = pack; }
+    /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
+    __device__ __forceinline__ void drain(int g0, int ng, int destw)
+    {
+        __syncthreads();
+        const int first = (g0 + piece * 4) * 4;               /* first sample of my piece */
+        const int nbytes = destw - first < 16 ? destw - first : 16;
+#pragma unroll 2
+        for (int i = 0; i < PIECES; i++) {
+            const int r = i * ROWS + prow;
+            const unsigned long long d = s_dst[r];
+            if (d != 0 && piece * 4 < ng && nbytes > 0) {
+                const unsigned *sp = s_out + r * STRIDE + piece * 4;
+                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+                if (nbytes == 16) {
+                    gstore16u(d + first, o);
+                } else {
+                    const int wds[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    /* after sample group g (4 samples = 1 dword per row): flush when the tile is full or the line ends */
+    __device__ __forceinline__ void group_done(int g, int ngroups, int destw)
+    {
+        if ((g & (TILE - 1)) == TILE - 1 || g == ngroups - 1) drain(g & ~(TILE - 1), (g & (TILE - 1)) + 1, destw);
+    }
+};
+
+/* source image row of destination row y: crt_ntsc.c:256-263 (field_offset where the system has one),
+ * crt_nes.c:165-168 / crt_nesrgb.c:94-97 (NES timing).  The reference's `if (sy >= h) sy = h` (sic) addresses the
+ * row BEHIND the image; that row is only read when the caller vouches for it (CRTHIP_F_IMAGE_SPARE_ROW). */
+template <class S> __device__ __forceinline__ int source_row(const crthip_params &P, int y, int field)
+{
+    int sy;
+    if constexpr (S::NES_TIMING) {
+        sy = (y * P.h) / S::LINES;
+    } else {
+        const int field_offset = S::FIELD_ROWS ? (field * P.h + P.desth) / P.desth / 2 : 0;
+        sy = (y * P.h) / P.desth + field_offset;
+    }
+    if (sy >= P.h) sy = (P.flags & CRTHIP_F_IMAGE_SPARE_ROW) ? P.h : P.h - 1;
+    if (sy < 0) sy = 0;
+    return sy;
+}
+
 /* FAST: 24-bit multiplies (always in range for the IIRs and the carrier products: 8-bit pixels
  * bound every state; `white` and `noise` are range-checked on the host).
- * IN4: 4-byte input pixels moved through a cooperative LDS tile (see the comment above k_decode);
+ * IN4: 4-byte input pixels moved through a cooperative LDS tile (RowTiles);
  * otherwise (3-byte formats, tiny images) each lane reads its own pixels bytewise.
  * The produced samples always leave through a cooperative LDS tile. */
 /* ACT = dwords per row and tile (ACT pixels in, 4*ACT samples out): 32 moves full 128-byte lines per row
@@ -156,10 +276,10 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
          const uint2 *__restrict__ jump16)
 {
-    constexpr int AC_TILE = ACT, AC_STRIDE = ACT + 1, AC_PIECES = ACT / 4;   /* 16-byte pieces per tile row */
-    constexpr int AC_ROWS = 64 / AC_PIECES, AC_SHIFT = ACT == 32 ? 5 : 4;      /* rows per load instruction */
-    __shared__ unsigned s_pix[64 * AC_STRIDE];
-    __shared__ unsigned s_out[64 * AC_STRIDE];
+    using T = RowTiles<ACT>;
+    constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
+    __shared__ unsigned s_pix[64 * T::STRIDE];
+    __shared__ unsigned s_out[64 * T::STRIDE];
     __shared__ unsigned long long s_src[64], s_dst[64];
 
     const int lane = threadIdx.x;
@@ -180,52 +300,17 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     const int ngroups = (destw + 3) >> 2;
 
     /* per-row source / destination, published to the whole wave */
-    int sy;
-    if constexpr (S::IS_NES) {
-        sy = (y * P.h) / S::LINES;                            /* crt_nes.c:165-168 */
-        if (sy >= P.h) sy = P.h;
-        if (sy < 0) sy = 0;
-    } else {
-        const int field = st.field & 1;
-        const int field_offset = (field * P.h + P.desth) / P.desth / 2;
-        sy = (y * P.h) / P.desth + field_offset;              /* crt_ntsc.c:258-263 */
-        if (sy >= P.h) sy = P.h;                              /* (sic) */
-    }
+    const int sy = source_row<S>(P, y, st.field & 1);
     const int in_bpp = S::IS_NES ? 2 : P.in_bpp;
     const unsigned char *row = img + (size_t) sy * w * in_bpp;
     s_src[lane] = (unsigned long long) row;
     s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
     __syncthreads();
-
-    /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
-    auto drain = [&](int g0, int ng) {
-        __syncthreads();
-        const int orow = lane / AC_PIECES, piece = lane % AC_PIECES;   /* 16 bytes per piece */
-        const int first = (g0 + piece * 4) * 4;               /* first sample of my piece */
-        const int nbytes = destw - first < 16 ? destw - first : 16;
-#pragma unroll 2
-        for (int i = 0; i < AC_PIECES; i++) {
-            const int r = i * AC_ROWS + orow;
-            const unsigned long long d = s_dst[r];
-            if (d != 0 && piece * 4 < ng && nbytes > 0) {
-                const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
-                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
-                if (nbytes == 16) {
-                    gstore16u(d + first, o);
-                } else {
-                    const int wds[4] = { o.x, o.y, o.z, o.w };
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    };
+    T tiles;
+    tiles.init(s_pix, s_out, s_src, s_dst, lane, w * 4);
 
     if constexpr (S::IS_NES) {
-        /* crt_nes.c:162-193 */
+        /* crt_nes.c:162-193, images too narrow for the tile path (k_active_nes otherwise) */
         const unsigned short *prow = (const unsigned short *) row;
         int phase = 4 * ((y + P.yo + st.aux) % 3);           /* phasetab {0,4,8} */
         for (int g = 0; g < ngroups; g++) {
@@ -250,61 +335,25 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     if (err >= destw) { err -= destw; col++; }
                 }
             }
-            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack;
-            if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+            tiles.put(g, pack);
+            tiles.group_done(g, ngroups, destw);
         }
     } else {
-        /* crt_ntsc.c:254-324 */
-        const int field = st.field & 1;
-        const int inv_phase = (field == (st.frame & 1));
-        const int ph = (S::PATTERN == 1 && (inv_phase & 1)) ? -1 : 1;
-        /* (h * ph) * cc == h * (ph * cc) in wrapping arithmetic; xo is a multiple of 4 (crt_ntsc.c:203)
-         * so the carrier phase (x + xo) % 4 is x & 3 */
-        const int cI0 = ph * P.modI[0], cI1 = ph * P.modI[1], cI2 = ph * P.modI[2], cI3 = ph * P.modI[3];
-        const int cQ0 = ph * P.modQ[0], cQ1 = ph * P.modQ[1], cQ2 = ph * P.modQ[2], cQ3 = ph * P.modQ[3];
+        /* crt_ntsc.c:254-324 and its siblings crt_ntscvhs.c, crt_snes.c:246-319, crt_template.c, crt_pv1k.c:233-312,
+         * crt_nesrgb.c:91-163.  Carrier row of this line: (h * ph) * cc == h * (ph * cc) in wrapping arithmetic,
+         * the +-1 line phase of crt_ntsc.c:199-200 is folded into row 1 of the tables on the host.  xo is a multiple
+         * of CC_SAMPLES (crt_ntsc.c:203, crt_snes.c:201), so the carrier phase (x + xo) % CCS is x % CCS. */
+        const int crow = carrier_row<S>(y + P.yo, st.field, st.frame, st.aux);
+        int cI[S::CCS], cQ[S::CCS];
+#pragma unroll
+        for (int k = 0; k < S::CCS; k++) { cI[k] = P.modI[crow][k]; cQ[k] = P.modQ[crow][k]; }
         const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
         const unsigned isel = input_selector(P.format);
         const int white = P.white, ire_base = P.ire_base, noise = P.noise;
         int hy = 0, hi = 0, hq = 0;
+        int cph = 0;                                              /* x % CCS for the 5-sample system (wave-uniform) */
 
-        /* IN4 pixel tiles: 32 pixels (128 bytes) per row; pieces of 16 bytes, 8 per row, 8 rows per
-         * load instruction.  `have` = tile in LDS, `stage[]` = tile have+1 in flight / in registers.
-         * A piece that would run past the row end is moved back to the row's last 16 bytes, so
-         * nothing beyond the image is touched (w >= 4). */
-        const int prow_ = lane / AC_PIECES, piece = lane % AC_PIECES;
-        const int last_tile = (w - 1) >> AC_SHIFT;
-        const int row_bytes = w * 4;
-        v4i stage[AC_PIECES];
-        auto piece_offset = [&](int tile) {
-            int off = tile * (AC_TILE * 4) + piece * 16;
-            return off > row_bytes - 16 ? row_bytes - 16 : off;
-        };
-        auto fetch = [&](int tile) {
-            const int off = piece_offset(tile);
-#pragma unroll
-            for (int i = 0; i < AC_PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * AC_ROWS + prow_] + off);
-        };
-        auto stash = [&](int tile) {
-            /* dword index inside the tile where my (possibly moved-back) piece belongs; moved-back
-             * pieces of several lanes overlap and carry identical bytes */
-            const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;     /* may be negative for a moved-back piece */
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < AC_PIECES; i++) {
-                unsigned *d = s_pix + (i * AC_ROWS + prow_) * AC_STRIDE;
-                if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
-                if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
-                if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
-                if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
-            }
-            __syncthreads();
-        };
-        int have = 0;
-        if (IN4) {
-            fetch(0);
-            stash(0);
-            if (last_tile > 0) fetch(1);
-        }
+        if (IN4) tiles.start();
         const int noise127 = 0x7f * noise;
         for (int g = 0; g < ngroups; g++) {
             int smp[4] = { 0, 0, 0, 0 };
@@ -314,14 +363,8 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                 if (x < destw) {
                     unsigned pixel;
                     if (IN4) {
-                        const int need = col >> AC_SHIFT;          /* wave-uniform */
-                        if (need != have) {
-                            if (need != have + 1) fetch(need);      /* only when w > 32*destw */
-                            stash(need);
-                            have = need;
-                            if (need < last_tile) fetch(need + 1);
-                        }
-                        pixel = s_pix[lane * AC_STRIDE + (col & (AC_TILE - 1))];
+                        tiles.want(col >> AC_SHIFT);               /* wave-uniform */
+                        pixel = tiles.pixel_dword(col);
                     } else {
                         const unsigned char *pp = row + (size_t) col * in_bpp;
                         pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
@@ -332,11 +375,24 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     const int fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
                     const int fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
                     const int fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
-                    hy += mulq<FAST>(fy - hy, cy_) >> 11;           /* iirf, crt_ntsc.c:117-126 */
-                    hi += mulq<FAST>(fi - hi, ci_) >> 11;
-                    hq += mulq<FAST>(fq - hq, cq_) >> 11;
-                    const int mi = mulq<FAST>(hi, k == 0 ? cI0 : k == 1 ? cI1 : k == 2 ? cI2 : cI3) >> 4;
-                    const int mq = mulq<FAST>(hq, k == 0 ? cQ0 : k == 1 ? cQ1 : k == 2 ? cQ2 : cQ3) >> 4;
+                    if (S::BANDLIMIT) {
+                        hy += mulq<FAST>(fy - hy, cy_) >> 11;       /* iirf, crt_ntsc.c:117-126 */
+                        hi += mulq<FAST>(fi - hi, ci_) >> 11;
+                        hq += mulq<FAST>(fq - hq, cq_) >> 11;
+                    } else {                                        /* CRT_DO_BANDLIMITING 0, crt_snes.c:113-122 */
+                        hy = fy; hi = fi; hq = fq;
+                    }
+                    int ccI, ccQ;
+                    if constexpr (S::CCS == 4) {
+                        ccI = k == 0 ? cI[0] : k == 1 ? cI[1] : k == 2 ? cI[2] : cI[3];
+                        ccQ = k == 0 ? cQ[0] : k == 1 ? cQ[1] : k == 2 ? cQ[2] : cQ[3];
+                    } else {
+                        ccI = cph == 0 ? cI[0] : cph == 1 ? cI[1] : cph == 2 ? cI[2] : cph == 3 ? cI[3] : cI[4];
+                        ccQ = cph == 0 ? cQ[0] : cph == 1 ? cQ[1] : cph == 2 ? cQ[2] : cph == 3 ? cQ[3] : cQ[4];
+                        cph = cph == S::CCS - 1 ? 0 : cph + 1;
+                    }
+                    const int mi = mulq<FAST>(hi, ccI) >> 4;
+                    const int mq = mulq<FAST>(hq, ccQ) >> 4;
                     int ire = ire_base + (mulq<FAST>(hy + mi + mq, white) >> 10);
                     ire = clampi(ire, 0, 110);
                     if (NOISE) {
@@ -349,8 +405,8 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     if (err >= destw) { err -= destw; col++; }
                 }
             }
-            s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack4(smp[0], smp[1], smp[2], smp[3]);
-            if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+            tiles.put(g, pack4(smp[0], smp[1], smp[2], smp[3]));
+            tiles.group_done(g, ngroups, destw);
         }
     }
 }
@@ -360,8 +416,8 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
 /* ------------------------------------------------------------------------- */
 /* A composite sample of the NES is  ((BLACK + black_point + sum_{k<4} square(p, phase+k)) * white_point / 100) >> 12
  * truncated to a signed char.  square() depends on the phase only through (hue+phase)%12 and (phase>>1)%6,
- * both 12-periodic, so the sample is a function of (9-bit pixel, phase mod 12): 512 x 12 bytes, rebuilt per
- * launch because it contains the black / white point knobs. */
+ * both 12-periodic, so the sample is a function of (9-bit pixel, phase mod 12): 512 x 12 bytes, rebuilt whenever
+ * the black / white point knobs change (cached in the context). */
 template <class S>
 __global__ void k_nes_table(const crthip_params P, signed char *tab)
 {
@@ -383,10 +439,10 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
              signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
              const uint2 *__restrict__ jump16, const signed char *__restrict__ tab)
 {
-    constexpr int AC_TILE = ACT, AC_STRIDE = ACT + 1, AC_PIECES = ACT / 4;
-    constexpr int AC_ROWS = 64 / AC_PIECES, AC_SHIFT = ACT == 32 ? 5 : 4;
-    __shared__ unsigned s_pix[64 * AC_STRIDE];
-    __shared__ unsigned s_out[64 * AC_STRIDE];
+    using T = RowTiles<ACT>;
+    constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
+    __shared__ unsigned s_pix[64 * T::STRIDE];
+    __shared__ unsigned s_out[64 * T::STRIDE];
     __shared__ unsigned long long s_src[64], s_dst[64];
     __shared__ unsigned s_tab[NES_TAB_SIZE / 4];
 
@@ -407,69 +463,14 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     const int qstep = w / destw, rstep = w - qstep * destw;
     int col = 0, err = 0;
     const int ngroups = (destw + 3) >> 2;
-    int sy = (y * P.h) / S::LINES;                              /* crt_nes.c:165-168 */
-    if (sy >= P.h) sy = P.h;
-    if (sy < 0) sy = 0;
+    const int sy = source_row<S>(P, y, 0);                      /* crt_nes.c:165-168 */
     s_src[lane] = (unsigned long long) (img + (size_t) sy * w * 2);
     s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
     __syncthreads();
-
-    auto drain = [&](int g0, int ng) {
-        __syncthreads();
-        const int orow = lane / AC_PIECES, piece = lane % AC_PIECES;
-        const int first = (g0 + piece * 4) * 4;
-        const int nbytes = destw - first < 16 ? destw - first : 16;
-#pragma unroll 2
-        for (int i = 0; i < AC_PIECES; i++) {
-            const int r = i * AC_ROWS + orow;
-            const unsigned long long d = s_dst[r];
-            if (d != 0 && piece * 4 < ng && nbytes > 0) {
-                const unsigned *sp = s_out + r * AC_STRIDE + piece * 4;
-                v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
-                if (nbytes == 16) {
-                    gstore16u(d + first, o);
-                } else {
-                    const int wds[4] = { o.x, o.y, o.z, o.w };
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    };
-    /* pixel tiles: AC_TILE dwords = 2*AC_TILE PPU pixels per row (see k_active) */
-    const int prow_ = lane / AC_PIECES, piece = lane % AC_PIECES;
-    const int row_bytes = w * 2;
-    const int last_tile = (row_bytes - 1) / (AC_TILE * 4);
-    v4i stage[AC_PIECES];
-    auto piece_offset = [&](int tile) {
-        int off = tile * (AC_TILE * 4) + piece * 16;
-        return off > row_bytes - 16 ? row_bytes - 16 : off;
-    };
-    auto fetch = [&](int tile) {
-        const int off = piece_offset(tile);
-#pragma unroll
-        for (int i = 0; i < AC_PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * AC_ROWS + prow_] + off);
-    };
-    auto stash = [&](int tile) {
-        const int dw0 = (piece_offset(tile) - tile * (AC_TILE * 4)) >> 2;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < AC_PIECES; i++) {
-            unsigned *d = s_pix + (i * AC_ROWS + prow_) * AC_STRIDE;
-            if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
-            if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
-            if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
-            if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
-        }
-        __syncthreads();
-    };
-    int have = 0;
-    fetch(0);
-    stash(0);
-    if (last_tile > 0) fetch(1);
+    /* pixel tiles: ACT dwords = 2*ACT PPU pixels per row */
+    T tiles;
+    tiles.init(s_pix, s_out, s_src, s_dst, lane, w * 2);
+    tiles.start();
 
     int ph = 4 * ((y + P.yo + st.aux) % 3);                    /* phasetab {0,4,8}; advances by 3 per sample, mod 12 */
     const signed char *tb = (const signed char *) s_tab;
@@ -479,14 +480,8 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
         for (int k = 0; k < 4; k++) {
             const int x = 4 * g + k;
             if (x < destw) {
-                const int need = col >> (AC_SHIFT + 1);         /* wave-uniform */
-                if (need != have) {
-                    if (need != have + 1) fetch(need);
-                    stash(need);
-                    have = need;
-                    if (need < last_tile) fetch(need + 1);
-                }
-                const unsigned dw = s_pix[lane * AC_STRIDE + ((col >> 1) & (AC_TILE - 1))];
+                tiles.want(col >> (AC_SHIFT + 1));              /* wave-uniform */
+                const unsigned dw = tiles.pixel_dword(col >> 1);
                 const int p = (int) ((col & 1) ? dw >> 16 : dw & 0xffffu);
                 /* data[] is unsigned short (crt_nes.h:133): the reference's table walks only look at bits 0-8 */
                 int ire = tb[(p & 511) * 12 + ph];
@@ -499,15 +494,27 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
                 if (err >= destw) { err -= destw; col++; }
             }
         }
-        s_out[lane * AC_STRIDE + (g & (AC_TILE - 1))] = pack4(smp[0], smp[1], smp[2], smp[3]);
-        if ((g & (AC_TILE - 1)) == AC_TILE - 1 || g == ngroups - 1) drain(g & ~(AC_TILE - 1), (g & (AC_TILE - 1)) + 1);
+        tiles.put(g, pack4(smp[0], smp[1], smp[2], smp[3]));
+        tiles.group_done(g, ngroups, destw);
     }
 }
 
 /* The clean skeleton (blanking / sync / burst, 0 where crt_modulate writes nothing) of a whole field depends
- * only on a handful of per-field inputs: RGB systems (field, frame parity) -> 4 variants; NES the dot crawl
- * offset mod 3 -> 3 variants.  k_skeleton writes the variants once per launch (a few fields' worth of work),
- * k_margin then only copies 16 bytes and adds the channel noise. */
+ * only on a handful of per-field inputs: NTSC / VHS (field, frame parity) -> 4 variants; the systems with
+ * per-line-class carriers: dot crawl offset 0..5 (x field parity where the vertical sync depends on it) -> up to
+ * 12.  k_skeleton writes the variants (cached in the context, rebuilt when the burst table changes), k_margin then
+ * only copies 16 bytes and adds the channel noise. */
+template <class S> __device__ __forceinline__ int skeleton_variant(int field, int frame, int aux)
+{
+    if constexpr (S::LINE_ROWS) {
+        int dco = aux;
+        if (dco < 0 || dco > CRTHIP_DCO_MAX) dco = ((dco % S::VPER) + S::VPER) % S::VPER;
+        return (S::VS_BY_FIELD && !S::NES_TIMING ? (field & 1) * (CRTHIP_DCO_MAX + 1) : 0) + dco;
+    } else {
+        return ((field & 1) << 1) | (frame & 1);
+    }
+}
+
 template <class S>
 __global__ void __launch_bounds__(256)
 k_skeleton(const crthip_params P, signed char *__restrict__ skel, size_t fstride)
@@ -517,16 +524,17 @@ k_skeleton(const crthip_params P, signed char *__restrict__ skel, size_t fstride
     if (gid >= SKEL_VARIANTS * CHUNKS) return;
     const int var = gid / CHUNKS;
     const int idx0 = (gid - var * CHUNKS) * 16;
-    const int field = S::IS_NES ? 0 : var >> 1;
-    const int inv_phase = S::IS_NES ? 0 : (field == (var & 1));
-    const int aux = S::IS_NES ? var : 0;                       /* VHS: the aberration band is patched in by k_margin */
+    /* inverse of skeleton_variant(); VHS: the aberration band is patched in by k_margin, aux = 0 here */
+    const int field = S::LINE_ROWS ? var / (CRTHIP_DCO_MAX + 1) : var >> 1;
+    const int frame = S::LINE_ROWS ? 0 : var & 1;
+    const int aux = S::LINE_ROWS ? var % (CRTHIP_DCO_MAX + 1) : 0;
     int line = idx0 / S::HRES;
     int t = idx0 - line * S::HRES;
     int vals[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         int v = 0;
-        if (!skeleton<S>(P, line, t, field, inv_phase, aux, true, v)) v = 0;
+        if (!skeleton<S>(P, line, t, field, frame, aux, true, v)) v = 0;
         vals[k] = v;
         if (++t == S::HRES) { t = 0; line++; }
     }
@@ -544,8 +552,10 @@ k_skeleton(const crthip_params P, signed char *__restrict__ skel, size_t fstride
  *     head   [0, S0)                                   S0 = yo*HRES + xo
  *     gap y  [S0 + y*HRES + destw, S0 + (y+1)*HRES)    y = 0 .. desth-2
  *     tail   [S0 + (desth-1)*HRES + destw, INPUT_SIZE)
- * and each lane takes one run of up to 16 samples of it: 16 bytes of the cached skeleton variant
- * (k_skeleton), + noise (LCG state by the 16-step jump table and a 16-entry table for the remainder). */
+ * (flat indices, exactly like the reference's analog[(x + xo) + (y + yo) * HRES]: a rectangle that runs over the
+ * end of a line simply continues in the next one) and each lane takes one run of up to 16 samples of it: 16 bytes
+ * of the cached skeleton variant (k_skeleton), + noise (LCG state by the 16-step jump table and a 16-entry table
+ * for the remainder). */
 template <class S, bool NOISE>
 __global__ void __launch_bounds__(256)
 k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
@@ -576,7 +586,7 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     if (len > 16) len = 16;
     const crthip_state *st = state + f;
     const int aux = st->aux;
-    const int var = S::IS_NES ? aux % 3 : ((st->field & 1) << 1) | (st->frame & 1);
+    const int var = skeleton_variant<S>(st->field, st->frame, aux);
     signed char *out = dst + (size_t) f * fstride;
     const v4i sk = load16u(skel + (size_t) var * fstride + idx0);
     int wds[4] = { sk.x, sk.y, sk.z, sk.w };
@@ -647,7 +657,8 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const unsigned char *img = (const unsigned char *) d_images;
     if constexpr (S::IS_NES) {
         if (p->w >= 8) {
-            hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, c->stream, *p, c->d_nes_tab);
+            /* the sample table depends on the black / white point only: rebuilt when those change, always on the
+             * context's main stream (crt_run_encoder_prepare), never concurrently with a reader */
             if (FULL && p->noise != 0)
                 hipLaunchKernelGGL((k_active_nes<S, true, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
             else
@@ -679,8 +690,6 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
         const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
         const int tail = (tail_len + 15) / 16;
         const int total = n * (head + (p->desth - 1) * gap + tail);
-        constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
-        hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
         if (p->noise != 0)
             hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
                                *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
@@ -699,27 +708,33 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
     return CRTHIP_OK;
 }
 
-/* after crt_modulate: ccf preset (crt_ntsc.c:325-329, crt_nes.c:196-200), VHS resets (crt_ntscvhs.c:259,332-336) */
+/* after crt_modulate: ccf preset (crt_ntsc.c:325-329, crt_nes.c:196-200, crt_snes.c:238-240,321-325),
+ * VHS resets (crt_ntscvhs.c:259,332-336) */
 template <class S>
 __global__ void k_encoder_state(const crthip_params P, int n_fields, crthip_state *state)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_fields) return;
     crthip_state *st = state + f;
-    if constexpr (S::IS_NES) {
-        for (int r = 0; r < 3; r++) {
-            /* iccf[n % 3] is last written by the bottom-most line with that residue; all lines of a
-             * residue class write the same burst, so any line n of the class will do */
-            for (int k = 0; k < 4; k++) {
-                int cb = P.burst[(r + st->aux) % 3][k];
-                st->ccf[r][k] = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
+    if constexpr (S::LINE_ROWS) {
+        /* iccf[(n + CCF_SHIFT) % VPER][t % CCS] is last written by the bottom-most line of its class; all lines of
+         * a class write the same burst, so any line n of the class will do */
+        for (int cls = 0; cls < S::VPER; cls++) {
+            const int row = carrier_row<S>(cls, st->field, st->frame, st->aux);
+            for (int k = 0; k < S::CCS; k++) {
+                const int cb = P.burst[row][k];
+                st->ccf[(cls + S::CCF_SHIFT) % S::VPER][k] = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
             }
         }
+        if (!S::NES_TIMING) {
+            st->field &= 1;
+            st->frame &= 1;
+        }
     } else {
-        const int inv_phase = ((st->field & 1) == (st->frame & 1));
+        const int row = carrier_row<S>(0, st->field, st->frame, st->aux);
         for (int k = 0; k < 4; k++) {
-            int cb = S::PATTERN == 1 ? P.burst[0][(k + inv_phase * 2) & 3] : P.burst[0][k];
-            int v = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
+            const int cb = P.burst[row][k];
+            const int v = ((int) (signed char) ((S::BLANK + cb * S::BURST) >> 5)) << 7;
             st->ccf[0][k] = S::IS_VHS ? 0 : v;
         }
         if (S::IS_VHS) st->hsync = 0;
@@ -728,6 +743,32 @@ __global__ void k_encoder_state(const crthip_params P, int n_fields, crthip_stat
     }
 }
 
+/* Encoder tables that depend on the parameter blob only (clean skeleton variants, NES sample table): (re)built on
+ * the context's CURRENT stream when the inputs they derive from changed.  crthip_fieldpass calls this before it
+ * forks onto its second stream, so the chunks only ever read the tables. */
+int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        if (fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0)) {
+            constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
+            ProfScope ps(c, CRTHIP_K_TEMPLATE);
+            hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
+            memcpy(c->skel_burst, p->burst, sizeof(p->burst));
+            c->skel_valid = true;
+        }
+        if constexpr (S::IS_NES) {
+            if (!c->nes_tab_valid || c->nes_tab_black != p->black_point || c->nes_tab_white != p->white_point) {
+                ProfScope ps(c, CRTHIP_K_ACTIVE);
+                hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, c->stream, *p, c->d_nes_tab);
+                c->nes_tab_black = p->black_point;
+                c->nes_tab_white = p->white_point;
+                c->nes_tab_valid = true;
+            }
+        }
+        return CRTHIP_OK;
+    });
+}
 
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                     signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state)

@@ -274,13 +274,17 @@ static int check_params(crthip_ctx *c, const crthip_params *p, int n)
     return CRTHIP_OK;
 }
 
-/* the encoder contract: the active rectangle lies inside the field (the reference would
- * scribble over neighbouring lines / out of bounds otherwise, crt_ntsc.c:322) */
+/* The encoder contract.  The reference writes analog[(x + xo) + (y + yo) * HRES] (crt_ntsc.c:322) -- a FLAT index:
+ * a rectangle that runs over the end of a line (xoffset = 4 in standard NTSC: 160 + 753 > 910) simply continues in
+ * the next line's front porch, and the kernels do exactly the same (they work on flat indices too).  What is refused
+ * is only what is undefined in the reference: samples outside analog[], and negative origins (negative carrier
+ * table index, crt_ntsc.c:314). */
 static int check_encoder(crthip_ctx *c, const crthip_params *p)
 {
     if (c->system != CRTHIP_SYSTEM_NES && p->in_bpp == 0) return 1;   /* silent no-op, crt_ntsc.c:190-193 */
-    if (p->xo < 0 || p->yo < 0 || p->xo + p->destw > c->sd.hres || p->yo + p->desth > c->sd.vres || p->destw <= 0 || p->desth <= 0)
-        return set_err(c, CRTHIP_E_ARG, "active rectangle leaves the field (xoffset/yoffset out of contract)", hipSuccess);
+    const long long end = (long long) p->yo * c->sd.hres + p->xo + (long long) (p->desth - 1) * c->sd.hres + p->destw;
+    if (p->xo < 0 || p->yo < 0 || p->destw <= 0 || p->desth <= 0 || p->destw > c->sd.hres || end > c->sd.input_size)
+        return set_err(c, CRTHIP_E_ARG, "active rectangle leaves analog[] (xoffset/yoffset out of contract)", hipSuccess);
     return CRTHIP_OK;
 }
 
@@ -293,6 +297,8 @@ int crthip_modulate(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     if (rc) return rc < 0 ? rc : CRTHIP_OK;
     if (!d_images || !d_analog || !d_state) return CRTHIP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    rc = crt_run_encoder_prepare(c, p, false);
+    if (rc) return rc;
     rc = crt_run_encoder(c, p, n, d_images, istride, d_analog, d_state, false, (p->flags & CRTHIP_F_NES_SETUP) != 0, true);
     HIPCHK(c, hipGetLastError());
     return rc;
@@ -409,6 +415,11 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
      * caller's stream and an internal one: the latency-bound kernels of one chunk (sync chain,
      * margins, launch gaps) then overlap the VALU-bound kernels of the other.  The internal stream
      * is fenced by events on both sides, so to the caller everything is still ordered on ITS stream. */
+    if (enc == 0) {
+        /* tables shared by all chunks are (re)built here, on the caller's stream, before any fork */
+        rc = crt_run_encoder_prepare(c, p, true);
+        if (rc) return rc;
+    }
     const int nchunks = (c->overlap_chunks > 1 && n >= 256 * c->overlap_chunks && !c->prof) ? c->overlap_chunks : 1;
     if (nchunks == 1) {
         rc = fieldpass_chunk(c, p, enc, 0, n, d_images, istride, d_out, ostride, d_state);
@@ -481,6 +492,8 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     crthip_state first;
     HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = crt_run_encoder_prepare(c, p, true);
+    if (rc) return rc;
     if (vhs) {
         /* the fields share one rand() stream: run the chain ahead (k_vhs_chain: hist[k] = generator at the start
          * of field k, aberration heights drawn in-stream if asked), after which every field is independent;
@@ -535,6 +548,13 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     hipLaunchKernelGGL(k_seq_weave, dim3((unsigned) n * (unsigned) outh), dim3(256), 0, c->stream, n, outh, pitch,
                        (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, latest);
     HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_shape(crthip_ctx *c, int shape)
+{
+    if (!c || shape < 0 || shape > 2) return CRTHIP_E_ARG;
+    c->shape = shape;
     return CRTHIP_OK;
 }
 

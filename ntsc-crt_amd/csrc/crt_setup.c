@@ -128,17 +128,28 @@ crt_sysdef_get(struct crt_sysdef *d, int system, int chroma_pattern)
     d->system = system;
     d->chroma_pattern = chroma_pattern;
     d->vres = 262;
-    if (system == CRTHIP_SYSTEM_NTSC || system == CRTHIP_SYSTEM_NTSCVHS) {
-        /* crt_ntsc.h:25-109: times in ns on a 63500 ns line */
+    d->cc_samples = 4;
+    d->cb_len = 40;
+    d->burst_off = 33;
+    d->q_off = -90;
+    d->hue_in_mod = 1;
+    d->equ_a_lo = 0; d->equ_a_hi = 3; d->equ_b_lo = 7; d->equ_b_hi = 9;     /* crt_ntsc.c:211 */
+    d->vs_lo = 4; d->vs_hi = 6; d->vs_by_field = 1;                            /* crt_ntsc.c:217-223 */
+    if (system == CRTHIP_SYSTEM_NTSC || system == CRTHIP_SYSTEM_NTSCVHS || system == CRTHIP_SYSTEM_TEMP) {
+        /* crt_ntsc.h:25-109 (= crt_ntscvhs.h, crt_template.h): times in ns on a 63500 ns line */
         const int line_ns = 63500;
-        if (chroma_pattern != 0 && chroma_pattern != 1) {
+        if (system == CRTHIP_SYSTEM_TEMP) {
+            if (chroma_pattern != 1) {
+                return CRTHIP_E_ARG;
+            }
+        } else if (chroma_pattern != 0 && chroma_pattern != 1) {
             return CRTHIP_E_ARG;
         }
         cc_line = (chroma_pattern == 1) ? 2275 : 2280;
         d->hres = cc_line * 4 / 10;
         d->top = 21;
         d->bot = 261;
-        d->vper = 1;
+        d->vper = (system == CRTHIP_SYSTEM_TEMP) ? 2 : 1;
         d->hsync_window = 8;
         d->vsync_window = 8;
         d->white_level = 100;
@@ -151,33 +162,102 @@ crt_sysdef_get(struct crt_sysdef *d, int system, int chroma_pattern)
         d->cb_beg = 6800 * d->hres / line_ns;
         d->av_beg = 10900 * d->hres / line_ns;
         d->av_len = 52600 * d->hres / line_ns;
+        d->field_rows = 1;
         if (system == CRTHIP_SYSTEM_NTSCVHS) {   /* VHS_SP, crt_ntscvhs.h:109-113 */
             d->y_freq = 300000;
             d->i_freq = 62700;
             d->q_freq = 62700;
-        } else {                                 /* crt_ntsc.h:99-102 */
+        } else {                                 /* crt_ntsc.h:99-102, crt_template.h:107-110 */
             d->y_freq = 420000;
             d->i_freq = 150000;
             d->q_freq = 55000;
         }
-    } else if (system == CRTHIP_SYSTEM_NES) {
-        /* crt_nes.h:30-126: positions in PPU pixels on a 341 px line */
-        const int line_px = 341;
-        if (chroma_pattern < 0 || chroma_pattern > 2) {
+        if (system == CRTHIP_SYSTEM_TEMP) {      /* crt_template.h:133-146, crt_template.c:171-183,240 */
+            d->line_rows = 1;
+            d->burst_off = -60 - 90;
+            d->equ_a_hi = 2;
+            d->vs_lo = 3;
+            d->ccf_row_shift = 3;
+        }
+    } else if (system == CRTHIP_SYSTEM_PV1K) {
+        /* crt_pv1k.h:24-98: 5 samples per chroma cycle; times in units of 4 dots (892 ns), 71 units per line */
+        const int unit = 892, line_ns = 71 * 892;
+        if (chroma_pattern != 1) {
             return CRTHIP_E_ARG;
         }
-        cc_line = (chroma_pattern == 1) ? 2275 : ((chroma_pattern == 2) ? 2273 : 2280);
+        d->hres = 2304 * 5 / 6;
+        d->top = 21;
+        d->bot = 261;
+        d->vper = 5;
+        d->cc_samples = 5;
+        d->cb_len = 50;
+        d->hsync_window = 8;
+        d->vsync_window = 8;
+        d->white_level = 100;
+        d->burst_level = 20;
+        d->black_level = 7;
+        d->blank_level = 0;
+        d->sync_level = -40;
+        d->sync_beg = 3 * unit * d->hres / line_ns;
+        d->bw_beg = 6 * unit * d->hres / line_ns;
+        d->cb_beg = 8 * unit * d->hres / line_ns;
+        d->av_beg = 16 * unit * d->hres / line_ns;
+        d->av_len = 55 * unit * d->hres / line_ns;
+        d->y_freq = 420000;
+        d->i_freq = 150000;
+        d->q_freq = 55000;
+        d->field_rows = 1;
+        d->line_rows = 1;
+        d->burst_off = -72;                      /* crt_pv1k.c:172: n - step */
+        d->q_off = 90;
+        d->equ_a_hi = -1;                        /* crt_pv1k.c:197: only lines 7..9 */
+        d->vs_lo = 258;                          /* crt_pv1k.c:204 */
+        d->vs_hi = 260;
+        d->ccf_row_shift = 3;
+    } else if (system == CRTHIP_SYSTEM_NES || system == CRTHIP_SYSTEM_NESRGB || system == CRTHIP_SYSTEM_SNES) {
+        /* crt_nes.h:30-126, crt_nesrgb.h, crt_snes.h:24-116: positions in PPU pixels on a 341 px line */
+        const int line_px = 341;
+        if (system == CRTHIP_SYSTEM_SNES) {
+            if (chroma_pattern != 1) {
+                return CRTHIP_E_ARG;
+            }
+            cc_line = 2273;
+        } else {
+            if (chroma_pattern < 0 || chroma_pattern > 2) {
+                return CRTHIP_E_ARG;
+            }
+            cc_line = (chroma_pattern == 1) ? 2275 : ((chroma_pattern == 2) ? 2273 : 2280);
+        }
         d->hres = cc_line * 4 / 10;
         d->top = 15;
         d->bot = 255;
         d->vper = 3;
         d->hsync_window = 6;
         d->vsync_window = 6;
-        d->white_level = 110;
-        d->burst_level = 30;
-        d->black_level = 0;
         d->blank_level = 0;
-        d->sync_level = -37;
+        if (system == CRTHIP_SYSTEM_SNES) {
+            d->white_level = 100;
+            d->burst_level = 20;
+            d->black_level = 7;
+            d->sync_level = -40;
+            d->burst_off = 210 - 90;             /* crt_snes.c:176: n - step + HUE_OFFSET */
+            d->equ_a_hi = 2;                     /* crt_snes.h:137-146 */
+            d->vs_lo = 3;
+            d->vs_by_field = 0;                  /* crt_snes.c:216-218: even pattern only */
+            d->ccf_row_shift = 3;
+        } else {
+            d->white_level = (system == CRTHIP_SYSTEM_NES) ? 110 : 100;
+            d->burst_level = 30;
+            d->black_level = 0;
+            d->sync_level = -37;
+            d->nes_timing = 1;
+            d->ppu_input = (system == CRTHIP_SYSTEM_NES);
+            if (system == CRTHIP_SYSTEM_NESRGB) {
+                d->burst_off = 90 + 33;          /* crt_nesrgb.c:72 */
+                d->hue_in_mod = 0;
+            }
+        }
+        d->line_rows = 1;
         d->sync_beg = 9 * d->hres / line_px;
         d->bw_beg = 34 * d->hres / line_px;
         d->cb_beg = 38 * d->hres / line_px;
@@ -186,6 +266,10 @@ crt_sysdef_get(struct crt_sysdef *d, int system, int chroma_pattern)
         d->vs_sep_end = 327 * d->hres / line_px;
     } else {
         return CRTHIP_E_ARG;
+    }
+    d->vert_step = d->vper > 1 ? 360 / d->vper : 0;
+    if (system == CRTHIP_SYSTEM_PV1K) {
+        d->vert_step = 360 * 2 / 5;              /* crt_pv1k.c:168 */
     }
     d->input_size = d->hres * d->vres;
     d->lines = d->bot - d->top;
@@ -218,7 +302,7 @@ int
 crthip_lines(int system)
 {
     struct crt_sysdef d;
-    if (crt_sysdef_get(&d, system, system == CRTHIP_SYSTEM_NES ? 2 : 1) != CRTHIP_OK) {
+    if (crt_sysdef_get(&d, system, (system == CRTHIP_SYSTEM_NES || system == CRTHIP_SYSTEM_NESRGB) ? 2 : 1) != CRTHIP_OK) {
         return 0;
     }
     return d.lines;
@@ -229,11 +313,13 @@ crthip_field_stride(int system, int chroma_pattern)
 {
     /* INPUT_SIZE + room for the mirrored struct tail and for the widest out-of-contract
      * window (pos <= INPUT_SIZE-1, window AV_LEN, 16-byte vector reads), rounded to 256 */
-    size_t n = (size_t) crthip_input_size(system, chroma_pattern);
-    if (n == 0) {
+    struct crt_sysdef d;
+    size_t n;
+    if (crt_sysdef_get(&d, system, chroma_pattern) != CRTHIP_OK) {
         return 0;
     }
-    n += 1024;
+    n = (size_t) d.input_size;
+    n += (size_t) (d.av_len > 960 ? 2048 : 1024);
     return (n + 255) & ~(size_t) 255;
 }
 
@@ -273,13 +359,16 @@ lowpass_coef(int limit)
 int
 crthip_params_finalize(crthip_params *p)
 {
-    /* crt_core.c:278-280: band edges in kHz and band gains (Q16) for Y, I, Q */
+    /* crt_core.c:272-286: band edges in kHz and band gains (Q16) for Y, I, Q */
     static const int edge_khz[3][2] = { { 1500, 3000 }, { 80, 1150 }, { 80, 1000 } };
-    static const int band_gain[3][3] = {
+    static const int band_gain4[3][3] = {
         { 65536, 8192, 9175 }, { 65536, 65536, 1311 }, { 65536, 65536, 0 }
     };
+    static const int band_gain5[3][3] = {           /* CRT_CC_SAMPLES == 5, crt_core.c:281-283 */
+        { 65536, 12192, 7775 }, { 65536, 65536, 1311 }, { 65536, 65536, 0 }
+    };
     struct crt_sysdef d;
-    int k, r, sn, cs;
+    int k, r, sn, cs, rows;
 
     if (p == 0 || crt_sysdef_get(&d, p->system, p->chroma_pattern) != CRTHIP_OK) {
         return CRTHIP_E_ARG;
@@ -293,31 +382,46 @@ crthip_params_finalize(crthip_params *p)
     if (p->eq_kernel != 0 && (p->eq_kernel < 4 || p->eq_kernel > 7)) {
         return CRTHIP_E_ARG;
     }
+    p->bloom = (p->flags & CRTHIP_F_BLOOM) != 0;                /* crt_core.h:70 */
+    if (p->bloom && (d.nes_timing || p->eq_kernel != 0)) {
+        return CRTHIP_E_ARG;                                    /* "does not work for NES" (crt_core.h:70) */
+    }
 
     memset(p->burst, 0, sizeof(p->burst));
     memset(p->modI, 0, sizeof(p->modI));
     memset(p->modQ, 0, sizeof(p->modQ));
-    if (p->system == CRTHIP_SYSTEM_NES) {
-        /* crt_nes.c:110-136.  burst row r serves lines with (n + dot_crawl_offset) % 3 == r */
+    memset(p->dem_cs, 0, sizeof(p->dem_cs));
+    memset(p->dem_sn, 0, sizeof(p->dem_sn));
+    p->iir_c[0] = p->iir_c[1] = p->iir_c[2] = 0;
+    if (d.ppu_input) {
+        /* crt_nes.c:110-136.  Row r = (line % 3) + dot_crawl_offset: the reference reduces the ANGLE mod 360 with
+         * C's truncating %, not the row, so the unreduced row keeps negative hues exact */
         p->in_bpp = 2;
         p->destw = d.av_len;
         p->desth = d.lines;
         p->xo = (d.av_beg + p->xoffset) & ~3;
         p->yo = d.top + p->yoffset;
-        for (r = 0; r < 3; r++) {
+        for (r = 0; r < CRTHIP_CARRIER_ROWS; r++) {
             for (k = 0; k < 4; k++) {
                 int ang = (p->hue + k * 90 + r * 120 + 33) % 360;
                 crt_setup_sincos14(&sn, &cs, ang * 8192 / 180);
                 p->burst[r][k] = sn >> 10;
             }
         }
-        p->iir_c[0] = p->iir_c[1] = p->iir_c[2] = 0;
     } else {
-        /* crt_ntsc.c:132-133, 163-203 */
+        const int step = 360 / d.cc_samples;
         p->in_bpp = crt_setup_bpp4fmt(p->format);
+        /* geometry: crt_ntsc.c:132-133, 148-173, 194-203; crt_nesrgb.c:51-52, 85-89 */
         p->destw = d.av_len;
-        p->desth = (d.lines * 64500) >> 16;
-        if (p->raw) {
+        if (d.nes_timing) {
+            p->desth = d.lines;
+        } else if (p->bloom) {
+            p->destw = (d.av_len * 55500) >> 16;
+            p->desth = (d.lines * 63500) >> 16;
+        } else {
+            p->desth = (d.lines * 64500) >> 16;
+        }
+        if (p->raw && !d.nes_timing) {
             if (p->w < p->destw) {
                 p->destw = p->w;
             }
@@ -325,22 +429,49 @@ crthip_params_finalize(crthip_params *p)
                 p->desth = p->h;
             }
         }
-        p->xo = (d.av_beg + p->xoffset + (d.av_len - p->destw) / 2) & ~3;
+        p->xo = d.av_beg + p->xoffset + (d.av_len - p->destw) / 2;
         p->yo = d.top + p->yoffset + (d.lines - p->desth) / 2;
-        if (p->as_color) {
-            for (k = 0; k < 4; k++) {
-                int ang = p->hue + k * 90;
-                crt_setup_sincos14(&sn, &cs, (ang + 33) * 8192 / 180);
-                p->burst[0][k] = sn >> 10;
-                crt_setup_sincos14(&sn, &cs, ang * 8192 / 180);
-                p->modI[k] = sn >> 10;
-                crt_setup_sincos14(&sn, &cs, (ang - 90) * 8192 / 180);
-                p->modQ[k] = sn >> 10;
+        if (d.line_rows && !d.nes_timing) {
+            p->xo = p->xo - (p->xo % d.cc_samples);             /* crt_snes.c:201 */
+        } else {
+            p->xo &= ~3;
+        }
+        if (p->as_color || d.nes_timing) {                      /* NES-RGB has no as_color member: always colour */
+            rows = d.line_rows ? CRTHIP_CARRIER_ROWS : 1;
+            for (r = 0; r < rows; r++) {
+                for (k = 0; k < d.cc_samples; k++) {
+                    /* crt_ntsc.c:175-182; crt_snes.c:171-182; crt_pv1k.c:167-178; crt_nesrgb.c:67-78 */
+                    int ang = r * d.vert_step + k * step;
+                    int hue_mod = d.hue_in_mod ? p->hue : 0;
+                    crt_setup_sincos14(&sn, &cs, (ang + p->hue + d.burst_off) * 8192 / 180);
+                    p->burst[r][k] = sn >> 10;
+                    crt_setup_sincos14(&sn, &cs, (ang + hue_mod) * 8192 / 180);
+                    p->modI[r][k] = sn >> 10;
+                    crt_setup_sincos14(&sn, &cs, (ang + hue_mod + d.q_off) * 8192 / 180);
+                    p->modQ[r][k] = sn >> 10;
+                }
+            }
+            if (!d.line_rows) {
+                /* row 1 = the lines of a field whose parity equals the frame's (inv_phase, crt_ntsc.c:199-200,
+                 * 243-247): burst advanced by half a cycle, modulation carriers negated -- CRT_CHROMA_PATTERN 1 only */
+                for (k = 0; k < 4; k++) {
+                    if (p->chroma_pattern == 1) {
+                        p->burst[1][k] = p->burst[0][(k + 2) & 3];
+                        p->modI[1][k] = -p->modI[0][k];
+                        p->modQ[1][k] = -p->modQ[0][k];
+                    } else {
+                        p->burst[1][k] = p->burst[0][k];
+                        p->modI[1][k] = p->modI[0][k];
+                        p->modQ[1][k] = p->modQ[0][k];
+                    }
+                }
             }
         }
-        p->iir_c[0] = lowpass_coef(d.y_freq);
-        p->iir_c[1] = lowpass_coef(d.i_freq);
-        p->iir_c[2] = lowpass_coef(d.q_freq);
+        if (d.y_freq != 0) {
+            p->iir_c[0] = lowpass_coef(d.y_freq);
+            p->iir_c[1] = lowpass_coef(d.i_freq);
+            p->iir_c[2] = lowpass_coef(d.q_freq);
+        }
     }
 
     /* crt_core.c:171-196 with EQ_P = 16: cut-off as 2*sin(pi*f/rate), Q16 */
@@ -352,7 +483,7 @@ crthip_params_finalize(crthip_params *p)
         crt_setup_sincos14(&sn, &cs, 8192 * f_hi / d.hres);
         p->eq_hf[k] = 2 * (sn << 1);
         for (r = 0; r < 3; r++) {
-            p->eq_g[k][r] = band_gain[k][r];
+            p->eq_g[k][r] = d.cc_samples == 5 ? band_gain5[k][r] : band_gain4[k][r];
         }
     }
 
@@ -360,11 +491,28 @@ crthip_params_finalize(crthip_params *p)
     crt_setup_sincos14(&sn, &cs, ((p->mon_hue % 360) + 33) * 8192 / 180);
     p->huesn = sn >> 11;
     p->huecs = cs >> 11;
+    if (d.cc_samples == 5) {
+        /* crt_core.c:484,497-505: demodulation carriers rotated by the monitor hue, one entry per sample phase */
+        int ang = p->mon_hue % 360;
+        for (k = 0; k < 5; k++) {
+            crt_setup_sincos14(&sn, &cs, ang * 8192 / 180);
+            p->dem_cs[0][k] = cs;
+            p->dem_sn[0][k] = sn;
+            crt_setup_sincos14(&sn, &cs, (ang + 90) * 8192 / 180);
+            p->dem_cs[1][k] = cs;
+            p->dem_sn[1][k] = sn;
+            ang += 360 / 5;
+        }
+    }
     p->bright = p->brightness - (d.black_level + p->black_point);
     p->white = d.white_level * p->white_point / 100;
     p->ire_base = d.black_level + p->black_point;
     p->dx = ((d.av_len - 1) << 12) / p->outw;
     p->ratio = (((p->outh << 16) / d.lines) + 32768) >> 16;
+    p->bloom_max_e = (128 + (p->noise / 2)) * d.av_len;         /* crt_core.c:400 */
+    if (p->bloom && p->bloom_max_e <= 0) {
+        return CRTHIP_E_ARG;                                    /* the reference would divide by zero (:522) */
+    }
     p->finalized = CRTHIP_PARAMS_MAGIC;
     return CRTHIP_OK;
 }

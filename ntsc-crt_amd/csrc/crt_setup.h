@@ -24,7 +24,20 @@ struct crt_sysdef {
     int sync_beg, bw_beg, cb_beg, av_beg, av_len;
     int vs_sep_end;                  /* NES: PPUpx2pos(327), crt_nes.c:95 */
     int white_level, burst_level, black_level, blank_level, sync_level;
-    int y_freq, i_freq, q_freq;      /* encoder band limits (0 for NES) */
+    int y_freq, i_freq, q_freq;      /* encoder band limits (0: no band limit) */
+    int cc_samples, cb_len;          /* CRT_CC_SAMPLES; CB_CYCLES * CRT_CB_FREQ */
+    /* what differs between the RGB encoders crt_ntsc.c / crt_ntscvhs.c / crt_snes.c / crt_template.c / crt_pv1k.c /
+     * crt_nesrgb.c */
+    int ppu_input;                   /* NES: the image is 9-bit PPU pixels (crt_nes.c) */
+    int nes_timing;                  /* NES, NES-RGB: setup_field skeleton, full-height progressive geometry */
+    int field_rows;                  /* source row offset by field parity (crt_ntsc.c:258) */
+    int line_rows;                   /* carrier tables per line class + dot_crawl_offset (crt_snes.c:171-183) */
+    int vert_step;                   /* degrees per line class */
+    int burst_off, q_off;            /* burst / Q carrier angle relative to the I carrier, degrees */
+    int hue_in_mod;                  /* the encoder hue rotates the modulation carriers too (not NES-RGB, crt_nesrgb.c:72-77) */
+    int equ_a_lo, equ_a_hi, equ_b_lo, equ_b_hi;   /* equalising-pulse lines, inclusive */
+    int vs_lo, vs_hi, vs_by_field;   /* vertical sync lines, inclusive; odd-field pattern (crt_ntsc.c:219-223) */
+    int ccf_row_shift;               /* ccf preset row = (line + shift) % vper: 3 in crt_snes.c:240, 0 in crt_nes.c:177 */
 };
 
 /* returns 0, or CRTHIP_E_ARG for a system outside SURVEY.md section 8 */

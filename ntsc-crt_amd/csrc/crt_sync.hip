@@ -52,38 +52,47 @@ k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthi
     crthip_state *st = state + f;
     const int vsync = st->vsync;
     int vline = 0, vj = S::HRES;
-    v4i cand[2 * S::VWIN];
+    constexpr int PIECES = (S::HRES + 1023) / 1024;      /* 64 lanes x 16 samples per piece; 2 pieces for the PV-1000's 1920 */
+    v4i cand[2 * S::VWIN][PIECES];
 #pragma unroll
     for (int i = 0; i < 2 * S::VWIN; i++) {
         const int l = posmod(vsync + i - S::VWIN, S::VRES);
-        cand[i] = load16u(in + l * S::HRES + lane * 16);
+#pragma unroll
+        for (int pc = 0; pc < PIECES; pc++) cand[i][pc] = load16u(in + l * S::HRES + pc * 1024 + lane * 16);
     }
     bool found = false;
 #pragma unroll
     for (int i = 0; i < 2 * S::VWIN; i++) {
-        if (!found) {
-            vline = posmod(vsync + i - S::VWIN, S::VRES);
-            const int wds[4] = { cand[i].x, cand[i].y, cand[i].z, cand[i].w };
-            int pre[16];
-            int run = 0;
+        int carry = 0;                                   /* sum of the line's earlier pieces */
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
-                if (lane * 16 + k >= S::HRES) s = 0;
-                run += s;
-                pre[k] = run;
-            }
-            const int excl = wave_incl_scan(run) - run;
-            int first = 16;
+        for (int pc = 0; pc < PIECES; pc++) {
+            if (!found) {
+                vline = posmod(vsync + i - S::VWIN, S::VRES);
+                const int wds[4] = { cand[i][pc].x, cand[i][pc].y, cand[i][pc].z, cand[i][pc].w };
+                const int s0 = pc * 1024 + lane * 16;
+                int pre[16];
+                int run = 0;
 #pragma unroll
-            for (int k = 15; k >= 0; k--) {
-                if (lane * 16 + k < S::HRES && excl + pre[k] <= S::VTHR) first = k;
-            }
-            const unsigned long long m = __ballot(first < 16);
-            if (m) {
-                const int L = __ffsll((long long) m) - 1;
-                vj = L * 16 + __builtin_amdgcn_readlane(first, L);
-                found = true;
+                for (int k = 0; k < 16; k++) {
+                    int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
+                    if (s0 + k >= S::HRES) s = 0;
+                    run += s;
+                    pre[k] = run;
+                }
+                const int incl = wave_incl_scan(run);
+                const int excl = carry + incl - run;
+                int first = 16;
+#pragma unroll
+                for (int k = 15; k >= 0; k--) {
+                    if (s0 + k < S::HRES && excl + pre[k] <= S::VTHR) first = k;
+                }
+                const unsigned long long m = __ballot(first < 16);
+                if (m) {
+                    const int L = __ffsll((long long) m) - 1;
+                    vj = pc * 1024 + L * 16 + __builtin_amdgcn_readlane(first, L);
+                    found = true;
+                }
+                carry += __builtin_amdgcn_readlane(incl, 63);
             }
         }
     }
@@ -95,18 +104,23 @@ k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthi
     }
 }
 
-#define SYNC_WIN      256      /* bytes of a line's parked sync/burst window (16 lanes x 16 bytes) */
-#define SYNC_WIN_BACK 40       /* window starts this far before ln + hsync                         */
+#define SYNC_WIN_BACK 40       /* a line's parked window starts this far before ln + hsync */
 
-/* D4-D7, crt_core.c:428-479.  Needs state.vsync / state.odd_field from k_vsync. */
+/* D4-D7, crt_core.c:428-510.  Needs state.vsync / state.odd_field from k_vsync. */
 template <class S>
 __global__ void __launch_bounds__(64)
 k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
         crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
 {
-    __shared__ int s_win[4][3][SYNC_WIN / 4];
-    __shared__ int s_fb[4][16];                          /* fallback scratch: 16 hsync + 40 burst bytes per row */
-    __shared__ int s_lines[4][S::LINES * 6];              /* the rows' line tables; written to memory after the loop so
+    constexpr int WIN = S::SYNC_WIN;                     /* bytes of a line's parked sync/burst window (16 lanes x WP x 16 bytes) */
+    constexpr int WP = WIN / 256;                        /* 16-byte pieces per lane */
+    constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS; /* burst samples per carrier phase */
+    constexpr int LW = 8;                                /* ints per line table entry */
+    static_assert(sizeof(crthip_line) == LW * 4, "line table entry");
+    __shared__ int s_win[4][3][WIN / 4];
+    __shared__ int s_fb[4][(16 + S::CB_LEN + 3) / 4 + 1]; /* fallback scratch: 16 hsync + CB_LEN burst bytes per row */
+    __shared__ int s_cc[4][8];                            /* 5-sample systems: the row's five integrators */
+    __shared__ int s_lines[4][S::LINES * LW];             /* the rows' line tables; written to memory after the loop so
                                                              that no store sits between the window prefetches */
     const int lane = threadIdx.x;
     const int row = lane >> 4, j = lane & 15;            /* field slot in the wave, lane in the row */
@@ -118,9 +132,10 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
     int hsync = st->hsync;
     const int vsync = st->vsync;
     const int field_rows = st->odd_field * (P.ratio / 2);             /* crt_core.c:407 */
-    int ccr[S::VPER];                                    /* lane holds ccf[r][j & 3] */
+    const int phase = CCS == 4 ? (j & 3) : j % CCS;      /* the carrier phase this lane integrates */
+    int ccr[S::VPER];                                    /* lane holds ccf[r][phase] */
 #pragma unroll
-    for (int r = 0; r < S::VPER; r++) ccr[r] = st->ccf[r][j & 3];
+    for (int r = 0; r < S::VPER; r++) ccr[r] = st->ccf[r][phase];
     crthip_line *out_lines = lines + (size_t) fc * S::LINES;
 
     /* flat base of the window of line `line` assuming hsync h (row-uniform) */
@@ -130,15 +145,18 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         const int b = l * S::HRES + h - SYNC_WIN_BACK;
         return b < 0 ? 0 : b;
     };
-    /* each of the 16 lanes of a row moves 16 bytes of its field's window */
+    /* each of the 16 lanes of a row moves WP x 16 bytes of its field's window */
     int base_cur = window_base(S::TOP, hsync);           /* window parked for the current line */
-    {
-        const v4i w = load16u(in + base_cur + j * 16);
-        int *d = s_win[row][S::TOP % 3] + j * 4;
+#pragma unroll
+    for (int q = 0; q < WP; q++) {
+        const v4i w = load16u(in + base_cur + q * 256 + j * 16);
+        int *d = s_win[row][S::TOP % 3] + q * 64 + j * 4;
         d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
     }
     int base_p = window_base(S::TOP + 1, hsync);         /* window in flight for line + 1 */
-    v4i wp = load16u(in + base_p + j * 16);
+    v4i wp[WP];
+#pragma unroll
+    for (int q = 0; q < WP; q++) wp[q] = load16u(in + base_p + q * 256 + j * 16);
     __syncthreads();
 
     const unsigned span = (unsigned) P.outh + P.v_fac;
@@ -146,8 +164,13 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
     for (int line = S::TOP; line < S::BOT; line++) {
         /* speculative fetch of the window of line + 2 (see the comment above) */
         const int base_n = window_base(line + 2, hsync);
-        v4i wn = wp;
-        if (line + 2 < S::BOT) wn = load16u(in + base_n + j * 16);
+        v4i wn[WP];
+#pragma unroll
+        for (int q = 0; q < WP; q++) wn[q] = wp[q];
+        if (line + 2 < S::BOT) {
+#pragma unroll
+            for (int q = 0; q < WP; q++) wn[q] = load16u(in + base_n + q * 256 + j * 16);
+        }
         const signed char *win = (const signed char *) s_win[row][line % 3];
 
         /* D4, crt_core.c:428-432 (unsigned arithmetic: v_fac is unsigned) */
@@ -170,7 +193,7 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         /* the fast path reads LDS only; if the bytes are not in the parked window (rare) the fallback fetches
          * them into an LDS scratch row INSIDE its own branch, so no memory wait leaks into the common path */
         signed char *fb = (signed char *) s_fb[row];
-        const bool a_in = a_off >= 0 && a_off + 2 * S::HWIN <= SYNC_WIN;
+        const bool a_in = a_off >= 0 && a_off + 2 * S::HWIN <= WIN;
         if (!a_in) {
             if (j < 2 * S::HWIN) fb[j] = in[ln + hsync + S::SYNC_BEG - S::HWIN + j];
             __builtin_amdgcn_s_waitcnt(0);
@@ -201,27 +224,28 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         if (ypos >= S::VRES) ypos -= S::VRES;
         const int pos = xpos + ypos * S::HRES;
 
-        /* D6 burst lock, crt_core.c:456-467.  Lane j integrates phase (j & 3): its samples are burst
-         * bytes k0, k0+4, ... with (CB_BEG + k0) & 3 == (j & 3) */
-        const int b_off = ln + (hsync & ~3) + S::CB_BEG - base_cur;
-        const bool b_in = b_off >= 0 && b_off + CB_SAMPLES <= SYNC_WIN;
-        const int k0 = ((j & 3) - S::CB_BEG) & 3;
+        /* D6 burst lock, crt_core.c:456-467.  The lane of carrier phase p integrates the burst bytes CB_BEG + k0,
+         * CB_BEG + k0 + CCS, ... with (CB_BEG + k0) % CCS == p; the burst is read from the sample grid aligned to
+         * the chroma cycle (hsync & ~3, :459; hsync - hsync % 5, :461) */
+        const int halign = CCS == 4 ? (hsync & ~3) : hsync - hsync % CCS;
+        const int b_off = ln + halign + S::CB_BEG - base_cur;
+        const bool b_in = b_off >= 0 && b_off + S::CB_LEN <= WIN;
+        const int k0 = CCS == 4 ? ((phase - S::CB_BEG) & 3) : ((phase - S::CB_BEG) % CCS + CCS) % CCS;
         if (!b_in) {
-            const signed char *g = in + ln + (hsync & ~3) + S::CB_BEG;
-            if (j < 10) { fb[16 + 4 * j + 0] = g[4 * j + 0]; fb[16 + 4 * j + 1] = g[4 * j + 1];
-                          fb[16 + 4 * j + 2] = g[4 * j + 2]; fb[16 + 4 * j + 3] = g[4 * j + 3]; }
+            const signed char *g = in + ln + halign + S::CB_BEG;
+            for (int k = j; k < S::CB_LEN; k += 16) fb[16 + k] = g[k];
             __builtin_amdgcn_s_waitcnt(0);
         }
         const signed char *bsrc = b_in ? win + b_off : fb + 16;
-        int smp[CB_SAMPLES / 4];
+        int smp[NB];
 #pragma unroll
-        for (int q = 0; q < CB_SAMPLES / 4; q++) smp[q] = bsrc[k0 + 4 * q];
+        for (int q = 0; q < NB; q++) smp[q] = bsrc[k0 + CCS * q];
         const int r = S::VPER == 1 ? 0 : ypos % S::VPER;
         int acc = ccr[0];
 #pragma unroll
         for (int k = 1; k < S::VPER; k++) if (r == k) acc = ccr[k];
 #pragma unroll
-        for (int q = 0; q < CB_SAMPLES / 4; q++) {
+        for (int q = 0; q < NB; q++) {
             const int t127 = (int) (((unsigned) acc << 7) - (unsigned) acc);   /* acc * 127 with wrap, no slow multiply */
             acc = ((t127 + ((t127 >> 31) & 127)) >> 7) + smp[q];          /* C's truncating /128 */
         }
@@ -230,32 +254,58 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
             for (int k = 0; k < S::VPER; k++) if (r == k) ccr[k] = acc;
         }
 
-        /* D7 carrier table, crt_core.c:469-479: quad lanes 0..3 hold ccr[0..3] */
-        const int q0 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(0), 0xf, 0xf, false);
-        const int q1 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(1), 0xf, 0xf, false);
-        const int q2 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(2), 0xf, 0xf, false);
-        const int q3 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(3), 0xf, 0xf, false);
-        const int pa = hsync & 3;
-        const int c0 = pa == 0 ? q0 : pa == 1 ? q1 : pa == 2 ? q2 : q3;
-        const int c1 = pa == 0 ? q1 : pa == 1 ? q2 : pa == 2 ? q3 : q0;
-        const int c2 = pa == 0 ? q2 : pa == 1 ? q3 : pa == 2 ? q0 : q1;
-        const int c3 = pa == 0 ? q3 : pa == 1 ? q0 : pa == 2 ? q1 : q2;
-        const int dci = c1 - c3, dcq = c2 - c0;
+        /* D7 carrier table */
+        int dci, dcq;
+        if constexpr (CCS == 4) {
+            /* crt_core.c:469-479: quad lanes 0..3 hold ccr[0..3] */
+            const int q0 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(0), 0xf, 0xf, false);
+            const int q1 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(1), 0xf, 0xf, false);
+            const int q2 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(2), 0xf, 0xf, false);
+            const int q3 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(3), 0xf, 0xf, false);
+            const int pa = hsync & 3;
+            const int c0 = pa == 0 ? q0 : pa == 1 ? q1 : pa == 2 ? q2 : q3;
+            const int c1 = pa == 0 ? q1 : pa == 1 ? q2 : pa == 2 ? q3 : q0;
+            const int c2 = pa == 0 ? q2 : pa == 1 ? q3 : pa == 2 ? q0 : q1;
+            const int c3 = pa == 0 ? q3 : pa == 1 ? q0 : pa == 2 ? q1 : q2;
+            dci = c1 - c3;
+            dcq = c2 - c0;
+        } else {
+            /* crt_core.c:480-494: lanes 0..4 of the row hold ccr[0..4]; exchanged through LDS */
+            if (j < CCS) s_cc[row][j] = acc;
+            wave_lds_fence();
+            const int pa = posmod(hsync, CCS);
+            const int peak_a = pa + CCS / 4, peak_b = pa;
+            const int dci_a = s_cc[row][peak_a % CCS];
+            const int dci_b = (s_cc[row][(peak_a + CCS / 2) % CCS] + s_cc[row][(peak_a + CCS / 2 + 1) % CCS]) / 2;
+            const int dcq_a = s_cc[row][(peak_b + CCS / 2) % CCS];
+            const int dcq_b = s_cc[row][peak_b % CCS];
+            dci = dci_a - dci_b;
+            dcq = dcq_a - dcq_b;
+            wave_lds_fence();
+        }
         if (j == 0 && live) {
             crthip_line lp;
+            lp.dx = P.dx; lp.scanl = 0;                                    /* :528-529; k_bloom rewrites them per line */
             if (skip) {
                 lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = hsync;
             } else {
                 lp.pos = pos;
-                lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
-                lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
+                if constexpr (CCS == 4) {
+                    lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
+                    lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
+                } else {
+                    lp.wave0 = dci;                                        /* the decoder builds waveI / waveQ (:497-505) */
+                    lp.wave1 = dcq;
+                }
                 lp.beg = beg;
                 int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
                 nrows = nrows < 1 ? 1 : nrows;
                 /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
                 if (nrows > CRTHIP_LINE_NROWS_MASK) nrows = CRTHIP_LINE_NROWS_MASK;
                 nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
-                if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
+                if (CCS != 4)
+                    nrows |= CRTHIP_LINE_WIDE;                             /* no amplitude envelope for the 5-sample carriers */
+                else if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
                     nrows |= CRTHIP_LINE_EXACT;
                 else if (lp.wave0 > T0_WAVE_MAX || lp.wave0 < -T0_WAVE_MAX || lp.wave1 > T0_WAVE_MAX || lp.wave1 < -T0_WAVE_MAX)
                     nrows |= CRTHIP_LINE_NOT64;
@@ -264,32 +314,77 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
                 lp.nrows = nrows;
                 lp.hsync = hsync;
             }
-            int *d = s_lines[row] + (line - S::TOP) * 6;
+            int *d = s_lines[row] + (line - S::TOP) * LW;
             d[0] = lp.pos; d[1] = lp.wave0; d[2] = lp.wave1; d[3] = lp.beg; d[4] = lp.nrows; d[5] = lp.hsync;
+            d[6] = lp.dx; d[7] = lp.scanl;
         }
         /* park the window of line + 1 (fetched one iteration ago), keep line + 2's in flight */
         if (line + 1 < S::BOT) {
-            int *d = s_win[row][(line + 1) % 3] + j * 4;
-            d[0] = wp.x; d[1] = wp.y; d[2] = wp.z; d[3] = wp.w;
+#pragma unroll
+            for (int q = 0; q < WP; q++) {
+                int *d = s_win[row][(line + 1) % 3] + q * 64 + j * 4;
+                d[0] = wp[q].x; d[1] = wp[q].y; d[2] = wp[q].z; d[3] = wp[q].w;
+            }
         }
         base_cur = base_p;
         base_p = base_n;
-        wp = wn;
+#pragma unroll
+        for (int q = 0; q < WP; q++) wp[q] = wn[q];
         __syncthreads();
     }
-    /* line tables: LINES * 24 bytes per row, copied out 16 bytes per lane and pass */
+    /* line tables: LINES * 32 bytes per row, copied out 16 bytes per lane and pass */
     if (live) {
         int *dst = (int *) out_lines;
-        for (int i = j * 4; i < S::LINES * 6; i += 64) {
+        for (int i = j * 4; i < S::LINES * LW; i += 64) {
             v4i v; v.x = s_lines[row][i]; v.y = s_lines[row][i + 1]; v.z = s_lines[row][i + 2]; v.w = s_lines[row][i + 3];
             store16u(dst + i, v);
         }
     }
-    if (j < 4 && live) {
+    if (j < CCS && live) {
 #pragma unroll
         for (int r = 0; r < S::VPER; r++) st->ccf[r][j] = ccr[r];
     }
     if (j == 0 && live) st->hsync = hsync;
+}
+
+/* CRT_DO_BLOOM (crt_core.c:399-402, 512-526): the beam energy of every decoded line (sum of its AV_LEN samples)
+ * drives a leaky integrator prev_e that runs over the lines of a field in order; each line gets its own width,
+ * i.e. its own resampler step dx and start scanL.  One workgroup per field: 256 lanes sum the lines in parallel
+ * (v_dot4 against 0x01010101), lane 0 then walks the 240-step chain and patches dx / scanl into the line table. */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_bloom(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+        crthip_line *__restrict__ lines)
+{
+    __shared__ int s_sum[S::LINES];
+    __shared__ int s_nrows[S::LINES];
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (f >= n_fields) return;
+    crthip_line *lt = lines + (size_t) f * S::LINES;
+    if (t < S::LINES) {
+        const crthip_line lp = lt[t];
+        const signed char *sig = inp + (size_t) f * fstride + lp.pos;
+        int sum = 0;
+        if ((lp.nrows & CRTHIP_LINE_NROWS_MASK) != 0) {
+            int i = 0;
+            for (; i + 4 <= S::AV_LEN; i += 4) sum = __builtin_amdgcn_sdot4(load4u(sig + i), 0x01010101, sum, false);
+            for (; i < S::AV_LEN; i++) sum += sig[i];
+        }
+        s_sum[t] = sum;
+        s_nrows[t] = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int max_e = P.bloom_max_e;                                  /* :400 */
+        int prev_e = 16384 / 8;                                           /* :401 */
+        for (int l = 0; l < S::LINES; l++) {
+            if (s_nrows[l] == 0) continue;                                /* :431: skipped lines do not reach :512 */
+            prev_e = (prev_e * 123 / 128) + ((((max_e >> 1) - s_sum[l]) << 10) / max_e);
+            const int line_w = (S::AV_LEN * 112 / 128) + (prev_e >> 9);
+            lt[l].dx = (line_w << 12) / P.outw;
+            lt[l].scanl = ((S::AV_LEN / 2) - (line_w >> 1) + 8) << 12;
+        }
+    }
 }
 
 
@@ -301,6 +396,8 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         ProfScope ps(c, CRTHIP_K_SYNC);
         hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
         hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+        if (p->bloom)
+            hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;
     });
 }

@@ -72,7 +72,15 @@ DROPIN = {"ntsc": ("libntsccrt_hip_ntsc.so", ["-DCRT_SYSTEM=0"]),
           "nes": ("libntsccrt_hip_nes.so", ["-DCRT_SYSTEM=1"]),
           "nesp0": ("libntsccrt_hip_nesp0.so", ["-DCRT_SYSTEM=1", "-DCRT_CHROMA_PATTERN=0"]),
           "ntscp0": ("libntsccrt_hip_ntscp0.so", ["-DCRT_SYSTEM=0", "-DCRT_CHROMA_PATTERN=0"]),
-          "ntscfir7": ("libntsccrt_hip_ntsc_fir7.so", ["-DCRT_SYSTEM=0"])}
+          "ntscfir7": ("libntsccrt_hip_ntsc_fir7.so", ["-DCRT_SYSTEM=0"]),
+          "snes": ("libntsccrt_hip_snes.so", ["-DCRT_SYSTEM=3"]),
+          "pv1k": ("libntsccrt_hip_pv1k.so", ["-DCRT_SYSTEM=2"]),
+          "temp": ("libntsccrt_hip_temp.so", ["-DCRT_SYSTEM=4"]),
+          "nesrgb": ("libntsccrt_hip_nesrgb.so", ["-DCRT_SYSTEM=6"]),
+          "ntscbloom": ("libntsccrt_hip_ntsc_bloom.so", ["-DCRT_SYSTEM=0", "-DCRT_DO_BLOOM=1"]),
+          "vhsbloom": ("libntsccrt_hip_vhs_bloom.so", ["-DCRT_SYSTEM=5", "-DCRT_DO_BLOOM=1"]),
+          "snesbloom": ("libntsccrt_hip_snes_bloom.so", ["-DCRT_SYSTEM=3", "-DCRT_DO_BLOOM=1"]),
+          "pv1kbloom": ("libntsccrt_hip_pv1k_bloom.so", ["-DCRT_SYSTEM=2", "-DCRT_DO_BLOOM=1"])}
 
 
 def build_dropin_probe(name):

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(L, n), n
-    assert L.crthip_abi_version() == 1
+    assert L.crthip_abi_version() == 2
 
 
 def test_struct_sizes_match_header(lib):
@@ -48,7 +48,50 @@ def test_struct_sizes_match_header(lib):
     assert c == 4 * lib.LINE_INTS
 
 
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0", "ntscp0"])
+ALL_SYSTEMS = ["ntsc", "vhs", "nes", "nesp0", "ntscp0", "snes", "pv1k", "temp", "nesrgb"]
+
+
+@pytest.mark.parametrize("hue", [0, 25, -42, -57, -79, -359, 700])
+@pytest.mark.parametrize("name", ALL_SYSTEMS + ["ntscbloom", "pv1kbloom"])
+def test_carrier_tables_and_geometry_match_the_oracle(lib, name, hue):
+    """crthip_params_finalize on the host: the burst table (row = line class + dot_crawl_offset, or field == frame)
+    must reproduce every burst sample the oracle's crt_modulate writes -- including negative hues, where C's
+    truncating % and / matter -- and the active rectangle must be where the oracle puts the picture."""
+    import numpy as np
+    orc = R.Oracle(name)
+    sysd = orc.sys
+    w, h = 300, 200
+    nes = orc.system == R.SYS_NES
+    for dco, field, frame, raw in [(0, 0, 0, 0), (1, 1, 0, 1), (2, 1, 1, 0), (5, 0, 1, 1)]:
+        c = orc.new_crt(640, 480, R.FMT_BGRA)
+        if nes:
+            img = np.full((h + 1, w), 0x30, dtype=np.uint16)
+            c.settings(img, w=w, h=h, dot_crawl_offset=dco % 3, hue=hue)
+        else:
+            img = np.full((h + 1, w, 4), 255, dtype=np.uint8)
+            kw = dict(format=R.FMT_BGRA, w=w, h=h, hue=hue)
+            if orc.system != R.SYS_NESRGB:
+                kw.update(as_color=1, field=field, frame=frame, raw=raw)
+            if orc.system in R.DOT_CRAWL_SYSTEMS:
+                kw.update(dot_crawl_offset=dco if orc.system in (R.SYS_PV1K, R.SYS_TEMP) else dco % 3)
+            c.settings(img, **kw)
+        c.modulate()
+        p = lib.make_params(name, w=w, h=h, outw=640, outh=480, hue=hue, raw=0 if nes or orc.system == R.SYS_NESRGB else raw)
+        an = c.analog.reshape(sysd.vres, sysd.hres)
+        line_rows = orc.system in R.DOT_CRAWL_SYSTEMS
+        eff = c.sget("dot_crawl_offset") if line_rows else 0
+        for n in range(p.yo, p.yo + 6):
+            row = (n % sysd.cc_vper) + eff if line_rows else int(field == frame)
+            for t in range(sysd.cb_beg, sysd.cb_beg + sysd.cb_len):
+                want = (sysd.blank_level + p.burst[row][t % sysd.cc_samples] * sysd.burst_level) >> 5
+                assert an[n, t] == ((want + 128) % 256) - 128, (name, hue, dco, n, t)
+        # geometry: the first active sample of the picture is white-ish, the sample before the rectangle is blank
+        ys, xs = np.nonzero(an[:, sysd.av_beg - 8:] > 40)
+        assert ys.min() == p.yo and ys.max() == p.yo + p.desth - 1, (name, raw)
+        assert xs.min() + sysd.av_beg - 8 == p.xo, (name, raw, xs.min() + sysd.av_beg - 8, p.xo)
+
+
+@pytest.mark.parametrize("name", ALL_SYSTEMS)
 def test_host_setup_matches_oracle(lib, name):
     orc = R.Oracle(name)
     L = lib.load_library()
@@ -56,14 +99,13 @@ def test_host_setup_matches_oracle(lib, name):
     assert L.crthip_input_size(sysid, pattern) == orc.input_size
     assert L.crthip_hres(sysid, pattern) == orc.hres
     assert L.crthip_lines(sysid) == orc.bot - orc.top
-    assert L.crthip_field_stride(sysid, pattern) >= orc.input_size + 16 + 753 + 16
+    assert L.crthip_field_stride(sysid, pattern) >= orc.input_size + 16 + orc.av_len + 16
     p = lib.make_params(name, w=640, h=480, outw=832, outh=624, hue=25, mon_hue=340, brightness=4,
                         black_point=2, white_point=97)
     assert list(p.eq_lf) == list(orc.sys.eq_lf)
     assert list(p.eq_hf) == list(orc.sys.eq_hf)
     assert [list(r) for r in p.eq_g] == [list(r) for r in orc.sys.eq_g]
-    if name in ("ntsc", "vhs", "ntscp0"):
-        assert list(p.iir_c) == list(orc.sys.iir_c)
+    assert list(p.iir_c) == list(orc.sys.iir_c)
     if name in ("ntsc", "vhs"):
         assert (p.destw, p.desth, p.xo, p.yo) == (753, 236, 156, 23)
     s, c = orc.sincos14(((340 % 360) + 33) * 8192 // 180)

@@ -19,8 +19,12 @@ def _built():
     g.build()
 
 
+ALL_DROPINS = ["ntsc", "vhs", "nes", "nesp0", "ntscp0", "snes", "pv1k", "temp", "nesrgb",
+               "ntscbloom", "vhsbloom", "snesbloom", "pv1kbloom"]
+
+
 @needs_ref
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0", "ntscp0"])
+@pytest.mark.parametrize("name", ALL_DROPINS)
 def test_struct_layout_identical_to_reference(name):
     ref = R.RefLib(name)
     ours = R.RefLib(name, dropin=True)
@@ -30,11 +34,11 @@ def test_struct_layout_identical_to_reference(name):
     assert ours.soff == ref.soff
     for f in ("hres", "vres", "input_size", "top", "bot", "vper", "av_beg", "av_len"):
         assert getattr(ours, f) == getattr(ref, f), f
-    for fn in ("refp_sync_beg", "refp_bw_beg", "refp_cb_beg", "refp_system"):
+    for fn in ("refp_sync_beg", "refp_bw_beg", "refp_cb_beg", "refp_system", "refp_cc_samples", "refp_do_bloom"):
         assert getattr(ours.lib, fn)() == getattr(ref.lib, fn)(), fn
 
 
-@pytest.mark.parametrize("name", ["ntsc", "vhs", "nes", "nesp0", "ntscp0"])
+@pytest.mark.parametrize("name", ALL_DROPINS)
 def test_dropin_exports_the_reference_api(name):
     lib = os.path.join(R.PKG_LIB, R.DROPIN[name][0])
     syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
@@ -55,6 +59,8 @@ def test_unchanged_reference_drivers_link_against_the_hip_library():
         for out, defs, drv, lib in [
             ("ntsc_cli_hip", ["-DCRT_SYSTEM=0"], "crt_main.c", "ntsccrt_hip_ntsc"),
             ("ntscvhs_video_hip", ["-DCRT_SYSTEM=5"], "video_convert.c", "ntsccrt_hip_vhs"),
+            ("ntsc_cli_snes_hip", ["-DCRT_SYSTEM=3"], "crt_main.c", "ntsccrt_hip_snes"),
+            ("ntsc_cli_pv1k_hip", ["-DCRT_SYSTEM=2"], "crt_main.c", "ntsccrt_hip_pv1k"),
         ]:
             exe = os.path.join(R.PKG_LIB, out)
             cmd = ["gcc", "-O2", "-w", "-std=c89", "-H", "-I" + inc, "-I" + REF] + defs + ["-o", exe,

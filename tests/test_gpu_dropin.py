@@ -141,6 +141,82 @@ def test_vhs_dropin_shares_the_libc_rand_stream(aberration):
         np.testing.assert_array_equal(a.out, b.out)
 
 
+@pytest.mark.parametrize("name", ["snes", "temp", "pv1k", "ntscbloom", "snesbloom", "pv1kbloom"])
+def test_f4_and_bloom_dropins(name):
+    """libntsccrt_hip_{snes,temp,pv1k}.so and the -DCRT_DO_BLOOM=1 libraries against the
+    reference built for the same CRT_SYSTEM (/ with crt_core.h:70 patched), every visible struct member after
+    every call, interlaced sequence with moving dot crawl offset"""
+    hip = R.RefLib(name, dropin=True)
+    chk = _checker(name)
+    img = R.synth_image(640, 480, 4, 31, "bars")
+    a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+    for c in (a, b):
+        c.set("scanlines", 1)
+        c.settings(img, format=R.FMT_BGRA, w=640, h=480, as_color=1, hue=15)
+    for step in range(4):
+        for c in (a, b):
+            if hip.system in R.DOT_CRAWL_SYSTEMS:
+                c.sset("dot_crawl_offset", step % 3)
+            c.modulate()
+            c.demodulate([0, 24, 12, 40][step])
+            c.sset("field", c.sget("field") ^ 1)
+            if step % 2 == 0:
+                c.sset("frame", c.sget("frame") ^ 1)
+        R.compare_state(a, b, "%s step %d" % (name, step))
+
+
+def test_nesrgb_dropin():
+    hip = R.RefLib("nesrgb", dropin=True)
+    chk = _checker("nesrgb")
+    a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+    for step in range(4):
+        img = R.synth_image(256, 240, 4, 17 + step, "random" if step % 2 else "bars")
+        for c in (a, b):
+            c.settings(img, format=R.FMT_BGRA, w=256, h=240, dot_crawl_offset=step % 3, hue=(step * 40) % 360)
+            c.modulate()
+            c.demodulate([0, 12, 24, 5][step])
+        R.compare_state(a, b, "nesrgb step %d" % step)
+
+
+def test_offsets_that_leave_analog_are_refused_not_fatal():
+    """ADVICE r1 / VERDICT r1: extra/video_convert.c:153 passes uninitialised xoffset / yoffset; a garbage value must
+    not kill the process.  In-bounds wrap-around is reproduced (test_gpu_parity), out-of-bounds is a warned no-op."""
+    hip = R.RefLib("ntsc", dropin=True)
+    img = R.synth_image(640, 480, 4, 3)
+    a = hip.new_crt(640, 480, R.FMT_BGRA)
+    a.settings(img, format=R.FMT_BGRA, w=640, h=480, as_color=1, xoffset=123456789, yoffset=-77)
+    before = a.analog.copy()
+    a.modulate()                                   # must return
+    np.testing.assert_array_equal(a.analog, before)
+    a.sset("xoffset", 4)                           # 160 + 753 > 910: wraps into the next line, like the reference
+    a.sset("yoffset", 0)
+    chk = _checker("ntsc")
+    b = chk.new_crt(640, 480, R.FMT_BGRA)
+    b.settings(img, format=R.FMT_BGRA, w=640, h=480, as_color=1, xoffset=4, yoffset=0)
+    for c in (a, b):
+        c.modulate()
+        c.demodulate(12)
+    R.compare_state(a, b, "xoffset 4")
+
+
+@pytest.mark.parametrize("sysname,flags,noise", [("snes", "-o", 24), ("snes", "-op", 0), ("pv1k", "-o", 12), ("pv1k", "-om", 0)])
+def test_unchanged_crt_main_driver_f4_systems(tmp_path, sysname, flags, noise):
+    """the reference's crt_main.c compiled with -DCRT_SYSTEM=3 / 2 against the HIP drop-in of that system"""
+    ref_cli = os.path.join(R.REF_DIR, "ntsc_cli_" + sysname)
+    hip_cli = os.path.join(R.PKG_LIB, "ntsc_cli_%s_hip" % sysname)
+    if not (os.path.exists(ref_cli) and os.path.exists(hip_cli)):
+        pytest.skip("driver binaries not prebuilt (they are built where /root/reference exists)")
+    src = str(tmp_path / "in.ppm")
+    _write_ppm(src, 640, 480, 2)
+    outs = []
+    for exe, tag in ((ref_cli, "ref"), (hip_cli, "hip")):
+        out = str(tmp_path / ("out_%s.ppm" % tag))
+        r = subprocess.run([exe, flags, "640", "480", str(noise), "0", src, out], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1], "%s driver output differs between the reference and the HIP library" % sysname
+
+
 def _write_ppm(path, w, h, seed):
     img = R.synth_image(w, h, 3, seed, "bars")
     with open(path, "wb") as f:

@@ -82,7 +82,9 @@ CASES = [
 ]
 
 
-def _run_case(crtlib, case, fused, steps=4, n=3, exact=False):
+def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1):
+    """shape: 1 = lane-per-scanline kernels (the throughput shape; forced, because small batches would otherwise
+    pick the other one), 2 = scanline-parallel kernels, 0 = the library's own choice"""
     name, outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = case
     bpp = R.bpp4fmt(ifmt)
     imgs = np.stack([R.synth_image(w, h, bpp, 777 + 13 * k, "random" if k % 2 == 0 else "bars") for k in range(n)])
@@ -91,14 +93,20 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False):
     g = crtlib.CRT(n, outw, outh, ofmt, name[:4] if name.startswith("ntscfir") else name, device=0)
     g.eq_fir = R.EQ_KERNEL.get(name, 0)              # "ntscfir7": the FIR decoder of a USE_CONVOLUTION build
     g.set_exact(exact)
+    g.set_shape(shape)
     for k, v in knobs.items():
         setattr(g, k, v)
     fields = [k & 1 for k in range(n)]
     frames = [(k >> 1) & 1 for k in range(n)]
-    s = crtlib.Settings(dimgs, format=ifmt, field=list(fields), frame=list(frames), **skw)
+    dot_crawl = orc.system in R.DOT_CRAWL_SYSTEMS      # SNES, template, PV-1000: NTSC_SETTINGS.dot_crawl_offset
+    dcos = [(2 * k + 1) % 6 if name.startswith(("pv1k", "temp")) else (k + 1) % 3 for k in range(n)]
+    s = crtlib.Settings(dimgs, format=ifmt, field=list(fields), frame=list(frames),
+                        dot_crawl_offset=list(dcos) if dot_crawl else 0, **skw)
     for k, c in enumerate(ocrts):
         pad = np.concatenate([imgs[k], imgs[k][-1:]], axis=0)
         c.settings(pad, format=ifmt, w=w, h=h, field=fields[k], frame=frames[k], **skw)
+        if dot_crawl:
+            c.sset("dot_crawl_offset", dcos[k])
     for step in range(steps):
         if fused:
             g.fieldpass(s, noise)
@@ -119,18 +127,18 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False):
             c.modulate()
             if not fused:
                 np.testing.assert_array_equal(analog[k, :orc.input_size], c.analog, err_msg=what + " analog")
-                np.testing.assert_array_equal(ccf_mod[k, :orc.vper], c.ccf, err_msg=what + " ccf after modulate")
+                np.testing.assert_array_equal(ccf_mod[k, :orc.vper, :orc.ccs], c.ccf, err_msg=what + " ccf after modulate")
             c.demodulate(noise, trace=True)
             if not fused:
                 np.testing.assert_array_equal(ginp[k, :orc.input_size], c.inp, err_msg=what + " inp")
                 tr = c.trace
                 valid = tr[:, 0] == 1
                 np.testing.assert_array_equal(glines[k][:, 4] > 0, valid, err_msg=what + " valid lines")
-                np.testing.assert_array_equal(glines[k][valid][:, [0, 1, 2, 3, 5]], tr[valid][:, [1, 2, 3, 4, 6]],
-                                              err_msg=what + " line table (pos, wave0, wave1, beg, hsync)")
+                np.testing.assert_array_equal(glines[k][valid][:, [0, 1, 2, 3, 5, 6, 7]], tr[valid][:, [1, 2, 3, 4, 6, 7, 8]],
+                                              err_msg=what + " line table (pos, wave0, wave1, beg, hsync, dx, scanl)")
             for f in ("hsync", "vsync", "rn"):
                 assert gst[f][k] == c.get(f), "%s %s: gpu %d oracle %d" % (what, f, gst[f][k], c.get(f))
-            np.testing.assert_array_equal(gccf[k, :orc.vper], c.ccf, err_msg=what + " ccf")
+            np.testing.assert_array_equal(gccf[k, :orc.vper, :orc.ccs], c.ccf, err_msg=what + " ccf")
             np.testing.assert_array_equal(gout[k].reshape(-1), c.out, err_msg=what + " out")
         # next field: interlaced sequence (video_convert.c:259-267)
         fields = [f ^ 1 for f in fields]
@@ -177,6 +185,172 @@ def test_slower_decoder_tiers_parity(crtlib, case, mode):
     exact 32-bit multiplies everywhere), tier 2 (mode 2: 24-bit mads) and tier 1 (mode 3: 64-bit mads, all
     cascades) onto them"""
     _run_case(crtlib, CASES[case], fused=True, exact=mode, steps=2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the scanline-parallel kernel shape (crt_decode2.hip): a DPP row of lanes per scanline
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_scanline_parallel_shape_parity(crtlib, case, fused):
+    """every case of the table, decoded by the scanline-parallel kernels instead of the lane-per-scanline ones"""
+    _run_case(crtlib, CASES[case], fused=fused, shape=2, steps=2)
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("case", [1, 2, 5])
+def test_scanline_parallel_wide_variant_on_ordinary_inputs(crtlib, case, mode):
+    """ordinary inputs take the 16-lane (NARROW) variant; set_exact 1 / 3 force the 32-lane one with all 6 cascades"""
+    _run_case(crtlib, CASES[case], fused=True, exact=mode, shape=2, steps=2)
+
+
+def test_library_picks_the_shape_by_batch_size(crtlib):
+    """crthip_set_shape(0): small batches -> scanline-parallel, large ones -> lane-per-scanline; same pictures"""
+    _run_case(crtlib, CASES[1], fused=True, shape=0, steps=2, n=2)
+    _run_case(crtlib, ("ntsc", 96, 240, R.FMT_BGRA, 64, 48, R.FMT_BGRA, 24, dict(as_color=1), dict(scanlines=1)),
+              fused=True, shape=0, steps=1, n=300)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f4): SNES, template, PV-1000 (5 samples per chroma cycle), NES-RGB;  8(f3): CRT_DO_BLOOM builds
+# ---------------------------------------------------------------------------------------------------------------
+F4_CASES = [
+    # outw, outh, ofmt, w, h, ifmt, noise, settings, knobs
+    (640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 0, dict(as_color=1), {}),
+    (640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1, hue=25), dict(scanlines=1)),
+    (832, 624, R.FMT_ARGB, 640, 480, R.FMT_ABGR, 40, dict(as_color=1, hue=350), dict(hue=17, saturation=14)),
+    (640, 480, R.FMT_RGB, 320, 200, R.FMT_RGB, 12, dict(as_color=1, hue=-57), dict(blend=1)),
+    (500, 300, R.FMT_BGR, 200, 100, R.FMT_ARGB, 60, dict(as_color=1, raw=1, xoffset=8, yoffset=2), dict(black_point=3, white_point=90)),
+    (753, 240, R.FMT_ABGR, 753, 236, R.FMT_RGBA, 5, dict(as_color=0), dict(brightness=9, contrast=200)),
+    (640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1), dict(saturation=900, contrast=300)),
+]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", range(len(F4_CASES)))
+@pytest.mark.parametrize("name", ["snes", "temp", "pv1k"])
+def test_f4_systems_parity(crtlib, name, case, fused):
+    """crt_snes.c / crt_template.c / crt_pv1k.c + the shared decoder (PV-1000: the 5-sample branch,
+    crt_core.c:480-510,544-549).  SNES and the template also run the lane-per-scanline decoder (even cases)."""
+    shape = 2 if name == "pv1k" or case % 2 else 1
+    _run_case(crtlib, (name,) + F4_CASES[case], fused=fused, shape=shape, steps=3)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("name", ["ntscbloom", "snesbloom", "pv1kbloom"])
+def test_bloom_build_parity(crtlib, name, case, fused):
+    """CRT_DO_BLOOM (crt_core.h:70 set to 1): encoder geometry 55500 / 63500 (crt_ntsc.c:148-161), per-line beam
+    width -> per-line resampler step and start (crt_core.c:399-402, 512-526).  The oracle's bloom mode is pinned
+    against the reference compiled with the patched header (tests/test_oracle_vs_ref.py)."""
+    _run_case(crtlib, (name,) + F4_CASES[case], fused=fused, shape=0, steps=3)
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+@pytest.mark.parametrize("fused", [False, True])
+def test_nesrgb_parity(crtlib, fused, shape):
+    """crt_nesrgb.c: an RGB image encoded with the NES's line timing (progressive, no band limit, 3 line classes)"""
+    n, w, h, outw, outh = 3, 256, 240, 640, 480
+    orc = R.Oracle("nesrgb")
+    g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, "nesrgb", device=0)
+    g.set_shape(shape)
+    g.scanlines = 1
+    ocrts = [orc.new_crt(outw, outh, R.FMT_BGRA) for _ in range(n)]
+    for c in ocrts:
+        c.set("scanlines", 1)
+    s = None
+    for step in range(4):
+        ifmt = [R.FMT_BGRA, R.FMT_RGB, R.FMT_ARGB, R.FMT_ABGR][step]
+        imgs = np.stack([R.synth_image(w, h, R.bpp4fmt(ifmt), 91 * step + k, "random" if k % 2 else "bars") for k in range(n)])
+        dco = [(step + k) % 3 for k in range(n)]
+        hue = [0, 50, -79, 200][step]
+        init = s.initialized if s is not None else 0
+        s = crtlib.Settings(_padded(imgs), format=ifmt, hue=hue, dot_crawl_offset=dco)
+        s.initialized = init
+        noise = [0, 12, 24, 50][step]
+        if fused:
+            g.fieldpass(s, noise)
+        else:
+            g.modulate(s)
+            analog = g.analog.cpu().numpy()
+            g.demodulate(noise)
+        g.synchronize()
+        gout = g.out.cpu().numpy()
+        for k, c in enumerate(ocrts):
+            what = "nesrgb fused=%s shape %d step %d field %d" % (fused, shape, step, k)
+            c.settings(np.concatenate([imgs[k], imgs[k][-1:]]), format=ifmt, w=w, h=h, dot_crawl_offset=dco[k], hue=hue)
+            if fused:
+                c.analog[:] = 0
+                c.sset("field_initialized", 0)
+            c.modulate()
+            if not fused:
+                np.testing.assert_array_equal(analog[k, :orc.input_size], c.analog, err_msg=what + " analog")
+            c.demodulate(noise)
+            for f in ("hsync", "vsync", "rn"):
+                assert g.get(f)[k] == c.get(f), "%s %s" % (what, f)
+            np.testing.assert_array_equal(g.ccf[k, :orc.vper, :orc.ccs], c.ccf, err_msg=what + " ccf")
+            np.testing.assert_array_equal(gout[k].reshape(-1), c.out, err_msg=what + " out")
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["nes", "nesp0"])
+def test_nes_negative_hue_and_dot_crawl(crtlib, name):
+    """the burst angle (hue + x*90 + (y + dot_crawl_offset)*120 + 33) % 360 goes negative for negative
+    hues and C's truncating % / then differ from the row-reduced form by one 14-bit step (hue -42/-57/-79)."""
+    import torch
+    n = 3
+    orc = R.Oracle(name)
+    g = crtlib.CRT(n, 320, 240, crtlib.FMT_BGRA, name, device=0)
+    ocrts = [orc.new_crt(320, 240, R.FMT_BGRA) for _ in range(n)]
+    for step, hue in enumerate([-42, -57, -79, -200, -359]):
+        ppu = np.stack([R.synth_ppu(256, 240, 5 + step + k) for k in range(n)])
+        full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
+        full[:, :240] = torch.from_numpy(ppu.astype(np.int16)).to("cuda:0")
+        dco = [(step + k) % 3 for k in range(n)]
+        s = crtlib.Settings(full[:, :240], hue=hue, dot_crawl_offset=dco)
+        g.modulate(s)
+        analog = g.analog.cpu().numpy()
+        g.demodulate(8)
+        g.synchronize()
+        gout = g.out.cpu().numpy()
+        for k, c in enumerate(ocrts):
+            c.settings(np.concatenate([ppu[k], ppu[k][-1:]]), w=256, h=240, dot_crawl_offset=dco[k], hue=hue)
+            c.modulate()
+            np.testing.assert_array_equal(analog[k, :orc.input_size], c.analog, err_msg="%s hue %d analog %d" % (name, hue, k))
+            c.demodulate(8)
+            np.testing.assert_array_equal(g.ccf[k, :3, :4], c.ccf)
+            np.testing.assert_array_equal(gout[k].reshape(-1), c.out, err_msg="%s hue %d out %d" % (name, hue, k))
+    g.close()
+
+
+def test_rectangle_running_over_the_line_end(crtlib):
+    """xoffset 4 in non-raw NTSC puts the rectangle at 160 + 753 = 913 > 910: the reference's flat index
+    (crt_ntsc.c:322) continues in the next line's front porch; so do the kernels."""
+    for fused in (False, True):
+        _run_case(crtlib, ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1, xoffset=4), {}),
+                  fused=fused, steps=2)
+        _run_case(crtlib, ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 0, dict(as_color=1, xoffset=150, yoffset=1), dict(scanlines=1)),
+                  fused=fused, steps=2, shape=2)
+
+
+def test_tight_images_are_never_read_past_their_end(crtlib):
+    """the reference's `if (sy >= h) sy = h` reads image row h (crt_ntsc.c:263) on odd fields of raw images
+    with h <= desth.  Without CRTHIP_F_IMAGE_SPARE_ROW the kernels read row h - 1 instead: a TIGHT [n,h,w,c] tensor
+    gives the same picture as the padded one whose spare row repeats row h - 1."""
+    import torch
+    n, w, h = 3, 100, 200
+    imgs = np.stack([R.synth_image(w, h, 4, 321 + k) for k in range(n)])
+    outs = []
+    for tight in (False, True):
+        g = crtlib.CRT(n, 320, 240, crtlib.FMT_BGRA, "ntsc", device=0)
+        data = _to_dev(imgs) if tight else _padded(imgs)
+        s = crtlib.Settings(data, format=crtlib.FMT_BGRA, raw=1, field=1, frame=0)
+        assert g._has_spare_row(s) == (not tight)
+        g.fieldpass(s, 0)
+        g.synchronize()
+        outs.append(g.out.cpu().numpy())
+        g.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
 
 
 NES_CASES = [
@@ -236,7 +410,7 @@ def test_nes_parity(crtlib, case, fused):
             c.demodulate(noise)
             for f in ("hsync", "vsync", "rn"):
                 assert g.get(f)[k] == c.get(f), "%s %s" % (what, f)
-            np.testing.assert_array_equal(g.ccf[k, :orc.vper], c.ccf, err_msg=what + " ccf")
+            np.testing.assert_array_equal(g.ccf[k, :orc.vper, :orc.ccs], c.ccf, err_msg=what + " ccf")
             np.testing.assert_array_equal(gout[k].reshape(-1), c.out, err_msg=what + " out")
     g.close()
 
@@ -268,7 +442,7 @@ def test_vhs_encoder_parity(crtlib, aberration):
             libc.srand(seed)
         c.modulate()
         np.testing.assert_array_equal(an[k, :orc.input_size], c.analog, err_msg="vhs analog %d" % k)
-        np.testing.assert_array_equal(g.ccf[k, :1], c.ccf)
+        np.testing.assert_array_equal(g.ccf[k, :1, :4], c.ccf)
         assert g.get("hsync")[k] == c.get("hsync") == 0
     g.close()
 
@@ -322,7 +496,7 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
             if not fused:
                 np.testing.assert_array_equal(g.inp[k, :orc.input_size].cpu().numpy(), inp, err_msg=what + " inp")
             assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), what
-            np.testing.assert_array_equal(g.ccf[k, :1], ccf, err_msg=what + " ccf")
+            np.testing.assert_array_equal(g.ccf[k, :1, :4], ccf, err_msg=what + " ccf")
             np.testing.assert_array_equal(gout[k].reshape(-1), out, err_msg=what + " out")
         fields = [f ^ 1 for f in fields]
         s.field = list(fields)
@@ -537,7 +711,15 @@ def test_random_configurations(crtlib, seed):
     """odd / tiny / large geometries, all format pairs, random knobs: stagewise AND fused, 2 steps each"""
     rng = np.random.default_rng(1000 + seed)
     case = _random_case(rng)
-    _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2)
+    _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2, shape=1)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations_scanline_parallel_shape(crtlib, seed):
+    """the same random configurations forced onto the scanline-parallel kernels"""
+    rng = np.random.default_rng(1000 + seed)
+    case = _random_case(rng)
+    _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2, shape=2)
 
 
 @pytest.mark.parametrize("n,w,h,noise", [(4096, 640, 480, 24), (64, 1920, 1080, 0)])
