@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the NTSC-CRT field-pass hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (crt_modulate + crt_demodulate, fused launch sequence)
-over one device-resident batch of synthetic fields.  Workload = BASELINE.json configs[1]:
-640x480 BGRA in -> 640x480 BGRA out, CRT_SYSTEM_NTSC, interlaced (field parity alternates per
-frame), full colour, noise 24, hue 0, scanlines 1.  "frames/sec" = field-passes/sec (one
-field-pass per input frame, as extra/video_convert.c:259-260 does).
+N = 1 runs in this process.  N > 1: if the process was not started by torch.distributed.run (no WORLD_SIZE in the
+environment) it re-executes itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 ... bench.py <same arguments>`, one rank per GPU; started by torch.distributed.run it is one of the ranks.
 
-Multi-GPU: one process per GPU, frames sharded by rank (weak scaling: fixed batch per GPU);
-the only collective on the data path is the RCCL broadcast of the settings blob from rank 0.
+A "step" is one pass of the hot path (crt_modulate + crt_demodulate, fused launch sequence) over one device-resident
+batch of synthetic fields.  Headline workload = BASELINE.json configs[1]: 640x480 BGRA in -> 640x480 BGRA out,
+CRT_SYSTEM_NTSC, interlaced (field parity alternates per frame), full colour, noise 24, hue 0, scanlines 1.
+"frames/sec" = field-passes/sec (one field-pass per input frame, as extra/video_convert.c:259-260 does).
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel vs the HBM roofline (bytes per SURVEY.md 8(d) / DESIGN.md)
-  cpu_baseline  the reference (oracle/_ref, unmodified sources) or the oracle port, 1 core
+Multi-GPU: one process per GPU, frames sharded by rank; the only collective on the data path is the RCCL broadcast of
+the settings blob from rank 0.  Default: weak scaling (fixed batch per GPU).  `--strong F` splits F frames of
+BASELINE configs[2] (1920x1080, noise 0) over the ranks (F = 512 is the configuration BASELINE states).
+
+Prints ONE JSON line (rank 0).  Objects:
+  roofline         dominant kernel vs the HBM roofline (bytes per SURVEY.md 8(d) / DESIGN.md section 5)
+  cpu_baseline     the reference (oracle/_ref, unmodified sources) or the oracle port on the host cores: 1 core, and
+                   all cores (independent processes)
+  extra_workloads  (N = 1) the same record for 1080p at batch 2048 and at configs[2]'s per-GPU share (64), VHS 832x624
+                   (configs[3]) and NES pattern 0 (configs[4])
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ntsc-crt_amd"))
@@ -30,22 +38,49 @@ sys.path.insert(0, os.path.join(ROOT, "ntsc-crt_amd"))
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
 
 
-def algorithmic_bytes(w, h, in_bpp, outw, outh, out_bpp, scanlines, blend, lines=240, desth=236):
-    """compulsory HBM bytes of one field-pass."""
-    rows_in = min(desth, h)
+def geometry(system, w, h, outw, outh, scanlines, bloom=False):
+    """Rows / samples of one field-pass (crt_ntsc.c:132-133, crt_core.c:428-432, :661-664; even field, v_fac 0)."""
+    nes = system.startswith("nes")
+    lines = 240
+    hres = {"nes": 909, "nesp0": 912, "nesrgb": 909, "snes": 909, "pv1k": 1920, "ntscp0": 912}.get(system, 910)
+    av_len = {"nes": 682, "nesp0": 684, "nesrgb": 682, "snes": 682, "pv1k": 1487, "ntscp0": 754}.get(system, 753)
+    desth = lines if nes else (lines * (63500 if bloom else 64500)) >> 16
+    destw = av_len if not bloom else (av_len * 55500) >> 16
     rows_out = 0
-    for l in range(lines):                       # crt_core.c:428-432, :661-664 (even field, v_fac 0)
+    for l in range(lines):
         beg, end = l * outh // lines, min((l + 1) * outh // lines, outh)
         if beg < outh:
             rows_out += max(end - scanlines - beg, 1)
-    b = rows_in * w * in_bpp + rows_out * outw * out_bpp
-    if blend:
-        b += lines * outw * out_bpp
-    return b
+    return dict(lines=lines, hres=hres, av_len=av_len, desth=desth, destw=destw, rows_in=min(desth, h), rows_out=rows_out,
+                input_size=hres * 262)
 
 
-def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s):
-    """Time the reference (or the oracle port) on ONE host core on a bounded sample."""
+def algorithmic_bytes(system, w, h, in_bpp, outw, outh, out_bpp, scanlines, blend):
+    """compulsory HBM bytes of one field-pass, and the share each kernel moves itself."""
+    g = geometry(system, w, h, outw, outh, scanlines)
+    img = g["rows_in"] * w * in_bpp
+    pic = g["rows_out"] * outw * out_bpp + (g["lines"] * outw * out_bpp if blend else 0)
+    act = g["destw"] * g["desth"]
+    own = {"template": g["input_size"] - act,                       # margins of inp[] written
+           "active": img + act,                                     # image rows read, active samples written
+           "noise": 2 * g["input_size"],
+           "sync": 25000 + g["lines"] * 32,                         # sync / burst windows read, line table written
+           "decode": g["lines"] * g["av_len"] + pic}                # sample windows read, picture written
+    return img + pic, own
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_time_workload(system, w, h, outw, outh, noise, scanlines, budget_s):
+    """Time the reference (or the oracle port) on the calling thread on a bounded sample; returns (fps, reps, kind)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import crtref as R
@@ -56,7 +91,7 @@ def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s):
         lib, kind = R.Oracle(system), "port"
     c = lib.new_crt(outw, outh, R.FMT_BGRA)
     c.set("scanlines", scanlines)
-    nes = system.startswith("nes")
+    nes = system in ("nes", "nesp0")
     if nes:
         ppu = R.synth_ppu(w, h, 12345)
         img = np.concatenate([ppu, ppu[-1:]])                 # the reference reads one row past the image (sic)
@@ -64,103 +99,99 @@ def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s):
     else:
         img = R.synth_image(w, h, 4, 12345)
         c.settings(np.concatenate([img, img[-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1, hue=0, field=0, frame=0)
-    if system == "vhs":
+    if system.startswith("vhs"):
         lib.srand(1)
-    t, _, _ = c.time_fieldpasses(noise, 20, not nes)         # warm-up + calibration
-    reps = max(50, min(4000, int(budget_s / (t / 20))))
+    t, _, _ = c.time_fieldpasses(noise, 10, not nes)          # warm-up + calibration
+    reps = max(20, min(4000, int(budget_s / (t / 10))))
     t, _, _ = c.time_fieldpasses(noise, reps, not nes)
-    return {"value": reps / t, "unit": "frames/sec", "cores": 1, "kind": kind,
-            "sample": "%d field-passes of the same %s %dx%d -> %dx%d noise-%d workload, 1 thread" % (reps, system, w, h, outw, outh, noise),
-            "host_cores_visible": os.cpu_count()}
+    return reps / t, reps, kind
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="fields per GPU per step")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--noise", type=int, default=24)
-    ap.add_argument("--scanlines", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--system", default="ntsc", choices=["ntsc", "ntscp0", "vhs", "nes", "nesp0"],
-                    help="non-default systems are extra measurements (BASELINE configs[3], [4]), not the headline")
-    ap.add_argument("--fir", type=int, default=0, choices=[0, 4, 5, 6, 7],
-                    help="decoder of a USE_CONVOLUTION build of the reference (FIR kernel of N taps) instead of the 3-band equaliser")
-    ap.add_argument("--outw", type=int, default=0)
-    ap.add_argument("--outh", type=int, default=0)
-    ap.add_argument("--sequence", action="store_true", help="treat the batch as ONE video (crthip_sequence) instead of independent frames")
-    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames (tiled to the batch)")
-    ap.add_argument("--pixel-tile", type=int, default=0, help="decoder output tile: 0 auto, 16, 32")
-    ap.add_argument("--overlap", type=int, default=1, help="chunks alternating between two streams")
-    args = ap.parse_args()
+def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s, all_cores=True):
+    """cpu_baseline object: 1 thread on 1 core (the reference is single-threaded), plus an all-cores figure from
+    independent processes, one per core."""
+    fps, reps, kind = cpu_time_workload(system, w, h, outw, outh, noise, scanlines, budget_s)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    out = {"value": fps, "unit": "frames/sec", "cores": 1, "kind": kind,
+           "sample": "%d field-passes of the same %s %dx%d -> %dx%d noise-%d workload, 1 thread" % (reps, system, w, h, outw, outh, noise),
+           "cpu_model": cpu_model(), "host_cores_visible": ncores}
+    if all_cores and ncores > 1:
+        sec = min(4.0, budget_s)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", system, str(w), str(h), str(outw), str(outh),
+               str(noise), str(scanlines), str(sec)]
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(ncores)]
+        rates = []
+        for p in procs:
+            o, _ = p.communicate()
+            try:
+                rates.append(float(o.decode().strip().splitlines()[-1]))
+            except (ValueError, IndexError):
+                pass
+        out["all_cores"] = {"value": sum(rates), "unit": "frames/sec", "cores": len(rates),
+                            "sample": "%d independent processes x %.0f s of the same workload (wall %.1f s)"
+                                      % (len(rates), sec, time.perf_counter() - t0)}
+    return out
 
-    import torch
-    import crtlib
-    import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+WORKLOAD_NOTES = {
+    "ntsc": "BASELINE configs[1]" , "1080p": "BASELINE configs[2] geometry", "vhs": "BASELINE configs[3]",
+    "nesp0": "BASELINE configs[4]",
+}
 
-    w, h, n = args.width, args.height, args.batch
-    nes = args.system.startswith("nes")
-    if nes:
-        w, h = 256, 240
-    outw, outh = args.outw or (640 if nes else w), args.outh or (480 if nes else h)
-    crt = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, args.system, device=local)
-    crt.scanlines = args.scanlines
-    crt.eq_fir = args.fir
+
+def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps, warmup, cpu_seconds, with_cpu, traffic_file=None):
+    """One workload on this rank's GPU; returns the result record (rank 0) or None."""
+    system, w, h, outw, outh = wl["system"], wl["w"], wl["h"], wl["outw"], wl["outh"]
+    n, noise, scanlines, fir = wl["batch"], wl["noise"], wl["scanlines"], wl.get("fir", 0)
+    nes = system in ("nes", "nesp0")
+    crt = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, system, device=local)
+    crt.scanlines = scanlines
+    crt.eq_fir = fir
     crt.reserve(n)
-    crt.set_overlap(args.overlap)
-    crt.set_pixel_tile(args.pixel_tile)
+    crt.set_overlap(wl.get("overlap", 0))
+    crt.set_pixel_tile(wl.get("pixel_tile", 0))
+    crt.set_shape(wl.get("shape", 0))
 
-    # synthetic input, generated on the device: uniform random BGRA bytes per frame
-    # (at most `--unique` distinct random frames, tiled to the batch: the kernels' work is data-independent,
-    #  and generating tens of GB of random bytes would dominate the run)
+    # synthetic input, generated on the device: uniform random bytes per frame (SURVEY 8(d) config 2); at most
+    # `unique` distinct frames, tiled to the batch: the kernels' work is data-independent
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
-    uniq = min(n, args.unique)
+    uniq = min(n, wl.get("unique", 64))
+    first = wl.get("first_frame", rank * n)                    # this rank's contiguous block of the global batch
     if nes:
         base = torch.randint(0, 512, (uniq, h + 1, w), dtype=torch.int16, device=dev, generator=gen)
         images = base.repeat((n + uniq - 1) // uniq, 1, 1)[:n][:, :h]
-        s = crtlib.Settings(images, hue=0, dot_crawl_offset=[(rank * n + k) % 3 for k in range(n)])
+        s = crtlib.Settings(images, hue=0, dot_crawl_offset=[(first + k) % 3 for k in range(n)])
     else:
         base = torch.randint(0, 256, (uniq, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
         images = base.repeat((n + uniq - 1) // uniq, 1, 1, 1)[:n][:, :h]
-        # this rank's contiguous block of the global batch: frames [rank*n, (rank+1)*n)
-        parity = [shard.field_parity(rank * n + k) for k in range(n)]
+        parity = [shard.field_parity(first + k) for k in range(n)]
         s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
                             field=[a for a, _ in parity], frame=[b for _, b in parity])
-    if args.system == "vhs":
-        crt.srand([1 + rank * n + k for k in range(n)])
+    if system.startswith("vhs"):
+        crt.srand([1 + first + k for k in range(n)])
 
     # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
-    p = crt.params(s, args.noise)
+    p = crt.params(s, noise)
+    blob_crcs = None
     if dist is not None:
         shard.broadcast_params(p, dist, dev)
+        crc = torch.tensor([zlib.crc32(bytes(p))], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(crc) for _ in range(world)]
+        dist.all_gather(allc, crc)
+        blob_crcs = [int(c.item()) for c in allc]
     crt._load_field_state(s)
 
     def step(k):
-        if args.sequence:
-            crt.sequence(s, args.noise)
+        if wl.get("sequence"):
+            crt.sequence(s, noise)
             return
-        crt.fieldpass(s, args.noise, params=p)
-        # next field of the interlaced sequence (video_convert.c:261-267)
-        if not nes:
+        crt.fieldpass(s, noise, params=p)
+        if not nes:        # next field of the interlaced sequence (video_convert.c:261-267)
             crt.state[:, crtlib.ST_FIELD] ^= 1
             if k % 2 == 0:
                 crt.state[:, crtlib.ST_FRAME] ^= 1
@@ -171,11 +202,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         step(k)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -184,66 +215,218 @@ def main():
 
     # per-kernel durations with HIP events on the launch stream (separate short run, same workload)
     crt.profile(True)
-    for k in range(min(args.steps, 5)):
+    for k in range(min(steps, 5)):
         step(k)
     prof = crt.profile_read()
     crt.profile(False)
-    kern_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+    kern_ms = {k: (v[0] / max(min(steps, 5), 1)) for k, v in prof.items()}     # ms per step (a step may launch a kernel twice)
     dom = max(kern_ms, key=lambda k: kern_ms[k])
+    crt.close()
+    del crt, images, base, s
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    total_frames = world * n * steps
+    fps = total_frames / elapsed
+    abytes, own = algorithmic_bytes(system, w, h, 2 if nes else 4, outw, outh, 4, scanlines, 0)
+    achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+    own_gbs = own[dom] * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+    traffic = None
+    if traffic_file and os.path.exists(traffic_file):        # PMC passes (tools/prof_pmc.sh) on this very workload
+        try:
+            tj = json.load(open(traffic_file))
+            if tj.get("workload") == wl["name"]:
+                traffic = tj.get("k_" + dom + "_bytes_per_field")
+                traffic = traffic * n if traffic else None
+        except Exception:
+            traffic = None
+    rec = {
+        "name": wl["name"],
+        "value": fps, "unit": "frames/sec", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+        "config": {"workload": wl["desc"], "fields_per_gpu_per_step": n, "frames_per_step": world * n,
+                   "sharding": "frames by rank, RCCL broadcast of settings only",
+                   "mode": "one video per GPU (crthip_sequence)" if wl.get("sequence") else "independent frames (crthip_fieldpass)"},
+        "roofline": {"bound": "hbm", "kernel": "k_" + dom,
+                     # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic,
+                     "algorithmic_bytes_per_field": abytes,
+                     "kernel_ms": kern_ms,
+                     # the dominant kernel on the bytes it moves itself
+                     "kernel_own_bytes_per_field": own[dom], "kernel_own_achieved": own_gbs,
+                     "kernel_own_frac": own_gbs / HBM_PEAK_GBS,
+                     # the whole launch sequence, end to end (wall clock of the timed region)
+                     "pipeline_achieved": abytes * n * steps / elapsed / 1e9,
+                     "pipeline_frac": abytes * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                     "note": "640x480-class workloads are integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); 1080p leans on HBM writes"},
+    }
+    if blob_crcs is not None:
+        rec["settings_blob_crc32_per_rank"] = blob_crcs
+    if with_cpu:
+        rec["cpu_baseline"] = cpu_baseline(system + ("fir%d" % fir if fir else ""), w, h, outw, outh, noise, scanlines, cpu_seconds,
+                                           all_cores=wl.get("cpu_all_cores", False))
+        rec["gpu_over_cpu"] = fps / rec["cpu_baseline"]["value"]
+    return rec
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        system, w, h, outw, outh, noise, scanlines = sys.argv[2], *map(int, sys.argv[3:9])
+        fps, _, _ = cpu_time_workload(system, w, h, outw, outh, noise, scanlines, float(sys.argv[9]))
+        print(fps)
+        return
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="fields per GPU per step (weak scaling)")
+    ap.add_argument("--strong", type=int, default=0, metavar="FRAMES",
+                    help="strong scaling: FRAMES 1920x1080 frames (BASELINE configs[2]: 512) split over the ranks")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--noise", type=int, default=24)
+    ap.add_argument("--scanlines", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads (1080p, VHS, NES)")
+    ap.add_argument("--system", default="ntsc",
+                    help="ntsc (headline), ntscp0, vhs, nes, nesp0, snes, pv1k, temp, nesrgb, <system>bloom: extra measurements")
+    ap.add_argument("--fir", type=int, default=0, choices=[0, 4, 5, 6, 7],
+                    help="decoder of a USE_CONVOLUTION build of the reference (FIR kernel of N taps) instead of the 3-band equaliser")
+    ap.add_argument("--outw", type=int, default=0)
+    ap.add_argument("--outh", type=int, default=0)
+    ap.add_argument("--sequence", action="store_true", help="treat the batch as ONE video (crthip_sequence) instead of independent frames")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--pixel-tile", type=int, default=0, help="decoder output tile: 0 auto, 16, 32")
+    ap.add_argument("--overlap", type=int, default=0, help="chunks alternating between two streams (0 = library default)")
+    ap.add_argument("--shape", type=int, default=0, help="kernel shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel")
+    ap.add_argument("--dry-run", action="store_true", help="(tests) exercise launch / collectives / JSON without a GPU")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: become the launcher, one rank per GPU
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but torch.distributed.run started %d ranks" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import shard
+    dist = None
+    if args.dry_run:
+        return dry_run(args, torch, shard, rank, world)
+    import crtlib
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    nes = args.system in ("nes", "nesp0")
+    w, h = (256, 240) if nes else (args.width, args.height)
+    outw, outh = args.outw or (640 if nes else w), args.outh or (480 if nes else h)
+    n, noise, scanlines = args.batch, args.noise, args.scanlines
+    scaling = "weak"
+    if args.strong:
+        w, h, outw, outh, noise = 1920, 1080, 1920, 1080, 0
+        lo, hi = shard.shard_range(args.strong, rank, world)
+        n = hi - lo
+        scaling = "strong"
+    headline = (args.system, w, h, outw, outh, noise, scanlines, args.fir, bool(args.strong)) == ("ntsc", 640, 480, 640, 480, 24, 1, 0, False)
+    desc = "%s %dx%d -> %dx%d BGRA, %s, full colour, noise %d, hue 0, scanlines %d%s" % (
+        args.system.upper(), w, h, outw, outh, "progressive" if nes else "interlaced", noise, scanlines,
+        " (BASELINE configs[1])" if headline else (" (BASELINE configs[2]: %d frames over %d GPUs)" % (args.strong, world) if args.strong
+                                                    else (", %d-tap FIR decoder (USE_CONVOLUTION build)" % args.fir if args.fir else "")))
+    wl = dict(name="headline" if headline else "custom", system=args.system, w=w, h=h, outw=outw, outh=outh, batch=n, noise=noise,
+              scanlines=scanlines, fir=args.fir, unique=args.unique, overlap=args.overlap, pixel_tile=args.pixel_tile,
+              shape=args.shape, sequence=args.sequence, desc=desc, cpu_all_cores=True)
+    if args.strong:
+        wl["first_frame"] = shard.shard_range(args.strong, rank, world)[0]
+    with_cpu = world == 1 and not args.no_cpu
+    rec = run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, args.steps, args.warmup, args.cpu_seconds, with_cpu,
+                       traffic_file=os.path.join(ROOT, "profiles", "traffic.json"))
+
+    extras = []
+    if world == 1 and headline and not args.no_extra:
+        EX = [
+            dict(name="1080p_batch2048", system="ntsc", w=1920, h=1080, outw=1920, outh=1080, batch=2048, noise=0, scanlines=1,
+                 desc="NTSC 1920x1080 -> 1920x1080 BGRA, interlaced, noise 0, scanlines 1 (BASELINE configs[2] geometry, one GPU full)"),
+            dict(name="1080p_batch64", system="ntsc", w=1920, h=1080, outw=1920, outh=1080, batch=64, noise=0, scanlines=1,
+                 desc="NTSC 1920x1080 -> 1920x1080 BGRA, noise 0, scanlines 1, 64 frames = configs[2]'s per-GPU share (512 / 8)"),
+            dict(name="vhs_832x624", system="vhs", w=832, h=624, outw=832, outh=624, batch=2048, noise=12, scanlines=1,
+                 desc="CRT_SYSTEM_NTSCVHS 832x624 -> 832x624 BGRA, interlaced, noise 12 (libc rand() stream per field), scanlines 1 (BASELINE configs[3])"),
+            dict(name="nes_pattern0", system="nesp0", w=256, h=240, outw=640, outh=480, batch=4096, noise=12, scanlines=1,
+                 desc="NES 256x240 PPU pixels, CRT_CHROMA_PATTERN 0 -> 640x480 BGRA, progressive, noise 12 (BASELINE configs[4])"),
+            dict(name="640x480_batch64", system="ntsc", w=640, h=480, outw=640, outh=480, batch=64, noise=24, scanlines=1,
+                 desc="the headline workload at batch 64 (small-batch path: scanline-parallel kernel shape)"),
+            dict(name="640x480_batch1", system="ntsc", w=640, h=480, outw=640, outh=480, batch=1, noise=24, scanlines=1,
+                 desc="the headline workload, ONE field per launch sequence (latency)"),
+        ]
+        for e in EX:
+            small = e["batch"] <= 64
+            r = run_workload(torch, crtlib, shard, None, dev, 0, 1, local, e, 30 if small else max(5, args.steps // 2), 3,
+                             min(args.cpu_seconds, 4.0), not args.no_cpu and not small,
+                             traffic_file=os.path.join(ROOT, "profiles", "traffic_%s.json" % e["name"]))
+            extras.append(r)
 
     if rank == 0:
-        total_frames = world * n * args.steps
-        fps = total_frames / elapsed
-        abytes = algorithmic_bytes(w, h, 2 if nes else 4, outw, outh, 4, args.scanlines, 0, desth=240 if nes else 236)
-        achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        headline = (args.system, w, h, outw, outh, args.noise, args.scanlines, args.fir) == ("ntsc", 640, 480, 640, 480, 24, 1, 0)
-        if headline and os.path.exists(tpath):               # the PMC passes were made on the headline workload only
-            try:
-                traffic = json.load(open(tpath)).get("k_" + dom + "_bytes_per_field")
-                traffic = traffic * n if traffic else None
-            except Exception:
-                traffic = None
-        # cycle-weighted VALU bound of the dominant kernel at 640x480 (the bound that actually binds there):
-        # ISA-inspected inner loops of decoder tier 0, ~60 VALU ~ 170 cycles per sample (16 filter stages) and
-        # ~46 VALU ~ 130 cycles per pixel with the measured issue costs (profiles/r01_valu_issue_rates.txt),
-        # 3.75 waves per field, 1024 SIMDs
-        valu = None
-        if dom == "decode" and (args.system, w, h, outw, outh, args.fir) == ("ntsc", 640, 480, 640, 480, 0):
-            cycles_per_field = 3.75 * (756 * 170 + 640 * 130)
-            clk = 2.34e9                                   # GRBM_GUI_ACTIVE / duration in profiles/r01_final_sq_counters.json
-            need_ms = cycles_per_field * n / 1024.0 / clk * 1e3
-            valu = {"bound": "int-valu (cycle-weighted)", "simd_cycles_per_field": cycles_per_field, "clock_hz": clk,
-                    "min_kernel_ms": need_ms, "frac": need_ms / kern_ms[dom],
-                    "source": "DESIGN.md section 5, profiles/r01_valu_issue_rates.txt, profiles/r01_final_sq_counters.json"}
         out = {
             "metric": "frames/sec at 640x480 interlaced, bit-exact vs CPU; % HBM roofline",
-            "value": fps, "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": rec["value"], "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d -> %dx%d BGRA, %s, full colour, noise %d, hue 0, scanlines %d%s"
-                                   % (args.system.upper(), w, h, outw, outh, "progressive" if nes else "interlaced", args.noise,
-                                      args.scanlines, " (BASELINE configs[1])" if (args.system, w, h, outw, outh, args.fir) == ("ntsc", 640, 480, 640, 480, 0)
-                                      else (", %d-tap FIR decoder (USE_CONVOLUTION build)" % args.fir if args.fir else "")),
-                       "fields_per_gpu_per_step": n, "frames_per_step": world * n,
-                       "sharding": "frames by rank, RCCL broadcast of settings only",
-                       "mode": "one video per GPU (crthip_sequence)" if args.sequence else "independent frames (crthip_fieldpass)"},
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_field": abytes,
-                         "kernel_ms": kern_ms,
-                         "pipeline_achieved": abytes * n * args.steps / elapsed / 1e9,
-                         "pipeline_frac": abytes * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "valu_roofline": valu,
-                         "note": "640x480 is integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); see DESIGN.md"},
+            "config": rec["config"], "roofline": rec["roofline"],
+            "world_size": world, "world_size_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
         }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.system + ("fir%d" % args.fir if args.fir else ""), w, h, outw, outh,
-                                               args.noise, args.scanlines, args.cpu_seconds)
-            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+        for k in ("settings_blob_crc32_per_rank", "cpu_baseline", "gpu_over_cpu"):
+            if k in rec:
+                out[k] = rec[k]
+        if extras:
+            out["extra_workloads"] = extras
         print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run(args, torch, shard, rank, world):
+    """No GPU: the launch path, the settings broadcast (gloo) and the JSON contract only (tests/test_bench_cpu.py)."""
+    import crtlib
+    dist = None
+    dev = torch.device("cpu")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    p = crtlib.make_params("ntsc", w=640, h=480, outw=640, outh=480, noise=24 if rank == 0 else 99, scanlines=1)
+    crcs = [zlib.crc32(bytes(p))]
+    if dist is not None:
+        shard.broadcast_params(p, dist, dev)
+        crc = torch.tensor([zlib.crc32(bytes(p))], dtype=torch.int64)
+        allc = [torch.zeros_like(crc) for _ in range(world)]
+        dist.all_gather(allc, crc)
+        crcs = [int(c.item()) for c in allc]
+    n = args.batch
+    if args.strong:
+        lo, hi = shard.shard_range(args.strong, rank, world)
+        n = hi - lo
+    tot = torch.tensor([n], dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(tot)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "world_size": world,
+                          "world_size_seen_by_backend": dist.get_world_size() if dist is not None else 1,
+                          "settings_blob_crc32_per_rank": crcs, "frames_per_step": int(tot.item()),
+                          "scaling": "strong" if args.strong else "weak", "noise_after_broadcast": p.noise}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -270,7 +270,7 @@ int  crthip_decode(crthip_ctx *ctx, const crthip_params *p, int n,
 
 /* crthip_fieldpass may cut a batch into `chunks` pieces that alternate between the caller's
  * stream and an internal stream (fenced by events on both sides), so that the latency-bound
- * kernels of one piece overlap the ALU-bound kernels of the next.  1 = off (default). */
+ * kernels of one piece overlap the ALU-bound kernels of the next.  1 = off, 0 = chosen per launch (default). */
 int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
 
 /* Kernel shape.  0 (default): chosen per launch -- lane-per-scanline kernels (64 scanlines per wavefront, the

@@ -143,7 +143,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         return CRTHIP_E_HIP;
     }
     c->stream = 0;              /* the device's default stream until crthip_set_stream() */
-    c->overlap_chunks = 1;
+    c->overlap_chunks = 0;      /* automatic */
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;
@@ -420,7 +420,12 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         rc = crt_run_encoder_prepare(c, p, true);
         if (rc) return rc;
     }
-    const int nchunks = (c->overlap_chunks > 1 && n >= 256 * c->overlap_chunks && !c->prof) ? c->overlap_chunks : 1;
+    /* 0 = automatic: pictures that lean on HBM write bandwidth (1080p) gain from running the VALU / latency bound
+     * encoder + sync chain of one chunk under the decoder of the previous one; narrow pictures are VALU bound in
+     * every kernel and gain nothing */
+    int want_chunks = c->overlap_chunks;
+    if (want_chunks == 0) want_chunks = ((long) p->outw * p->outh >= 1280L * 720L && n >= 1024) ? 4 : 1;
+    const int nchunks = (want_chunks > 1 && n >= 256 * want_chunks && !c->prof) ? want_chunks : 1;
     if (nchunks == 1) {
         rc = fieldpass_chunk(c, p, enc, 0, n, d_images, istride, d_out, ostride, d_state);
     } else {
@@ -560,7 +565,7 @@ int crthip_set_shape(crthip_ctx *c, int shape)
 
 int crthip_set_overlap(crthip_ctx *c, int chunks)
 {
-    if (!c || chunks < 1 || chunks > 64) return CRTHIP_E_ARG;
+    if (!c || chunks < 0 || chunks > 64) return CRTHIP_E_ARG;
     c->overlap_chunks = chunks;
     return CRTHIP_OK;
 }
