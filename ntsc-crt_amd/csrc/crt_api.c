@@ -391,10 +391,17 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
 
     lib = park_libc_rand();
     sl = get_slot(v);
-    /* the kernels never read behind the image (no CRTHIP_F_IMAGE_SPARE_ROW): row h - 1 stands in for the
-     * reference's out-of-bounds row h (crt_ntsc.c:263) */
-    ensure(&sl->d_img, &sl->img_cap, img_bytes + 256);
-    CHECK(crthip_upload(g_ctx, sl->d_img, s->data, img_bytes));
+    /* The reference clamps the source row with `if (sy >= h) sy = h` (crt_ntsc.c:263) and so reads the image row
+     * BEHIND the caller's buffer on odd fields of small raw images.  That memory is not ours to read; the device copy
+     * gets one spare row of zeros instead -- what a freshly mapped heap block behind a calloc'ed image holds, i.e. what
+     * the reference's drivers see in practice (crt_main.c -r; tests/test_gpu_dropin.py) -- re-zeroed on every call. */
+    {
+        const size_t row_bytes = img_bytes / (size_t) s->h;
+        ensure(&sl->d_img, &sl->img_cap, img_bytes + row_bytes + 256);
+        CHECK(crthip_upload(g_ctx, sl->d_img, s->data, img_bytes));
+        CHECK(crthip_memset(g_ctx, sl->d_img + img_bytes, 0, row_bytes));
+        p.flags |= CRTHIP_F_IMAGE_SPARE_ROW;
+    }
     CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
     state_to_device(sl, v, field, frame, aux);
     CHECK(crthip_modulate(g_ctx, &p, 1, sl->d_img, 0, sl->d_analog, sl->d_state));

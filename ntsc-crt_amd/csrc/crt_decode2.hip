@@ -37,10 +37,11 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int TS = 32, RING = 64;                   /* samples per tile; LDS ring length (two tiles) */
     constexpr int WINB = ((S::AV_LEN + 31) / 16) * 16;  /* bytes of a line's sample window in LDS */
     __shared__ __attribute__((aligned(16))) signed char s_inp[LPW][WINB];
-    __shared__ int s_u[LPW][3][RING];                   /* filter inputs per channel */
-    __shared__ int s_c[LPW][6][RING];                   /* cascade outputs: [Ylo, Yhi, Ilo, Ihi, Qlo, Qhi], slot (x + 3) % RING */
-    __shared__ int s_yiq[LPW][3][RING];
+    __shared__ int s_u[LPW][3][RING + 1];                 /* filter inputs per channel */
+    __shared__ int s_c[LPW][6][RING + 1];                 /* cascade outputs: [Ylo, Yhi, Ilo, Ihi, Qlo, Qhi], slot (x + 3) % RING */
+    __shared__ int s_yiq[LPW][3][RING + 1];    /* + 1: (scanline, channel) rows start on different LDS banks */
     __shared__ int s_wave[LPW][2][8];                   /* demodulation carriers per sample phase */
+    __shared__ int s_sink[64 + TS];                     /* where the lanes that are not the last stage of a cascade "store" */
 
     const int lane = threadIdx.x;
     const int lrow = lane >> 4, jj = lane & 15, bank = jj >> 2, cidx = jj & 3;
@@ -83,8 +84,11 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     const int coef = is_hi ? (ch == 0 ? P.eq_hf[0] : ch == 1 ? P.eq_hf[1] : P.eq_hf[2])
                            : (ch == 0 ? P.eq_lf[0] : ch == 1 ? P.eq_lf[1] : P.eq_lf[2]);
     const int *my_u = &s_u[ls][ch][0];
-    int *my_c = &s_c[ls][ch * 2 + is_hi][0];
     const bool writes = active && bank == 3;
+    /* every lane stores after every step (no divergent control flow inside the systolic loop); only the last stage of a
+     * live cascade stores into its ring, everybody else into the sink */
+    int *my_c = writes ? &s_c[ls][ch * 2 + is_hi][0] : &s_sink[lane];
+    const int c_half = writes ? TS : 0;                 /* the sink has no halves */
 
     /* sample window -> LDS (16-byte pieces, LPL lanes per scanline) */
     {
@@ -155,12 +159,15 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
         /* ---- filter: TS systolic steps ---- */
         {
             const int hb = t0 & TS;                      /* which half of the ring this tile uses */
-#pragma unroll 8
+            int ub[TS];                                  /* the tile's inputs up front: no LDS latency inside the chain */
+#pragma unroll
+            for (int k = 0; k < TS; k++) ub[k] = my_u[hb + k];
+            int *cdst = my_c + ((t0 & TS) ? c_half : 0);
+#pragma unroll
             for (int k = 0; k < TS; k++) {
-                const int uin = my_u[hb + k];
-                const int tin = __builtin_amdgcn_update_dpp(uin, xs, DPP_ROW_SHR4, 0xf, 0xf, false);
+                const int tin = __builtin_amdgcn_update_dpp(ub[k], xs, DPP_ROW_SHR4, 0xf, 0xf, false);
                 xs += (int) ((unsigned) coef * (unsigned) (tin - xs) + 32768u) >> 16;     /* crt_core.c:211-217 */
-                if (writes) my_c[hb + k] = xs;           /* bank 3 at step t holds the cascade output of sample t - 3 */
+                cdst[k] = xs;                            /* bank 3 at step t holds the cascade output of sample t - 3 */
             }
         }
         wave_lds_fence();

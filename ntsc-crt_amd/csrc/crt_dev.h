@@ -258,6 +258,23 @@ __device__ __forceinline__ unsigned pack4(int v0, int v1, int v2, int v3)
 
 /* noise LCG, crt_core.c:359-364 */
 __device__ __forceinline__ unsigned lcg_step(unsigned rn) { return LCG_MUL * rn + LCG_ADD; }
+/* the same in ONE vector instruction: the low half of v_mad_u64_u32(rn, MUL, {ADD, 0}) is the wrapped 32-bit result
+ * (v_mul_lo_u32 + v_add_u32 otherwise).  `add_pair` = {LCG_ADD, 0} kept in a register pair by the caller. */
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lcg_step_mad64(unsigned rn, v2u add_pair)
+{
+    v2u r;
+    unsigned long long carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(rn), "s"(LCG_MUL), "v"(add_pair));
+    return r.x;
+}
+/* vgpr * sgpr + vgpr with the addend already in a VGPR (24-bit operands) */
+__device__ __forceinline__ int mad24_vv(int v, int s_uniform, int acc_v)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(s_uniform), "v"(acc_v));
+    return r;
+}
 __device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)
 {
     int s = sample + (((int) ((rn >> 16) & 0xffu) - 0x7f) * noise >> 8);
@@ -312,6 +329,7 @@ struct crthip_ctx {
     bool skel_valid;
     int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
     int shape;                  /* crthip_set_shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel */
+    bool legacy_sync;           /* CRTHIP_LEGACY_SYNC=1 in the environment: the 16-lanes-per-field sync kernel (A/B measurements) */
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;

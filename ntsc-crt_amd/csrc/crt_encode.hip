@@ -211,6 +211,11 @@ struct RowTiles {
     }
     __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[lane * STRIDE + (idx & (TILE - 1))]; }
     __device__ __forceinline__ void put(int g, unsigned pack) { s_out[lane * STRIDE + (g & (TILE - 1))] = pack; }
+    /* sample k of group g as one LDS byte store: no packing arithmetic on the vector unit */
+    __device__ __forceinline__ void put_byte(int g, int k, int v)
+    {
+        ((unsigned char *) s_out)[(lane * STRIDE + (g & (TILE - 1))) * 4 + k] = (unsigned char) v;
+    }
     /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
     __device__ __forceinline__ void drain(int g0, int ng, int destw)
     {
@@ -354,27 +359,36 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         int cph = 0;                                              /* x % CCS for the 5-sample system (wave-uniform) */
 
         if (IN4) tiles.start();
-        const int noise127 = 0x7f * noise;
+        /* loop invariants the compiler would otherwise re-materialise per sample (constant-bus limit of VOP3) */
+        int neg_noise127 = -0x7f * noise;
+        asm volatile("" : "+v"(neg_noise127));
+        v2u lcg_add = { LCG_ADD, 0u };
+        asm volatile("" : "+v"(lcg_add));
+        int fy = 0, fi = 0, fq = 0, have_col = -1;                 /* YIQ of source column have_col (wave-uniform) */
         for (int g = 0; g < ngroups; g++) {
-            int smp[4] = { 0, 0, 0, 0 };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = 4 * g + k;
                 if (x < destw) {
-                    unsigned pixel;
-                    if (IN4) {
-                        tiles.want(col >> AC_SHIFT);               /* wave-uniform */
-                        pixel = tiles.pixel_dword(col);
-                    } else {
-                        const unsigned char *pp = row + (size_t) col * in_bpp;
-                        pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
-                        if (in_bpp == 4) pixel |= (unsigned) pp[3] << 24;
+                    /* an upscaled line (w < destw) samples some source pixels twice: all 64 lanes are at the same
+                     * column, so "same pixel as before" is a scalar branch that skips the fetch and the conversion */
+                    if (col != have_col) {
+                        unsigned pixel;
+                        if (IN4) {
+                            tiles.want(col >> AC_SHIFT);           /* wave-uniform */
+                            pixel = tiles.pixel_dword(col);
+                        } else {
+                            const unsigned char *pp = row + (size_t) col * in_bpp;
+                            pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
+                            if (in_bpp == 4) pixel |= (unsigned) pp[3] << 24;
+                        }
+                        const unsigned rgb = __builtin_amdgcn_perm(pixel, pixel, isel);
+                        const int r = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, b = rgb & 255;
+                        fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
+                        fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
+                        fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
+                        have_col = col;
                     }
-                    const unsigned rgb = __builtin_amdgcn_perm(pixel, pixel, isel);
-                    const int r = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, b = rgb & 255;
-                    const int fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
-                    const int fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
-                    const int fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
                     if (S::BANDLIMIT) {
                         hy += mulq<FAST>(fy - hy, cy_) >> 11;       /* iirf, crt_ntsc.c:117-126 */
                         hi += mulq<FAST>(fi - hi, ci_) >> 11;
@@ -396,16 +410,19 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     int ire = ire_base + (mulq<FAST>(hy + mi + mq, white) >> 10);
                     ire = clampi(ire, 0, 110);
                     if (NOISE) {
-                        rn = lcg_step(rn);
-                        /* (byte - 0x7f) * noise, distributed: the byte select rides on the multiply (SDWA) */
-                        ire = clampi(ire + ((mulq<FAST>((int) ((rn >> 16) & 0xffu), noise) - noise127) >> 8), -127, 127);
+                        rn = lcg_step_mad64(rn, lcg_add);
+                        /* (byte - 0x7f) * noise, distributed: the byte select rides on the multiply-add */
+                        const int nb = (int) ((rn >> 16) & 0xffu);
+                        const int nz = FAST ? mad24_vv(nb, noise, neg_noise127) : nb * noise + neg_noise127;
+                        ire = clampi(ire + (nz >> 8), -127, 127);
                     }
-                    smp[k] = ire;
+                    tiles.put_byte(g, k, ire);
                     col += qstep; err += rstep;
                     if (err >= destw) { err -= destw; col++; }
+                } else {
+                    tiles.put_byte(g, k, 0);
                 }
             }
-            tiles.put(g, pack4(smp[0], smp[1], smp[2], smp[3]));
             tiles.group_done(g, ngroups, destw);
         }
     }

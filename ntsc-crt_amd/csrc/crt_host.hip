@@ -144,6 +144,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     }
     c->stream = 0;              /* the device's default stream until crthip_set_stream() */
     c->overlap_chunks = 0;      /* automatic */
+    { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;

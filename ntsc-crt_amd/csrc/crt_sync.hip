@@ -347,6 +347,280 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
     if (j == 0 && live) st->hsync = hsync;
 }
 
+/* ------------------------------------------------------------------------------------------------------------ */
+/* D4-D7, second implementation: ONE WAVE PER FIELD, scalar control                                               */
+/* ------------------------------------------------------------------------------------------------------------ */
+/* k_hsync (above) walks a field's 240 lines with everything -- sync search, burst integrators, carrier table, row
+ * bookkeeping -- inside one serial iteration of ~1800 cycles, four fields per wave: 0.18 ms however small the batch,
+ * one wave per SIMD however large.  Here the two serial recurrences are separated and stripped to their cores:
+ *   pass 1   hsync chain: per line 16 LDS bytes -> DPP row scan -> ballot -> scalar update           (~200 cycles)
+ *   pass 2   burst integrators (crt_core.c:462-467): 10 steps per line and carrier phase of
+ *            acc' = acc + s - ((acc >> 7) + (acc > 0 && (acc & 127) != 0))   [== acc * 127 / 128 + s in C]
+ *            on CC_VPER x CC_SAMPLES lanes, each walking the lines of its own line class          (~25 cycles a step)
+ *   pass 3   everything else (carrier table, positions, rows, ranks, flags) in parallel, one lane per line
+ * The lines are processed in chunks of 64 (one per lane): the sync windows of chunk c+1 and the burst samples of chunk
+ * c are fetched (global -> registers -> LDS) while chunk c / c-1 are being processed, so a field needs ~12 KB of LDS
+ * and 16 fields per CU run interleaved.  A line whose sync window is not where the prefetch put it (hsync far from
+ * both 0 and HRES: first lines after a caller-supplied hsync, runaway sync) is served by direct loads -- slower, same
+ * result. */
+template <class S, bool EXACT_MUL>
+__device__ __forceinline__ int burst_step(int acc, int s)
+{
+    if (EXACT_MUL) {
+        const int t127 = (int) (((unsigned) acc << 7) - (unsigned) acc);      /* acc * 127 with 32-bit wrap */
+        return ((t127 + ((t127 >> 31) & 127)) >> 7) + s;                       /* C's truncating / 128 */
+    }
+    /* |acc| < 2^24: acc * 127 / 128 == acc - (acc >> 7) - (acc > 0 && (acc & 127) != 0), the last term being
+     * "(acc & 0x8000007f) > 0" as a signed compare */
+    return (acc + s) - (acc >> 7) - (int) ((int) ((unsigned) acc & 0x8000007fu) > 0);
+}
+
+template <class S>
+__global__ void __launch_bounds__(64)
+k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+             crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
+{
+    constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS, VPER = S::VPER;
+    constexpr int WOFF = S::SYNC_BEG - S::HWIN;          /* first byte of the search window relative to ln + hsync */
+    constexpr int CH = 64, NCH = (S::LINES + CH - 1) / CH;
+    constexpr int WBACK = 24, WPIECES = 5, WLEN = WPIECES * 16;   /* per line: bytes [ln + WOFF - 24, + 80): hsync -24 .. 40 */
+    constexpr int WSTR = 21;                             /* dwords per window row (84 bytes: odd stride, no bank conflicts) */
+    constexpr int BPIECES = (S::CB_LEN + 15 + 15) / 16;  /* 16-byte pieces covering CB_LEN bytes from an arbitrary address */
+    constexpr int BSTR = BPIECES * 4 + 1;                /* dwords per burst row */
+    __shared__ int s_win[(CH + 1) * WSTR];               /* sync windows of the chunk's lines (+ the line after it) */
+    __shared__ int s_bur[CH * BSTR];                     /* burst samples of the chunk's lines */
+    __shared__ int s_hs[CH], s_skip[CH];                 /* hsync after each line of the chunk; line skipped (:431) */
+    __shared__ int s_ccr[CH][8];                         /* integrators of the line's class after the line */
+    __shared__ short s_list[VPER][CH + 2];               /* chunk lines of each line class, in order */
+    __shared__ int s_cnt[VPER];
+
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x;
+    if (f >= n_fields) return;
+    const signed char *in = inp + (size_t) f * fstride;
+    crthip_state *st = state + f;
+    int hsync = __builtin_amdgcn_readfirstlane(st->hsync);
+    const int vsync = __builtin_amdgcn_readfirstlane(st->vsync);
+    const int field_rows = __builtin_amdgcn_readfirstlane(st->odd_field) * (P.ratio / 2);      /* crt_core.c:407 */
+    const unsigned span = (unsigned) P.outh + P.v_fac;
+    crthip_line *out_lines = lines + (size_t) f * S::LINES;
+
+    /* chain lanes: lane = r * CCS + p integrates carrier phase p of line class r */
+    const int my_r = lane / CCS, my_p = lane - my_r * CCS;
+    const bool chain_lane = lane < VPER * CCS;
+    int acc = chain_lane ? st->ccf[my_r][my_p] : 0;
+    bool big = chain_lane && (acc >= (1 << 23) || acc <= -(1 << 23));
+    const bool exact_mul = __ballot(big) != 0ull;        /* caller-supplied garbage in ccf: keep the wrapping multiply */
+    const int k0 = CCS == 4 ? ((my_p - S::CB_BEG) & 3) : ((my_p - S::CB_BEG) % CCS + CCS) % CCS;
+
+    auto lidx_of = [&](int line) { int l = line + vsync; return l >= S::VRES ? l - S::VRES : l; };   /* 0 <= vsync < VRES */
+    /* flat start of the sync window of decoded line `line` (lines TOP .. BOT: one past the end is needed too) */
+    auto win_base = [&](int line) { return lidx_of(line) * S::HRES + WOFF - WBACK; };
+
+    /* ---- prologue: sync windows of chunk 0 in flight ---- */
+    v4i wreg[WPIECES], wext[WPIECES], breg[BPIECES];
+    auto fetch_windows = [&](int c) {
+        const int line = S::TOP + c * CH + lane;
+        int b = win_base(line < S::BOT ? line : S::BOT);
+        if (b < 0) b = 0;
+#pragma unroll
+        for (int q = 0; q < WPIECES; q++) wreg[q] = load16u(in + b + q * 16);
+        /* lane 0 also brings the window of the line after the chunk (wrapped hsync values look there) */
+        int be = win_base(S::TOP + (c + 1) * CH < S::BOT ? S::TOP + (c + 1) * CH : S::BOT);
+        if (be < 0) be = 0;
+#pragma unroll
+        for (int q = 0; q < WPIECES; q++) wext[q] = load16u(in + be + q * 16);
+    };
+    auto park_windows = [&]() {
+#pragma unroll
+        for (int q = 0; q < WPIECES; q++) {
+            int *d = s_win + lane * WSTR + q * 4;
+            d[0] = wreg[q].x; d[1] = wreg[q].y; d[2] = wreg[q].z; d[3] = wreg[q].w;
+            if (lane == 0) {
+                int *e = s_win + CH * WSTR + q * 4;
+                e[0] = wext[q].x; e[1] = wext[q].y; e[2] = wext[q].z; e[3] = wext[q].w;
+            }
+        }
+    };
+    fetch_windows(0);
+
+    for (int c = 0; c <= NCH; c++) {
+        /* ================= pass 1 of chunk c: the hsync chain ================= */
+        if (c < NCH) {
+            wave_lds_fence();
+            park_windows();
+            wave_lds_fence();
+            if (c + 1 < NCH) fetch_windows(c + 1);
+            const int nl = S::LINES - c * CH < CH ? S::LINES - c * CH : CH;
+            for (int i = 0; i < nl; i++) {
+                const int line = S::TOP + c * CH + i;
+                /* D4, crt_core.c:428-432 (unsigned arithmetic: v_fac is unsigned) */
+                const int beg = (int) ((unsigned) (line - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows);
+                const bool skip = beg >= P.outh;
+                if (!skip) {
+                    /* D5, crt_core.c:437-450 */
+                    const int lidx = lidx_of(line);
+                    int wrow = -1, rel = 0;                     /* which parked window holds the 2*HWIN bytes, where */
+                    if (hsync >= -WBACK + 0 && hsync + 2 * S::HWIN + WBACK <= WLEN && win_base(line) >= 0) { wrow = i; rel = hsync + WBACK; }
+                    else if (hsync >= S::HRES - WBACK && hsync < S::HRES && lidx + 1 < S::VRES && line + 1 <= S::BOT &&
+                             lidx_of(line + 1) == lidx + 1) { wrow = i + 1; rel = hsync - S::HRES + WBACK; }
+                    int sv = 0;
+                    if (wrow >= 0) {
+                        if (lane < 2 * S::HWIN) sv = ((const signed char *) (s_win + wrow * WSTR))[rel + lane];
+                    } else {
+                        const long a = (long) lidx * S::HRES + hsync + WOFF + lane;
+                        if (lane < 2 * S::HWIN && a >= 0 && a < (long) fstride) sv = in[a];
+                    }
+                    const int pref = row_incl_scan(sv);
+                    const unsigned m16 = (unsigned) __ballot(lane < 2 * S::HWIN && pref <= S::HTHR) & 0xffffu;
+                    const int hi = m16 ? (__ffs((int) m16) - 1 - S::HWIN) : S::HWIN;
+                    hsync = posmod(hi + hsync, S::HRES);                  /* :447 */
+                }
+                if (lane == 0) { s_hs[i] = hsync; s_skip[i] = skip; }
+            }
+            wave_lds_fence();
+        }
+        /* ================= pass 2 of chunk c - 1: the burst integrators ================= */
+        if (c > 0) {
+            const int cc = c - 1;
+            const int nl = S::LINES - cc * CH < CH ? S::LINES - cc * CH : CH;
+            /* the burst samples fetched one iteration ago -> LDS */
+            {
+#pragma unroll
+                for (int q = 0; q < BPIECES; q++) {
+                    int *d = s_bur + lane * BSTR + q * 4;
+                    d[0] = breg[q].x; d[1] = breg[q].y; d[2] = breg[q].z; d[3] = breg[q].w;
+                }
+            }
+            wave_lds_fence();
+            const int n_mine = chain_lane ? s_cnt[my_r] : 0;
+            int n_max = n_mine;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(n_max, o); n_max = v > n_max ? v : n_max; }
+            for (int j = 0; j < n_max; j++) {
+                if (j < n_mine) {
+                    const int i = s_list[my_r][j];
+                    const signed char *b = (const signed char *) (s_bur + i * BSTR) + (s_ccr[i][7] /* byte offset of the burst in the row */);
+                    int smp[NB];
+#pragma unroll
+                    for (int q = 0; q < NB; q++) smp[q] = b[k0 + CCS * q];
+                    if (exact_mul) {
+#pragma unroll
+                        for (int q = 0; q < NB; q++) acc = burst_step<S, true>(acc, smp[q]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, smp[q]);
+                    }
+                    s_ccr[i][my_p] = acc;
+                }
+            }
+            wave_lds_fence();
+            /* ================= pass 3 of chunk c - 1: the line table, one lane per line ================= */
+            if (lane < nl) {
+                const int i = lane, line = S::TOP + cc * CH + i;
+                const int hs = s_ccr[i][6];                                /* hsync after this line (kept here: s_hs is reused) */
+                const bool skip = s_ccr[i][5] != 0;
+                int beg = (int) ((unsigned) (line - S::TOP + 0) * span / (unsigned) S::LINES + (unsigned) field_rows);
+                int end = (int) ((unsigned) (line - S::TOP + 1) * span / (unsigned) S::LINES + (unsigned) field_rows);
+                if (end > P.outh) end = P.outh;
+                crthip_line lp;
+                lp.dx = P.dx; lp.scanl = 0;                                /* :528-529; k_bloom rewrites them per line */
+                lp.hsync = hs;
+                if (skip) {
+                    lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0;
+                } else {
+                    const int lidx = lidx_of(line);
+                    const int xpos = posmod(S::AV_BEG + hs - 3, S::HRES);  /* :452-454 */
+                    int ypos = lidx + 3;
+                    if (ypos >= S::VRES) ypos -= S::VRES;
+                    lp.pos = xpos + ypos * S::HRES;
+                    int dci, dcq;
+                    const int pa = posmod(hs, CCS);
+                    if constexpr (CCS == 4) {                              /* :471-472 */
+                        dci = s_ccr[i][(pa + 1) & 3] - s_ccr[i][(pa + 3) & 3];
+                        dcq = s_ccr[i][(pa + 2) & 3] - s_ccr[i][(pa + 0) & 3];
+                        lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
+                        lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
+                    } else {                                               /* :480-494 */
+                        const int peak_a = pa + CCS / 4, peak_b = pa;
+                        const int dci_a = s_ccr[i][peak_a % CCS];
+                        const int dci_b = (s_ccr[i][(peak_a + CCS / 2) % CCS] + s_ccr[i][(peak_a + CCS / 2 + 1) % CCS]) / 2;
+                        const int dcq_a = s_ccr[i][(peak_b + CCS / 2) % CCS];
+                        const int dcq_b = s_ccr[i][peak_b % CCS];
+                        dci = dci_a - dci_b;
+                        dcq = dcq_a - dcq_b;
+                        lp.wave0 = dci;
+                        lp.wave1 = dcq;
+                    }
+                    lp.beg = beg;
+                    int nrows = end - P.scanlines - beg;                    /* rows beg .. end-scanlines-1, :662 */
+                    nrows = nrows < 1 ? 1 : nrows;
+                    if (nrows > CRTHIP_LINE_NROWS_MASK) nrows = CRTHIP_LINE_NROWS_MASK;
+                    /* rank among the lines that start on the same output row (outh + v_fac < LINES): beg is monotone in
+                     * the line and no line before a non-skipped one is skipped, so it is the distance to the first
+                     * line with this beg */
+                    int rank = 0;
+                    while (line - rank - 1 >= S::TOP &&
+                           (int) ((unsigned) (line - rank - 1 - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows) == beg)
+                        rank++;
+                    nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
+                    if (CCS != 4)
+                        nrows |= CRTHIP_LINE_WIDE;
+                    else if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
+                        nrows |= CRTHIP_LINE_EXACT;
+                    else if (lp.wave0 > T0_WAVE_MAX || lp.wave0 < -T0_WAVE_MAX || lp.wave1 > T0_WAVE_MAX || lp.wave1 < -T0_WAVE_MAX)
+                        nrows |= CRTHIP_LINE_NOT64;
+                    else if (lp.wave0 > LOSKIP_WAVE_MAX || lp.wave0 < -LOSKIP_WAVE_MAX || lp.wave1 > LOSKIP_WAVE_MAX || lp.wave1 < -LOSKIP_WAVE_MAX)
+                        nrows |= CRTHIP_LINE_WIDE;
+                    lp.nrows = nrows;
+                }
+                v4i a, b;
+                a.x = lp.pos; a.y = lp.wave0; a.z = lp.wave1; a.w = lp.beg;
+                b.x = lp.nrows; b.y = lp.hsync; b.z = lp.dx; b.w = lp.scanl;
+                store16u(out_lines + cc * CH + i, a);
+                store16u((int *) (out_lines + cc * CH + i) + 4, b);
+            }
+            wave_lds_fence();
+        }
+        /* ================= hand-over: per-line records of chunk c for passes 2 / 3, burst fetch ================= */
+        if (c < NCH) {
+            const int nl = S::LINES - c * CH < CH ? S::LINES - c * CH : CH;
+            /* line class lists (ypos % VPER, :456) in line order, skipped lines excluded */
+            const bool mine = lane < nl;
+            const int hs = mine ? s_hs[lane] : 0;
+            const bool skip = mine ? s_skip[lane] != 0 : true;
+            const int line = S::TOP + c * CH + lane;
+            const int lidx = lidx_of(line < S::BOT ? line : S::TOP);
+            int ypos = lidx + 3;
+            if (ypos >= S::VRES) ypos -= S::VRES;
+            const int cls = VPER == 1 ? 0 : ypos % VPER;
+#pragma unroll
+            for (int r = 0; r < VPER; r++) {
+                const unsigned long long m = __ballot(!skip && cls == r);
+                if (!skip && cls == r) s_list[r][__popcll(m & ((1ull << lane) - 1ull))] = (short) lane;
+                if (lane == 0) s_cnt[r] = __popcll(m);
+            }
+            /* burst samples: CB_LEN bytes from ln + halign + CB_BEG (:459-461), fetched as 16-byte pieces from the
+             * address rounded down to 4 (the row keeps the remainder) */
+            const int halign = CCS == 4 ? (hs & ~3) : hs - hs % CCS;
+            const int baddr = lidx * S::HRES + halign + S::CB_BEG;
+            if (mine) {
+                s_ccr[lane][5] = skip;
+                s_ccr[lane][6] = hs;
+                s_ccr[lane][7] = baddr & 3;
+            }
+            const int ba = (baddr & ~3);
+#pragma unroll
+            for (int q = 0; q < BPIECES; q++) {
+                breg[q] = (mine && !skip) ? load16u(in + ba + q * 16) : v4i{0, 0, 0, 0};
+            }
+            wave_lds_fence();
+        }
+    }
+    if (chain_lane) st->ccf[my_r][my_p] = acc;
+    if (lane == 0) st->hsync = hsync;
+}
+
 /* CRT_DO_BLOOM (crt_core.c:399-402, 512-526): the beam energy of every decoded line (sum of its AV_LEN samples)
  * drives a leaky integrator prev_e that runs over the lines of a field in order; each line gets its own width,
  * i.e. its own resampler step dx and start scanL.  One workgroup per field: 256 lanes sum the lines in parallel
@@ -395,7 +669,10 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
         hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
-        hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+        if (c->legacy_sync)
+            hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+        else
+            hipLaunchKernelGGL((k_hsync_wave<S>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         if (p->bloom)
             hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;

@@ -113,7 +113,7 @@ class _HipCRT:
 
     @property
     def ccf(self):
-        return self.g.ccf[0, :(3 if self.nes else 1)]
+        return self.g.ccf[0, :(3 if self.nes else 1), :4]
 
 
 @pytest.mark.gpu

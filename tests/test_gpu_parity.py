@@ -325,12 +325,28 @@ def test_nes_negative_hue_and_dot_crawl(crtlib, name):
 
 def test_rectangle_running_over_the_line_end(crtlib):
     """xoffset 4 in non-raw NTSC puts the rectangle at 160 + 753 = 913 > 910: the reference's flat index
-    (crt_ntsc.c:322) continues in the next line's front porch; so do the kernels."""
+    (crt_ntsc.c:322) continues in the next line's front porch; so do the kernels (both shapes, stagewise and fused).
+    xoffset 150 runs 147 samples into the next line -- over its sync pulse and burst: the ENCODER is still exact
+    (analog[] compared); what the decoder makes of such a field involves windows far behind inp[] (reference UB)."""
     for fused in (False, True):
         _run_case(crtlib, ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1, xoffset=4), {}),
                   fused=fused, steps=2)
-        _run_case(crtlib, ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 0, dict(as_color=1, xoffset=150, yoffset=1), dict(scanlines=1)),
+        _run_case(crtlib, ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 0, dict(as_color=1, xoffset=16, yoffset=1), dict(scanlines=1)),
                   fused=fused, steps=2, shape=2)
+    n, w, h = 2, 640, 480
+    imgs = np.stack([R.synth_image(w, h, 4, 55 + k) for k in range(n)])
+    g = crtlib.CRT(n, 640, 480, crtlib.FMT_BGRA, "ntsc", device=0)
+    s = crtlib.Settings(_padded(imgs), format=crtlib.FMT_BGRA, field=[0, 1], frame=[0, 0], xoffset=150, yoffset=2)
+    g.modulate(s)
+    g.synchronize()
+    an = g.analog.cpu().numpy()
+    orc = R.Oracle("ntsc")
+    for k in range(n):
+        c = orc.new_crt(640, 480, R.FMT_BGRA)
+        c.settings(np.concatenate([imgs[k], imgs[k][-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1, field=k, frame=0, xoffset=150, yoffset=2)
+        c.modulate()
+        np.testing.assert_array_equal(an[k, :orc.input_size], c.analog, err_msg="xoffset 150: analog of field %d" % k)
+    g.close()
 
 
 def test_tight_images_are_never_read_past_their_end(crtlib):
@@ -759,6 +775,44 @@ def test_full_size_batch_properties(crtlib, n, w, h, noise):
         c.modulate()
         c.demodulate(noise)
         np.testing.assert_array_equal(host[j].reshape(-1), c.out, err_msg="field %d of the full batch" % k)
+
+
+def test_full_batch_every_field_checked_against_the_oracle(crtlib):
+    """the 4096-field batch of BASELINE configs[1] with 64 DISTINCT images x 2 field parities; a per-field
+    checksum (plain byte sum + position-weighted sum, computed on the device) of EVERY one of the 4096 pictures is
+    compared with the checksum of the oracle's picture for that (image, parity), and so is every field's state."""
+    import torch
+    n, w, h, uniq, noise = 4096, 640, 480, 64, 24
+    base = np.stack([R.synth_image(w, h, 4, 9000 + k, "random" if k % 4 else "bars") for k in range(uniq)])
+    imgs = torch.from_numpy(np.concatenate([base, base[:, -1:]], axis=1)).to("cuda:0")       # + the spare row
+    data = imgs.repeat(n // uniq, 1, 1, 1)[:, :h]
+    fields = [(k // uniq) & 1 for k in range(n)]                   # image k % 64, parity (k // 64) & 1
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+    g.scanlines = 1
+    s = crtlib.Settings(data, format=crtlib.FMT_BGRA, field=list(fields), frame=0)
+    g.fieldpass(s, noise)
+    g.synchronize()
+    flat = g.out.reshape(n, -1).to(torch.int64)
+    wts = (torch.arange(flat.shape[1], device=flat.device, dtype=torch.int64) % 65521) + 1
+    sums = torch.stack([flat.sum(dim=1), (flat * wts).sum(dim=1)], dim=1).cpu().numpy()
+    st = g.state.cpu().numpy()
+    g.close()
+    orc = R.Oracle("ntsc")
+    wn = (np.arange(w * h * 4, dtype=np.int64) % 65521) + 1
+    want = {}
+    for img in range(uniq):
+        for par in (0, 1):
+            c = orc.new_crt(w, h, R.FMT_BGRA)
+            c.set("scanlines", 1)
+            c.settings(np.concatenate([base[img], base[img][-1:]]), format=R.FMT_BGRA, w=w, h=h, as_color=1, field=par, frame=0)
+            c.modulate()
+            c.demodulate(noise)
+            o = c.out.astype(np.int64)
+            want[(img, par)] = (int(o.sum()), int((o * wn).sum()), c.get("hsync"), c.get("vsync"), c.get("rn"))
+    for k in range(n):
+        a, b, hs, vs, rn = want[(k % uniq, fields[k])]
+        assert (int(sums[k, 0]), int(sums[k, 1])) == (a, b), "field %d: picture checksum differs from the oracle" % k
+        assert (int(st[k, crtlib.ST_HSYNC]), int(st[k, crtlib.ST_VSYNC]), int(st[k, crtlib.ST_RN])) == (hs, vs, rn), "field %d state" % k
 
 
 def test_fieldpass_is_graph_capturable(crtlib):
