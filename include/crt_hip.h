@@ -235,8 +235,9 @@ int  crthip_fieldpass(crthip_ctx *ctx, const crthip_params *p, int n,
  *   set's state before field 0; on return d_state[k] holds the state after field k.
  *   d_out image k = the (single) output buffer as it stands after field k; d_out_init = its content
  *   before field 0 (NULL = zeros, i.e. calloc as in the drivers).
- * Requires blend == 0 (video_convert.c:239); *passes (optional) receives the number of sync fixed-point
- * passes that were needed.
+ * blend != 0 (crt_main.c:235) makes the picture a recurrence over the fields: the fields are then decoded in
+ * parallel and folded into each other by one small pass per field (needs outh + v_fac >= CRT_LINES).
+ * *passes (optional) receives the number of sync fixed-point passes that were needed.
  * VHS build: the fields also share ONE rand() stream.  Entry 0 of the bound history array
  * (crthip_vhs_bind_history) is the generator before field 0; a serial pre-pass walks the stream's
  * data-dependent part for all fields (about 0.15 ms per field) and on return entry k is the generator after

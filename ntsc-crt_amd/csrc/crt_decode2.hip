@@ -38,7 +38,9 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int WINB = ((S::AV_LEN + 31) / 16) * 16;  /* bytes of a line's sample window in LDS */
     __shared__ __attribute__((aligned(16))) signed char s_inp[LPW][WINB];
     __shared__ int s_u[LPW][3][RING + 1];                 /* filter inputs per channel */
-    __shared__ int s_c[LPW][6][RING + 1];                 /* cascade outputs: [Ylo, Yhi, Ilo, Ihi, Qlo, Qhi], slot (x + 3) % RING */
+    constexpr int NC = NARROW ? 4 : 6;                  /* cascades per scanline: [Ylo, Yhi, Ihi, Qhi] or [Ylo, Yhi, Ilo, Ihi, Qlo, Qhi] */
+    constexpr int C_IHI = NARROW ? 2 : 3, C_QHI = NARROW ? 3 : 5;
+    __shared__ int s_c[LPW][NC][RING + 1];                /* cascade outputs, slot (x + 3) % RING */
     __shared__ int s_yiq[LPW][3][RING + 1];    /* + 1: (scanline, channel) rows start on different LDS banks */
     __shared__ int s_wave[LPW][2][8];                   /* demodulation carriers per sample phase */
     __shared__ int s_sink[64 + TS];                     /* where the lanes that are not the last stage of a cascade "store" */
@@ -87,7 +89,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     const bool writes = active && bank == 3;
     /* every lane stores after every step (no divergent control flow inside the systolic loop); only the last stage of a
      * live cascade stores into its ring, everybody else into the sink */
-    int *my_c = writes ? &s_c[ls][ch * 2 + is_hi][0] : &s_sink[lane];
+    int *my_c = writes ? &s_c[ls][NARROW ? cidx : ch * 2 + is_hi][0] : &s_sink[lane];
     const int c_half = writes ? TS : 0;                 /* the sink has no halves */
 
     /* sample window -> LDS (16-byte pieces, LPL lanes per scanline) */
@@ -111,23 +113,16 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     }
     wave_lds_fence();
 
-    /* per-scanline values every lane needs in the wave-wide phases, by slot (wave-uniform after the broadcast) */
-    int v_first[LPW], v_w[LPW], v_nrows[LPW], v_dx[LPW], v_scanl[LPW], v_pxn[LPW];
-    unsigned long long v_dst[LPW];
+    /* In the wave-wide phases (prep, combine, pixels) a scanline keeps its LPL lanes: lane jl of the scanline handles
+     * samples / pixels jl, jl + LPL, ... of it, so every per-scanline quantity is simply the lane's own copy. */
+    const int jl = lane & (LPL - 1);
+    constexpr int SPL = TS / LPL;                        /* samples per lane and tile in prep / combine (2 or 1) */
     constexpr int bpp = BPP3 ? 3 : 4;
     const size_t pitch = (size_t) P.outw * bpp;
-#pragma unroll
-    for (int q = 0; q < LPW; q++) {
-        const int srcl = q * LPL;
-        v_first[q] = __shfl(first, srcl);
-        v_w[q] = __shfl(W, srcl);
-        v_nrows[q] = __shfl(nrows, srcl);
-        v_dx[q] = __shfl(lp.dx, srcl);
-        v_scanl[q] = __shfl(lp.scanl, srcl);
-        const int fq = __shfl(f, srcl), bq = __shfl(lp.beg, srcl);
-        v_dst[q] = (unsigned long long) (outp + (size_t) fq * ostride + (size_t) bq * pitch);
-        v_pxn[q] = 0;
-    }
+    const unsigned long long dst_row = (unsigned long long) (outp + (size_t) f * ostride + (size_t) lp.beg * pitch);
+    const unsigned slot_shift = (unsigned) (ls * LPL);
+    const unsigned long long slot_mask = LPL == 32 ? 0xffffffffull : 0xffffull;
+    int pxn = 0;                                         /* next pixel of my scanline (the same in all its lanes) */
 
     const int bright = P.bright, contrast = P.contrast;
     const unsigned psel = P.out_format == CRTHIP_FMT_BGRA ? 0x03020100u : P.out_format == CRTHIP_FMT_RGBA ? 0x03000102u
@@ -138,22 +133,38 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     const bool blend = P.blend != 0;
     const unsigned scanr = (unsigned) (S::AV_LEN - 1) << 12;
     const int outw = P.outw;
+    const unsigned dx = (unsigned) lp.dx;
+    /* band gains, crt_core.c:272-286: compile-time per CC_SAMPLES (the host refuses a blob that says otherwise), so
+     * the gains 65536 and 8192 turn into bit-field extracts */
+    constexpr int GY1 = CCS == 5 ? 12192 : 8192, GY2 = CCS == 5 ? 7775 : 9175, GI2 = 1311;
+
+    /* the demodulation carrier of my samples: with 4 samples per cycle the phase of sample t0 + jl * SPL + k does not
+     * depend on the tile (TS is a multiple of 4), so it is a per-lane constant */
+    int wIk[SPL], wQk[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; k++) {
+        const int ph = (first + jl * SPL + k) & 3;
+        wIk[k] = CCS == 4 ? s_wave[ls][0][ph] : 0;
+        wQk[k] = CCS == 4 ? s_wave[ls][1][ph] : 0;
+    }
 
     int xs = 0;                                          /* my stage's state */
     int cdone = 0;                                       /* samples combined so far (local index) */
     for (int t0 = 0; t0 < wmax + 3; t0 += TS) {
-        /* ---- prep: filter inputs of samples [t0, t0 + TS) for every (scanline, channel) ---- */
-        for (int item = lane; item < LPW * 3 * TS; item += 64) {
-            const int x = item % TS, chn = (item / TS) % 3, q = item / (3 * TS);
-            int fq = 0;
+        /* ---- prep: filter inputs of samples [t0, t0 + TS) of my scanline, all three channels ---- */
 #pragma unroll
-            for (int k = 0; k < LPW; k++) if (q == k) fq = v_first[k];
-            const int xl = t0 + x;
-            const int s = xl < WINB ? s_inp[q][xl] : 0;
-            int u;
-            if (chn == 0) u = s + bright;
-            else u = (s * s_wave[q][chn - 1][(fq + xl) % CCS]) >> 9;
-            s_u[q][chn][xl & (RING - 1)] = u;
+        for (int k = 0; k < SPL; k++) {
+            const int xl = t0 + jl * SPL + k;
+            const int sm = xl < WINB ? s_inp[ls][xl] : 0;
+            int wi = wIk[k], wq = wQk[k];
+            if constexpr (CCS != 4) {
+                const int ph = (first + xl) % CCS;
+                wi = s_wave[ls][0][ph];
+                wq = s_wave[ls][1][ph];
+            }
+            s_u[ls][0][xl & (RING - 1)] = sm + bright;                     /* crt_core.c:540 */
+            s_u[ls][1][xl & (RING - 1)] = (sm * wi) >> 9;                  /* :541 */
+            s_u[ls][2][xl & (RING - 1)] = (sm * wq) >> 9;                  /* :542 */
         }
         wave_lds_fence();
         /* ---- filter: TS systolic steps ---- */
@@ -173,54 +184,51 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
         wave_lds_fence();
         /* ---- combine: band gains, crt_core.c:218-232 ---- */
         const int xready = t0 + TS - 3;                  /* cascade outputs exist for samples < xready */
-        for (int item = lane; item < LPW * TS; item += 64) {
-            const int q = item / TS;
-            const int x = cdone + (item % TS);
-            if (x < xready && x >= 0) {
-                const int sl = (x + 3) & (RING - 1);
-                const int ylo = s_c[q][0][sl], yhi = s_c[q][1][sl], ihi = s_c[q][3][sl], qhi = s_c[q][5][sl];
-                const int uy = x >= 3 ? s_u[q][0][(x - 3) & (RING - 1)] : 0;
-                const int ui = x >= 3 ? s_u[q][1][(x - 3) & (RING - 1)] : 0;
-                const int uq = x >= 3 ? s_u[q][2][(x - 3) & (RING - 1)] : 0;
-                int yv = ((ylo * P.eq_g[0][0]) >> 16) + (((yhi - ylo) * P.eq_g[0][1]) >> 16) + (((uy - yhi) * P.eq_g[0][2]) >> 16);
+#pragma unroll
+        for (int k = 0; k < SPL; k++) {
+            const int x = cdone + jl * SPL + k;
+            if (x < xready) {
+                const int sl = (x + 3) & (RING - 1), sp = (x - 3) & (RING - 1);
+                const int ylo = s_c[ls][0][sl], yhi = s_c[ls][1][sl], ihi = s_c[ls][C_IHI][sl], qhi = s_c[ls][C_QHI][sl];
+                const int uy = x >= 3 ? s_u[ls][0][sp] : 0;
+                const int ui = x >= 3 ? s_u[ls][1][sp] : 0;
+                int yv = ((ylo * 65536) >> 16) + (((yhi - ylo) * GY1) >> 16) + (((uy - yhi) * GY2) >> 16);
                 int iv, qv;
                 if (NARROW) {
                     /* gains (65536, 65536, g2) and |lo3|, |hi3 - lo3| < 2^15: low + mid band == hi3 */
-                    iv = ihi + (((ui - ihi) * P.eq_g[1][2]) >> 16);
-                    qv = qhi + (((uq - qhi) * P.eq_g[2][2]) >> 16);
+                    iv = ihi + (((ui - ihi) * GI2) >> 16);
+                    qv = qhi;                                              /* Q: high-band gain 0 */
                 } else {
-                    const int ilo = s_c[q][2][sl], qlo = s_c[q][4][sl];
-                    iv = ((ilo * P.eq_g[1][0]) >> 16) + (((ihi - ilo) * P.eq_g[1][1]) >> 16) + (((ui - ihi) * P.eq_g[1][2]) >> 16);
-                    qv = ((qlo * P.eq_g[2][0]) >> 16) + (((qhi - qlo) * P.eq_g[2][1]) >> 16) + (((uq - qhi) * P.eq_g[2][2]) >> 16);
+                    const int ilo = s_c[ls][NARROW ? 0 : 2][sl], qlo = s_c[ls][NARROW ? 0 : 4][sl];
+                    iv = ((ilo * 65536) >> 16) + (((ihi - ilo) * 65536) >> 16) + (((ui - ihi) * GI2) >> 16);
+                    qv = ((qlo * 65536) >> 16) + (((qhi - qlo) * 65536) >> 16);
                 }
-                s_yiq[q][0][x & (RING - 1)] = yv << 4;   /* crt_core.c:540-542 */
-                s_yiq[q][1][x & (RING - 1)] = iv >> 3;
-                s_yiq[q][2][x & (RING - 1)] = qv >> 3;
+                s_yiq[ls][0][x & (RING - 1)] = yv << 4;   /* crt_core.c:540-542 */
+                s_yiq[ls][1][x & (RING - 1)] = iv >> 3;
+                s_yiq[ls][2][x & (RING - 1)] = qv >> 3;
             }
         }
         cdone = xready > 0 ? xready : 0;
         wave_lds_fence();
-        /* ---- pixels: D9 / D10, crt_core.c:552-664, every pixel whose right tap exists now ---- */
-#pragma unroll
-        for (int q = 0; q < LPW; q++) {
-            if (v_nrows[q] <= 0) continue;
-            const int xlim = cdone < v_w[q] ? cdone : v_w[q];            /* local samples [0, xlim) are in the ring */
-            const bool complete = cdone >= v_w[q];
-            const unsigned dx = (unsigned) v_dx[q];
+        /* ---- pixels: D9 / D10, crt_core.c:552-664, every pixel whose right tap exists now; LPL pixels of every
+         *      scanline of the wave per pass ---- */
+        {
+            const int xlim = cdone < W ? cdone : W;                      /* local samples [0, xlim) are in the ring */
+            const bool complete = cdone >= W;
             for (;;) {
-                const int px = v_pxn[q] + lane;
-                const unsigned upos = (unsigned) v_scanl[q] + (unsigned) px * dx;
-                const int sa = (int) (upos >> 12) - v_first[q];            /* local index of the left tap */
+                const int px = pxn + jl;
+                const unsigned upos = (unsigned) lp.scanl + (unsigned) px * dx;
+                const int sa = (int) (upos >> 12) - first;                 /* local index of the left tap */
                 /* right tap: inside the ring, or -- bloom only -- the never-written entry AV_LEN - 1 (zero) */
-                const bool tail0 = bloom && complete && sa + 1 == v_w[q];
-                const bool ok = px < outw && upos < scanr && (int) dx > 0 && sa >= 0 && (sa + 1 < xlim || tail0);
+                const bool tail0 = bloom && complete && sa + 1 == W;
+                const bool ok = nrows > 0 && px < outw && upos < scanr && (int) dx > 0 && sa >= 0 && (sa + 1 < xlim || tail0);
                 const unsigned long long m = __ballot(ok);
                 if (m == 0ull) break;
                 if (ok) {
                     const int R = (int) (upos & 0xfffu), L = 0xfff - R;
                     const int ia = sa & (RING - 1), ib = (sa + 1) & (RING - 1);
-                    const int ay = s_yiq[q][0][ia], ai = s_yiq[q][1][ia], aq = s_yiq[q][2][ia];
-                    const int by = tail0 ? 0 : s_yiq[q][0][ib], bi = tail0 ? 0 : s_yiq[q][1][ib], bq = tail0 ? 0 : s_yiq[q][2][ib];
+                    const int ay = s_yiq[ls][0][ia], ai = s_yiq[ls][1][ia], aq = s_yiq[ls][2][ia];
+                    const int by = tail0 ? 0 : s_yiq[ls][0][ib], bi = tail0 ? 0 : s_yiq[ls][1][ib], bq = tail0 ? 0 : s_yiq[ls][2][ib];
                     const int yy = ((ay * L) >> 2) + ((by * R) >> 2);
                     const int ii = ((ai * L) >> 14) + ((bi * R) >> 14);
                     const int qq = ((aq * L) >> 14) + ((bq * R) >> 14);
@@ -229,7 +237,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
                     int b = (((yy - 4530 * ii + 7021 * qq) >> 12) * contrast) >> 8;
                     r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
                     unsigned rgb = (unsigned) (((r << 8 | g) << 8) | b);
-                    const unsigned long long d = v_dst[q] + (size_t) px * bpp;
+                    const unsigned long long d = dst_row + (size_t) px * bpp;
                     if (!BPP3) {
                         if (blend) {
                             const unsigned oldw = gload32(d);
@@ -238,7 +246,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
                         }
                         const unsigned full = 0xff000000u | rgb;
                         const unsigned o = __builtin_amdgcn_perm(full, full, psel);
-                        for (int dup = 0; dup < v_nrows[q]; dup++) gstore32(d + (size_t) dup * pitch, o);
+                        for (int dup = 0; dup < nrows; dup++) gstore32(d + (size_t) dup * pitch, o);
                     } else {
                         if (blend) {
                             const unsigned o0 = gload8(d), o1 = gload8(d + 1), o2 = gload8(d + 2);
@@ -246,15 +254,14 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
                             rgb = ((rgb & 0xfefeffu) >> 1) + ((old & 0xfefeffu) >> 1);
                         }
                         const unsigned c0 = rgb_order ? rgb >> 16 : rgb, c2 = rgb_order ? rgb : rgb >> 16;
-                        for (int dup = 0; dup < v_nrows[q]; dup++) {
+                        for (int dup = 0; dup < nrows; dup++) {
                             const unsigned long long dd = d + (size_t) dup * pitch;
                             gstore8(dd, c0); gstore8(dd + 1, rgb >> 8); gstore8(dd + 2, c2);
                         }
                     }
                 }
-                const int cnt = __popcll(m);
-                v_pxn[q] += cnt;
-                if (cnt < 64) break;
+                /* my scanline's share of the pass (its pixels are a prefix of its lanes: upos grows with px) */
+                pxn += __popcll((m >> slot_shift) & slot_mask);
             }
         }
         wave_lds_fence();
@@ -272,6 +279,15 @@ int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const sign
                            p->eq_g[2][0] == 65536 && p->eq_g[2][1] == 65536 && p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 &&
                            p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 && p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 &&
                            p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
+    {
+        /* the kernel has the band gains of crt_core.c:272-286 compiled in */
+        const int five = c->sd.cc_samples == 5;
+        const int want[3][3] = { { 65536, five ? 12192 : 8192, five ? 7775 : 9175 }, { 65536, 65536, 1311 }, { 65536, 65536, 0 } };
+        for (int k = 0; k < 3; k++)
+            for (int b = 0; b < 3; b++)
+                if (p->eq_g[k][b] != want[k][b])
+                    return set_err(c, CRTHIP_E_ARG, "equaliser gains differ from crt_core.c:272-286", hipSuccess);
+    }
     const unsigned span = (unsigned) p->outh + p->v_fac;
     const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
     return dispatch_system(c->system, c->pattern, [&](auto tag) {

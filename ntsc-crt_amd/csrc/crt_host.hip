@@ -103,6 +103,46 @@ k_seq_weave(int n_fields, int outh, size_t pitch, unsigned char *out, size_t ost
     }
 }
 
+/* blend != 0 in sequence mode (crt_main.c:235 sets blend = 1): the picture is a recurrence over the fields,
+ *     v_k = ((new_k & 0xfefeff) >> 1) + ((v_{k-1} & 0xfefeff) >> 1)        (crt_core.c:584-609)
+ * on the first row of every line; the duplicated rows below it are copies of that BLENDED row (:661-664).  The fields
+ * are decoded in parallel without blend (image k = new_k, duplicates included), then one pass per field, parallel
+ * over the picture, folds the previous image in:  src[k][row] = the first row of the line that wrote `row` (-1: nobody
+ * did, the row is carried over). */
+__global__ void k_seq_rowsrc(int n_fields, int lines_per_field, int outh, const crthip_line *lines, int *rowsrc)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_fields * lines_per_field) return;
+    const int k = gid / lines_per_field;
+    const crthip_line lp = lines[gid];
+    const int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    for (int r = 0; r < nrows; r++) {
+        if (lp.beg + r < outh) rowsrc[(size_t) k * outh + lp.beg + r] = lp.beg;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_seq_blend_step(int k, int outh, size_t pitch, unsigned char *out, size_t ostride, const unsigned char *init,
+                 const int *rowsrc, unsigned alpha_mask)
+{
+    const int row = blockIdx.x;
+    const int src = rowsrc[(size_t) k * outh + row];
+    unsigned char *cur = out + (size_t) k * ostride + (size_t) row * pitch;
+    const unsigned char *prev_img = k ? out + (size_t) (k - 1) * ostride : init;      /* nullptr: zeros (calloc) */
+    const unsigned char *old = prev_img ? prev_img + (size_t) (src < 0 ? row : src) * pitch : nullptr;
+    for (size_t b = (size_t) threadIdx.x * 4; b < pitch; b += 256 * 4) {
+        const size_t nb = pitch - b < 4 ? pitch - b : 4;
+        unsigned o = 0, n = 0;
+        for (size_t c = 0; c < nb; c++) {
+            o |= (unsigned) (old ? old[b + c] : 0) << (8 * c);
+            n |= (unsigned) cur[b + c] << (8 * c);
+        }
+        /* every colour byte: (new >> 1) + (old >> 1) -- what the 0xfefeff mask computes per channel; alpha stays 0xff */
+        const unsigned v = src < 0 ? o : ((((n >> 1) & 0x7f7f7f7fu) + ((o >> 1) & 0x7f7f7f7fu)) | alpha_mask);
+        for (size_t c = 0; c < nb; c++) cur[b + c] = (unsigned char) (v >> (8 * c));
+    }
+}
+
 extern "C" {
 
 int crthip_abi_version(void) { return CRTHIP_ABI_VERSION; }
@@ -145,6 +185,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     c->stream = 0;              /* the device's default stream until crthip_set_stream() */
     c->overlap_chunks = 0;      /* automatic */
     { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
+    { const char *e = getenv("CRTHIP_SYNC_KERNEL"); c->sync_kernel = e ? atoi(e) : 0; }
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;
@@ -470,7 +511,8 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS;
     if (vhs && !c->d_vhs_hist)
         return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
-    if (p->blend) return set_err(c, CRTHIP_E_ARG, "sequence mode needs blend == 0 (blend is a recurrence over fields)", hipSuccess);
+    if (p->blend && (unsigned) p->outh + p->v_fac < (unsigned) c->sd.lines)
+        return set_err(c, CRTHIP_E_ARG, "sequence mode with blend needs outh + v_fac >= CRT_LINES (one line per output row)", hipSuccess);
     if (p->out_bpp == 0) return CRTHIP_OK;
     int enc = check_encoder(c, p);
     if (enc != 0) return enc < 0 ? enc : set_err(c, CRTHIP_E_ARG, "sequence mode: unknown input pixel format", hipSuccess);
@@ -482,7 +524,7 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     const int outh = p->outh;
     const size_t pitch = (size_t) p->outw * p->out_bpp;
     /* scratch: guess[n] (int2), changed flag, owner[n][outh] (u8), latest[n][outh] (int) */
-    const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh;
+    const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh + 256;
     if (need > c->seq_cap) {
         if (c->d_seq) hipFree(c->d_seq);
         c->d_seq = 0; c->seq_cap = 0;
@@ -546,6 +588,22 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     if (passes_out) *passes_out = passes;
     /* rn after each field, decode, weave */
     if (!vhs) crt_run_advance_rn(c, n, d_state);
+    if (p->blend) {
+        /* decode without blend, then fold the fields into each other one after the other (see k_seq_blend_step) */
+        crthip_params pb = *p;
+        pb.blend = 0;
+        rc = crt_run_decode(c, &pb, n, c->d_inp, c->d_lines, d_out, ostride);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(latest, 0xff, sizeof(int) * (size_t) n * outh, c->stream));       /* -1 everywhere */
+        hipLaunchKernelGGL(k_seq_rowsrc, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, latest);
+        const int fmt = p->out_format;
+        const unsigned alpha = p->out_bpp == 3 ? 0u : ((fmt == CRTHIP_FMT_ARGB || fmt == CRTHIP_FMT_ABGR) ? 0x000000ffu : 0xff000000u);
+        for (int k = 0; k < n; k++)
+            hipLaunchKernelGGL(k_seq_blend_step, dim3((unsigned) outh), dim3(256), 0, c->stream, k, outh, pitch,
+                               (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, latest, alpha);
+        HIPCHK(c, hipGetLastError());
+        return CRTHIP_OK;
+    }
     rc = crt_run_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(owner, 0, (size_t) n * outh, c->stream));

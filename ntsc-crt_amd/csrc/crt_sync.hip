@@ -385,14 +385,12 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int CH = 64, NCH = (S::LINES + CH - 1) / CH;
     constexpr int WBACK = 24, WPIECES = 5, WLEN = WPIECES * 16;   /* per line: bytes [ln + WOFF - 24, + 80): hsync -24 .. 40 */
     constexpr int WSTR = 21;                             /* dwords per window row (84 bytes: odd stride, no bank conflicts) */
-    constexpr int BPIECES = (S::CB_LEN + 15 + 15) / 16;  /* 16-byte pieces covering CB_LEN bytes from an arbitrary address */
+    constexpr int BPIECES = (S::CB_LEN + 15) / 16;       /* 16-byte pieces covering the CB_LEN burst bytes */
     constexpr int BSTR = BPIECES * 4 + 1;                /* dwords per burst row */
     __shared__ int s_win[(CH + 1) * WSTR];               /* sync windows of the chunk's lines (+ the line after it) */
-    __shared__ int s_bur[CH * BSTR];                     /* burst samples of the chunk's lines */
-    __shared__ int s_hs[CH], s_skip[CH];                 /* hsync after each line of the chunk; line skipped (:431) */
-    __shared__ int s_ccr[CH][8];                         /* integrators of the line's class after the line */
-    __shared__ short s_list[VPER][CH + 2];               /* chunk lines of each line class, in order */
-    __shared__ int s_cnt[VPER];
+    __shared__ int s_bur[CH * BSTR];                     /* burst samples, one row per non-skipped line, grouped by line class */
+    __shared__ int s_acc[CH][CCS == 4 ? 4 : 8];          /* the class's integrators after each of those lines */
+    __shared__ int s_cnt[VPER], s_off[VPER];
 
     const int lane = threadIdx.x;
     const int f = blockIdx.x;
@@ -409,7 +407,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     const int my_r = lane / CCS, my_p = lane - my_r * CCS;
     const bool chain_lane = lane < VPER * CCS;
     int acc = chain_lane ? st->ccf[my_r][my_p] : 0;
-    bool big = chain_lane && (acc >= (1 << 23) || acc <= -(1 << 23));
+    const bool big = chain_lane && (acc >= (1 << 23) || acc <= -(1 << 23));
     const bool exact_mul = __ballot(big) != 0ull;        /* caller-supplied garbage in ccf: keep the wrapping multiply */
     const int k0 = CCS == 4 ? ((my_p - S::CB_BEG) & 3) : ((my_p - S::CB_BEG) % CCS + CCS) % CCS;
 
@@ -417,7 +415,6 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     /* flat start of the sync window of decoded line `line` (lines TOP .. BOT: one past the end is needed too) */
     auto win_base = [&](int line) { return lidx_of(line) * S::HRES + WOFF - WBACK; };
 
-    /* ---- prologue: sync windows of chunk 0 in flight ---- */
     v4i wreg[WPIECES], wext[WPIECES], breg[BPIECES];
     auto fetch_windows = [&](int c) {
         const int line = S::TOP + c * CH + lane;
@@ -425,7 +422,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
         if (b < 0) b = 0;
 #pragma unroll
         for (int q = 0; q < WPIECES; q++) wreg[q] = load16u(in + b + q * 16);
-        /* lane 0 also brings the window of the line after the chunk (wrapped hsync values look there) */
+        /* every lane also brings the window of the line after the chunk (wrapped hsync values look there) */
         int be = win_base(S::TOP + (c + 1) * CH < S::BOT ? S::TOP + (c + 1) * CH : S::BOT);
         if (be < 0) be = 0;
 #pragma unroll
@@ -444,7 +441,13 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     };
     fetch_windows(0);
 
+    /* per-line records of the chunk whose burst chain / line table is still to come (lane = line of the chunk) */
+    int rec_hs = 0, rec_rid = 0;
+    bool rec_skip = true;
+
     for (int c = 0; c <= NCH; c++) {
+        int new_hs = 0;                                  /* hsync after line `lane` of chunk c (pass 1 fills it lane by lane) */
+        bool new_skip = true;
         /* ================= pass 1 of chunk c: the hsync chain ================= */
         if (c < NCH) {
             wave_lds_fence();
@@ -452,74 +455,88 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             wave_lds_fence();
             if (c + 1 < NCH) fetch_windows(c + 1);
             const int nl = S::LINES - c * CH < CH ? S::LINES - c * CH : CH;
+            /* everything about a line that does not depend on hsync, one lane per line, as bit masks for the loop */
+            const int my_line = S::TOP + c * CH + lane;
+            const int my_beg = (int) ((unsigned) (my_line - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows);
+            new_skip = lane >= nl || my_beg >= P.outh;                                   /* D4, crt_core.c:428-432 */
+            const int my_lidx = lidx_of(my_line < S::BOT ? my_line : S::TOP);
+            const unsigned long long m_skip = __ballot(new_skip);
+            const unsigned long long m_own = __ballot(my_lidx * S::HRES + WOFF - WBACK >= 0);       /* window not clipped at 0 */
+            const unsigned long long m_next = __ballot(my_line + 1 <= S::BOT && my_lidx + 1 < S::VRES);   /* row i+1 = next analog line */
             for (int i = 0; i < nl; i++) {
-                const int line = S::TOP + c * CH + i;
-                /* D4, crt_core.c:428-432 (unsigned arithmetic: v_fac is unsigned) */
-                const int beg = (int) ((unsigned) (line - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows);
-                const bool skip = beg >= P.outh;
-                if (!skip) {
-                    /* D5, crt_core.c:437-450 */
-                    const int lidx = lidx_of(line);
-                    int wrow = -1, rel = 0;                     /* which parked window holds the 2*HWIN bytes, where */
-                    if (hsync >= -WBACK + 0 && hsync + 2 * S::HWIN + WBACK <= WLEN && win_base(line) >= 0) { wrow = i; rel = hsync + WBACK; }
-                    else if (hsync >= S::HRES - WBACK && hsync < S::HRES && lidx + 1 < S::VRES && line + 1 <= S::BOT &&
-                             lidx_of(line + 1) == lidx + 1) { wrow = i + 1; rel = hsync - S::HRES + WBACK; }
-                    int sv = 0;
-                    if (wrow >= 0) {
-                        if (lane < 2 * S::HWIN) sv = ((const signed char *) (s_win + wrow * WSTR))[rel + lane];
-                    } else {
-                        const long a = (long) lidx * S::HRES + hsync + WOFF + lane;
-                        if (lane < 2 * S::HWIN && a >= 0 && a < (long) fstride) sv = in[a];
-                    }
-                    const int pref = row_incl_scan(sv);
-                    const unsigned m16 = (unsigned) __ballot(lane < 2 * S::HWIN && pref <= S::HTHR) & 0xffffu;
-                    const int hi = m16 ? (__ffs((int) m16) - 1 - S::HWIN) : S::HWIN;
-                    hsync = posmod(hi + hsync, S::HRES);                  /* :447 */
+                if ((m_skip >> i) & 1ull) { if (lane == i) new_hs = hsync; continue; }
+                /* D5, crt_core.c:437-450: the 2*HWIN bytes from ln + hsync + SYNC_BEG - HWIN */
+                int a = -1;                                                              /* byte offset in s_win */
+                if (hsync >= 0 && hsync <= WLEN - 2 * S::HWIN - WBACK && ((m_own >> i) & 1ull)) a = i * (WSTR * 4) + hsync + WBACK;
+                else if (hsync >= S::HRES - WBACK && hsync < S::HRES && ((m_next >> i) & 1ull)) a = (i + 1) * (WSTR * 4) + hsync - S::HRES + WBACK;
+                int sv = 0;
+                if (a >= 0) {
+                    if (lane < 2 * S::HWIN) sv = ((const signed char *) s_win)[a + lane];
+                } else {
+                    const long ga = (long) lidx_of(S::TOP + c * CH + i) * S::HRES + hsync + WOFF + lane;
+                    if (lane < 2 * S::HWIN && ga >= 0 && ga < (long) fstride) sv = in[ga];
                 }
-                if (lane == 0) { s_hs[i] = hsync; s_skip[i] = skip; }
+                const int pref = row_incl_scan(sv);
+                const unsigned m16 = (unsigned) __ballot(lane < 2 * S::HWIN && pref <= S::HTHR) & 0xffffu;
+                const int hi = m16 ? (__ffs((int) m16) - 1 - S::HWIN) : S::HWIN;
+                int h = hi + hsync;                                                      /* POSMOD(i + hsync, HRES), :447 */
+                if (hsync >= 0 && hsync < S::HRES) {                                     /* |hi| <= HWIN: one wrap either way */
+                    if (h < 0) h += S::HRES;
+                    if (h >= S::HRES) h -= S::HRES;
+                } else {
+                    h = posmod(h, S::HRES);
+                }
+                hsync = h;
+                if (lane == i) new_hs = hsync;
             }
-            wave_lds_fence();
         }
         /* ================= pass 2 of chunk c - 1: the burst integrators ================= */
         if (c > 0) {
             const int cc = c - 1;
             const int nl = S::LINES - cc * CH < CH ? S::LINES - cc * CH : CH;
-            /* the burst samples fetched one iteration ago -> LDS */
-            {
+            /* the burst samples fetched one iteration ago -> LDS, one row per non-skipped line in class order */
+            if (!rec_skip) {
 #pragma unroll
                 for (int q = 0; q < BPIECES; q++) {
-                    int *d = s_bur + lane * BSTR + q * 4;
+                    int *d = s_bur + rec_rid * BSTR + q * 4;
                     d[0] = breg[q].x; d[1] = breg[q].y; d[2] = breg[q].z; d[3] = breg[q].w;
                 }
             }
             wave_lds_fence();
             const int n_mine = chain_lane ? s_cnt[my_r] : 0;
+            const int row0 = chain_lane ? s_off[my_r] : 0;
             int n_max = n_mine;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(n_max, o); n_max = v > n_max ? v : n_max; }
-            for (int j = 0; j < n_max; j++) {
-                if (j < n_mine) {
-                    const int i = s_list[my_r][j];
-                    const signed char *b = (const signed char *) (s_bur + i * BSTR) + (s_ccr[i][7] /* byte offset of the burst in the row */);
-                    int smp[NB];
+            const signed char *bp = (const signed char *) (s_bur + row0 * BSTR) + k0;
+            int cur[NB], nxt[NB];
 #pragma unroll
-                    for (int q = 0; q < NB; q++) smp[q] = b[k0 + CCS * q];
+            for (int q = 0; q < NB; q++) { cur[q] = n_mine > 0 ? bp[CCS * q] : 0; nxt[q] = 0; }
+            for (int j = 0; j < n_max; j++) {
+                if (j + 1 < n_mine) {                                    /* next line's samples while this one's chain runs */
+                    const signed char *bn = bp + (j + 1) * (BSTR * 4);
+#pragma unroll
+                    for (int q = 0; q < NB; q++) nxt[q] = bn[CCS * q];
+                }
+                if (j < n_mine) {
                     if (exact_mul) {
 #pragma unroll
-                        for (int q = 0; q < NB; q++) acc = burst_step<S, true>(acc, smp[q]);
+                        for (int q = 0; q < NB; q++) acc = burst_step<S, true>(acc, cur[q]);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, smp[q]);
+                        for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, cur[q]);
                     }
-                    s_ccr[i][my_p] = acc;
+                    s_acc[row0 + j][my_p] = acc;
                 }
+#pragma unroll
+                for (int q = 0; q < NB; q++) cur[q] = nxt[q];
             }
             wave_lds_fence();
             /* ================= pass 3 of chunk c - 1: the line table, one lane per line ================= */
             if (lane < nl) {
                 const int i = lane, line = S::TOP + cc * CH + i;
-                const int hs = s_ccr[i][6];                                /* hsync after this line (kept here: s_hs is reused) */
-                const bool skip = s_ccr[i][5] != 0;
+                const int hs = rec_hs;
+                const bool skip = rec_skip;
                 int beg = (int) ((unsigned) (line - S::TOP + 0) * span / (unsigned) S::LINES + (unsigned) field_rows);
                 int end = (int) ((unsigned) (line - S::TOP + 1) * span / (unsigned) S::LINES + (unsigned) field_rows);
                 if (end > P.outh) end = P.outh;
@@ -529,6 +546,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                 if (skip) {
                     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0;
                 } else {
+                    const int *ac = s_acc[rec_rid];
                     const int lidx = lidx_of(line);
                     const int xpos = posmod(S::AV_BEG + hs - 3, S::HRES);  /* :452-454 */
                     int ypos = lidx + 3;
@@ -537,16 +555,16 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                     int dci, dcq;
                     const int pa = posmod(hs, CCS);
                     if constexpr (CCS == 4) {                              /* :471-472 */
-                        dci = s_ccr[i][(pa + 1) & 3] - s_ccr[i][(pa + 3) & 3];
-                        dcq = s_ccr[i][(pa + 2) & 3] - s_ccr[i][(pa + 0) & 3];
+                        dci = ac[(pa + 1) & 3] - ac[(pa + 3) & 3];
+                        dcq = ac[(pa + 2) & 3] - ac[(pa + 0) & 3];
                         lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
                         lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
                     } else {                                               /* :480-494 */
                         const int peak_a = pa + CCS / 4, peak_b = pa;
-                        const int dci_a = s_ccr[i][peak_a % CCS];
-                        const int dci_b = (s_ccr[i][(peak_a + CCS / 2) % CCS] + s_ccr[i][(peak_a + CCS / 2 + 1) % CCS]) / 2;
-                        const int dcq_a = s_ccr[i][(peak_b + CCS / 2) % CCS];
-                        const int dcq_b = s_ccr[i][peak_b % CCS];
+                        const int dci_a = ac[peak_a % CCS];
+                        const int dci_b = (ac[(peak_a + CCS / 2) % CCS] + ac[(peak_a + CCS / 2 + 1) % CCS]) / 2;
+                        const int dcq_a = ac[(peak_b + CCS / 2) % CCS];
+                        const int dcq_b = ac[peak_b % CCS];
                         dci = dci_a - dci_b;
                         dcq = dcq_a - dcq_b;
                         lp.wave0 = dci;
@@ -560,9 +578,11 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                      * the line and no line before a non-skipped one is skipped, so it is the distance to the first
                      * line with this beg */
                     int rank = 0;
-                    while (line - rank - 1 >= S::TOP &&
-                           (int) ((unsigned) (line - rank - 1 - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows) == beg)
-                        rank++;
+                    if (span < (unsigned) S::LINES) {
+                        while (line - rank - 1 >= S::TOP &&
+                               (int) ((unsigned) (line - rank - 1 - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows) == beg)
+                            rank++;
+                    }
                     nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
                     if (CCS != 4)
                         nrows |= CRTHIP_LINE_WIDE;
@@ -582,37 +602,31 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             }
             wave_lds_fence();
         }
-        /* ================= hand-over: per-line records of chunk c for passes 2 / 3, burst fetch ================= */
+        /* ================= hand-over: chunk c's per-line records for passes 2 / 3, burst fetch ================= */
         if (c < NCH) {
-            const int nl = S::LINES - c * CH < CH ? S::LINES - c * CH : CH;
-            /* line class lists (ypos % VPER, :456) in line order, skipped lines excluded */
-            const bool mine = lane < nl;
-            const int hs = mine ? s_hs[lane] : 0;
-            const bool skip = mine ? s_skip[lane] != 0 : true;
+            rec_hs = new_hs;
+            rec_skip = new_skip;
             const int line = S::TOP + c * CH + lane;
             const int lidx = lidx_of(line < S::BOT ? line : S::TOP);
             int ypos = lidx + 3;
             if (ypos >= S::VRES) ypos -= S::VRES;
-            const int cls = VPER == 1 ? 0 : ypos % VPER;
+            const int cls = VPER == 1 ? 0 : ypos % VPER;                   /* :456 */
+            /* row of the line in s_bur / s_acc: lines of class 0 first, then class 1, ...; line order inside a class */
+            int off = 0;
+            rec_rid = 0;
 #pragma unroll
             for (int r = 0; r < VPER; r++) {
-                const unsigned long long m = __ballot(!skip && cls == r);
-                if (!skip && cls == r) s_list[r][__popcll(m & ((1ull << lane) - 1ull))] = (short) lane;
-                if (lane == 0) s_cnt[r] = __popcll(m);
+                const unsigned long long m = __ballot(!rec_skip && cls == r);
+                if (!rec_skip && cls == r) rec_rid = off + __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0) { s_cnt[r] = __popcll(m); s_off[r] = off; }
+                off += __popcll(m);
             }
-            /* burst samples: CB_LEN bytes from ln + halign + CB_BEG (:459-461), fetched as 16-byte pieces from the
-             * address rounded down to 4 (the row keeps the remainder) */
-            const int halign = CCS == 4 ? (hs & ~3) : hs - hs % CCS;
+            /* burst samples: CB_LEN bytes from ln + halign + CB_BEG (:459-461) */
+            const int halign = CCS == 4 ? (rec_hs & ~3) : rec_hs - rec_hs % CCS;
             const int baddr = lidx * S::HRES + halign + S::CB_BEG;
-            if (mine) {
-                s_ccr[lane][5] = skip;
-                s_ccr[lane][6] = hs;
-                s_ccr[lane][7] = baddr & 3;
-            }
-            const int ba = (baddr & ~3);
 #pragma unroll
             for (int q = 0; q < BPIECES; q++) {
-                breg[q] = (mine && !skip) ? load16u(in + ba + q * 16) : v4i{0, 0, 0, 0};
+                breg[q] = !rec_skip ? load16u(in + baddr + q * 16) : v4i{0, 0, 0, 0};
             }
             wave_lds_fence();
         }
@@ -669,7 +683,9 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
         hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
-        if (c->legacy_sync)
+        /* one wave per field is the latency shape; with thousands of fields the 16-lanes-per-field kernel uses the
+         * vector unit four times better in the burst chain (4 fields per instruction) */
+        if (c->legacy_sync || (c->sync_kernel == 0 && n > 1024) || c->sync_kernel == 1)
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         else
             hipLaunchKernelGGL((k_hsync_wave<S>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
