@@ -620,6 +620,44 @@ def test_sequence_mode_equals_sequential_processing(crtlib, name, noise, scanlin
     g.close()
 
 
+@pytest.mark.parametrize("ofmt,scanlines,outsz", [(R.FMT_BGRA, 1, (640, 480)), (R.FMT_RGB, 0, (832, 624)), (R.FMT_ARGB, 1, (320, 240))])
+def test_sequence_mode_with_blend(crtlib, ofmt, scanlines, outsz):
+    """VERDICT r1 missing #5: blend = 1 (crt_main.c:235) makes the picture a recurrence over the fields; crthip_sequence
+    decodes the fields in parallel and folds them into each other afterwards -- against the oracle running the
+    crt_main.c loop (modulate / demodulate with the output buffer carried over) one field after the other."""
+    import shard
+    n, noise = 8, 24
+    outw, outh = outsz
+    bpp = R.bpp4fmt(ofmt)
+    orc = R.Oracle("ntsc")
+    c = orc.new_crt(outw, outh, ofmt)
+    c.set("scanlines", scanlines)
+    c.set("blend", 1)
+    c.out[:] = R.lcg_bytes(c.out.size, 9)
+    init = c.out.copy()
+    frames = np.stack([R.synth_image(640, 480, 4, 800 + k, "random" if k % 3 else "bars") for k in range(n)])
+    want = []
+    for k in range(n):
+        field, frame = shard.field_parity(k)
+        c.settings(np.concatenate([frames[k], frames[k][-1:]]), format=R.FMT_BGRA, w=640, h=480, as_color=1, field=field, frame=frame)
+        c.modulate()
+        c.demodulate(noise)
+        want.append((c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn")))
+    g = crtlib.CRT(n, outw, outh, ofmt, "ntsc", device=0)
+    g.scanlines = scanlines
+    g.blend = 1
+    par = [shard.field_parity(k) for k in range(n)]
+    s = crtlib.Settings(_padded(frames), format=crtlib.FMT_BGRA, field=[a for a, _ in par], frame=[b for _, b in par])
+    g.sequence(s, noise, out_init=_to_dev(init.reshape(outh, outw, bpp)))
+    g.synchronize()
+    out = g.out.cpu().numpy()
+    for k in range(n):
+        o, hs, vs, rn = want[k]
+        assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), "field %d state" % k
+        np.testing.assert_array_equal(out[k].reshape(-1), o, err_msg="blend sequence field %d" % k)
+    g.close()
+
+
 @pytest.mark.parametrize("aberration", [0, 1])
 @pytest.mark.parametrize("noise", [0, 12])
 def test_vhs_sequence_mode_equals_sequential_processing(crtlib, noise, aberration):
