@@ -303,6 +303,9 @@ void  crthip_free(crthip_ctx *ctx, void *d_ptr);
 int   crthip_upload(crthip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int   crthip_download(crthip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int   crthip_memset(crthip_ctx *ctx, void *d_dst, int value, size_t bytes);
+/* page-lock / release a host buffer so that crthip_upload / crthip_download to it run as direct DMA */
+int   crthip_host_register(crthip_ctx *ctx, void *h_ptr, size_t bytes);
+int   crthip_host_unregister(crthip_ctx *ctx, void *h_ptr);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,15 @@
  * would have written (analog[] and ccf after crt_modulate; inp[], the output image, ccf, hsync,
  * vsync, rn after crt_demodulate).  Device buffers are cached per `struct CRT *`.
  *
+ * CRTHIP_LAZY_MIRROR=1|2 (environment, opt-in -- SURVEY.md 8b "lazy mirror"): the device copies of analog[] and of the
+ * output image become authoritative between calls.  What the caller does NOT get any more: crt.analog after
+ * crt_modulate and crt.inp after crt_demodulate are not refreshed on the host (crt_main.c's -a dump needs the strict
+ * mode).  What stays safe: analog[] and the output image are re-uploaded whenever the host copy differs from what this
+ * layer last saw there -- judged by a hash of the buffer, sampled (1: every 16th 64-byte block + both ends: catches
+ * memset / repaint / a new picture, not a sparse edit) or complete (2) -- and the input image is re-uploaded unless
+ * pointer, geometry and hash are unchanged (crt_main.c modulates the same picture 8 times).  The caller's image and
+ * output buffers are page-locked on first sight (hipHostRegister) so that the remaining copies run as direct DMA.
+ *
  * Errors: the reference API is all-void and has no error channel.  A HIP failure or a missing
  * gfx950 device is reported on stderr and the process aborts -- there is no CPU fallback.
  */
@@ -59,9 +68,81 @@ struct slot {
     crthip_line *d_lines;
     unsigned char *d_img, *d_out;
     size_t img_cap, out_cap;
+    /* lazy mirror: what the host copies looked like when this layer last read or wrote them */
+    int analog_valid, out_valid, img_valid;
+    unsigned long analog_hash, out_hash, img_hash;
+    const void *img_ptr, *out_ptr, *pinned_img, *pinned_out;
+    size_t img_bytes, out_bytes, pinned_img_bytes, pinned_out_bytes;
 };
 
 static crthip_ctx *g_ctx;
+static int g_lazy = -1;             /* CRTHIP_LAZY_MIRROR: 0 strict (default), 1 sampled hashes, 2 full hashes */
+
+static int
+lazy_mode(void)
+{
+    if (g_lazy < 0) {
+        const char *e = getenv("CRTHIP_LAZY_MIRROR");
+        g_lazy = e ? atoi(e) : 0;
+        if (g_lazy < 0 || g_lazy > 2) {
+            g_lazy = 0;
+        }
+    }
+    return g_lazy;
+}
+
+/* 64-bit multiplicative hash of a buffer: all of it (mode 2) or every 16th 64-byte block plus both ends (mode 1) */
+static unsigned long
+buf_hash(const void *buf, size_t bytes, int mode)
+{
+    const unsigned long *w = (const unsigned long *) buf;
+    const unsigned char *b = (const unsigned char *) buf;
+    size_t nw = bytes / sizeof(unsigned long), i, k;
+    unsigned long h = 0x9e3779b97f4a7c15ul ^ (unsigned long) bytes;
+
+    if (((size_t) buf & (sizeof(unsigned long) - 1)) != 0) {
+        for (i = 0; i < bytes; i += (mode == 2 ? 1 : 61)) {       /* unaligned buffer: bytewise */
+            h = (h ^ b[i]) * 0x100000001b3ul;
+        }
+        return h;
+    }
+    if (mode == 2 || nw < 1024) {
+        for (i = 0; i < nw; i++) {
+            h = (h ^ w[i]) * 0x100000001b3ul;
+        }
+    } else {
+        for (i = 0; i + 8 <= nw; i += 128) {                     /* 8 words out of every 128 */
+            for (k = 0; k < 8; k++) {
+                h = (h ^ w[i + k]) * 0x100000001b3ul;
+            }
+        }
+        for (i = nw - 32; i < nw; i++) {
+            h = (h ^ w[i]) * 0x100000001b3ul;
+        }
+    }
+    for (i = nw * sizeof(unsigned long); i < bytes; i++) {
+        h = (h ^ b[i]) * 0x100000001b3ul;
+    }
+    return h;
+}
+
+/* page-lock a caller buffer once (best effort: a failure only means staged copies) */
+static void
+pin_buffer(const void **pinned, size_t *pinned_bytes, const void *ptr, size_t bytes)
+{
+    if (*pinned == ptr && *pinned_bytes == bytes) {
+        return;
+    }
+    if (*pinned) {
+        crthip_host_unregister(g_ctx, (void *) *pinned);
+    }
+    *pinned = 0;
+    *pinned_bytes = 0;
+    if (crthip_host_register(g_ctx, (void *) ptr, bytes) == CRTHIP_OK) {
+        *pinned = ptr;
+        *pinned_bytes = bytes;
+    }
+}
 static struct slot g_slots[MAX_SLOTS];
 static size_t g_fstride;
 
@@ -115,6 +196,7 @@ get_slot(struct CRT *v)
         free_slot = &g_slots[0];
     }
     free_slot->host = v;
+    free_slot->analog_valid = free_slot->out_valid = free_slot->img_valid = 0;
     if (free_slot->d_analog == 0) {
         free_slot->d_analog = (signed char *) dev_alloc(g_fstride + 4096);
         free_slot->d_inp = (signed char *) dev_alloc(g_fstride + 4096);
@@ -269,6 +351,23 @@ write_libc_rand(int *lib, const unsigned hist[31])
 }
 #endif
 
+/* analog[] before a kernel reads it: strict mode uploads the caller's copy every time; lazy mode only when the caller's
+ * copy is not what this layer last saw there (memset(crt.analog, 0, ...) of the live driver, crt_init, a fresh struct) */
+static void
+sync_analog_to_device(struct slot *sl, const struct CRT *v)
+{
+    const int lazy = lazy_mode();
+    if (lazy) {
+        const unsigned long h = buf_hash(v->analog, CRT_INPUT_SIZE, lazy);
+        if (sl->analog_valid && sl->analog_hash == h) {
+            return;
+        }
+        sl->analog_hash = h;
+        sl->analog_valid = 1;
+    }
+    CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
+}
+
 /* ---- public API ---------------------------------------------------------------------------- */
 
 extern int
@@ -397,15 +496,34 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
      * the reference's drivers see in practice (crt_main.c -r; tests/test_gpu_dropin.py) -- re-zeroed on every call. */
     {
         const size_t row_bytes = img_bytes / (size_t) s->h;
-        ensure(&sl->d_img, &sl->img_cap, img_bytes + row_bytes + 256);
-        CHECK(crthip_upload(g_ctx, sl->d_img, s->data, img_bytes));
-        CHECK(crthip_memset(g_ctx, sl->d_img + img_bytes, 0, row_bytes));
+        const int lazy = lazy_mode();
+        unsigned long h = 0;
+        int same = 0;
+        if (lazy) {
+            h = buf_hash(s->data, img_bytes, lazy);
+            same = sl->img_valid && sl->img_ptr == (const void *) s->data && sl->img_bytes == img_bytes && sl->img_hash == h &&
+                   sl->img_cap >= img_bytes + row_bytes + 256;
+            if (!same) {
+                pin_buffer(&sl->pinned_img, &sl->pinned_img_bytes, s->data, img_bytes);
+            }
+        }
+        if (!same) {
+            ensure(&sl->d_img, &sl->img_cap, img_bytes + row_bytes + 256);
+            CHECK(crthip_upload(g_ctx, sl->d_img, s->data, img_bytes));
+            CHECK(crthip_memset(g_ctx, sl->d_img + img_bytes, 0, row_bytes));
+            sl->img_valid = lazy != 0;
+            sl->img_ptr = s->data;
+            sl->img_bytes = img_bytes;
+            sl->img_hash = h;
+        }
         p.flags |= CRTHIP_F_IMAGE_SPARE_ROW;
     }
-    CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
+    sync_analog_to_device(sl, v);
     state_to_device(sl, v, field, frame, aux);
     CHECK(crthip_modulate(g_ctx, &p, 1, sl->d_img, 0, sl->d_analog, sl->d_state));
-    CHECK(crthip_download(g_ctx, v->analog, sl->d_analog, CRT_INPUT_SIZE));
+    if (!lazy_mode()) {
+        CHECK(crthip_download(g_ctx, v->analog, sl->d_analog, CRT_INPUT_SIZE));
+    }
     state_from_device(sl, v, 0);
     unpark_libc_rand(lib);
 }
@@ -433,9 +551,22 @@ crt_demodulate(struct CRT *v, int noise)
     lib = park_libc_rand();
     sl = get_slot(v);
     out_bytes = (size_t) v->outw * (size_t) v->outh * (size_t) bpp;
-    ensure(&sl->d_out, &sl->out_cap, out_bytes + 256);
-    CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
-    CHECK(crthip_upload(g_ctx, sl->d_out, v->out, out_bytes));
+    {
+        const int lazy = lazy_mode();
+        int same = 0;
+        if (lazy) {
+            same = sl->out_valid && sl->out_ptr == (const void *) v->out && sl->out_bytes == out_bytes &&
+                   sl->out_cap >= out_bytes + 256 && sl->out_hash == buf_hash(v->out, out_bytes, lazy);
+            if (!same) {
+                pin_buffer(&sl->pinned_out, &sl->pinned_out_bytes, v->out, out_bytes);
+            }
+        }
+        ensure(&sl->d_out, &sl->out_cap, out_bytes + 256);
+        sync_analog_to_device(sl, v);
+        if (!same) {
+            CHECK(crthip_upload(g_ctx, sl->d_out, v->out, out_bytes));
+        }
+    }
     state_to_device(sl, v, 0, 0, 0);
 #if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
     {
@@ -455,8 +586,16 @@ crt_demodulate(struct CRT *v, int noise)
 #endif
     CHECK(crthip_sync(g_ctx, &p, 1, sl->d_inp, sl->d_state, sl->d_lines));
     CHECK(crthip_decode(g_ctx, &p, 1, sl->d_inp, sl->d_lines, sl->d_out, out_bytes));
-    CHECK(crthip_download(g_ctx, v->inp, sl->d_inp, CRT_INPUT_SIZE));
+    if (!lazy_mode()) {
+        CHECK(crthip_download(g_ctx, v->inp, sl->d_inp, CRT_INPUT_SIZE));
+    }
     CHECK(crthip_download(g_ctx, v->out, sl->d_out, out_bytes));
+    if (lazy_mode()) {
+        sl->out_valid = 1;
+        sl->out_ptr = v->out;
+        sl->out_bytes = out_bytes;
+        sl->out_hash = buf_hash(v->out, out_bytes, lazy_mode());
+    }
     state_from_device(sl, v, 1);
     unpark_libc_rand(lib);
 }

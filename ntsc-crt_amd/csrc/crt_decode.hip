@@ -399,10 +399,6 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
     return c->no_loskip ? 1 : 0;
 }
 
-/* fields per launch below which the scanline-parallel shape (crt_decode2.hip) is used: lane-per-scanline needs
- * n * 240 / 64 wavefronts >= a few per SIMD (1024 SIMDs) to hide its 60-instruction-per-sample serial chains */
-#define ROWS_SHAPE_MAX_FIELDS 256
-
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride)
 {

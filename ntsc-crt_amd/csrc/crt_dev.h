@@ -289,6 +289,11 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
     return rn;
 }
 
+/* fields per launch up to which the scanline-parallel kernel shape (k_active_row, k_decode_row) is chosen automatically:
+ * lane-per-scanline needs n * 240 / 64 wavefronts >= a few per SIMD (1024 SIMDs) to hide its serial chains; measured
+ * crossover of the decoders between 128 and 256 fields (profiles/r02_shape_sweep.txt) */
+#define ROWS_SHAPE_MAX_FIELDS 128
+
 /* sizes shared between kernels and the context */
 #define NES_TAB_SIZE (512 * 12)            /* NES composite-sample table: 9-bit pixel x phase mod 12 */
 #define SKEL_VARIANTS 12                   /* cached clean skeleton fields (k_skeleton): (field, frame) or field x dot_crawl_offset */

@@ -429,6 +429,161 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
 }
 
 /* ------------------------------------------------------------------------- */
+/* M5 in the scanline-parallel shape (small batches)                           */
+/* ------------------------------------------------------------------------- */
+/* k_active gives a destination row to ONE lane, which walks its 753 samples with ~45 vector instructions each: a single
+ * field is 4 waves and 0.15 ms however empty the chip is.  Here a wave takes R = 8 rows and cuts the work by kind, in
+ * tiles of 64 samples:
+ *   A  pixel fetch + RGB -> YIQ for (row, sample): fully parallel, 64 lanes = the 64 samples of one row at a time
+ *   B  the three one-pole low-passes (crt_ntsc.c:117-126): the only serial part; lane = (row, channel), 24 lanes,
+ *      64 steps of 4 instructions per tile, operands from / to LDS
+ *   C  modulate, scale, clamp, + noise, pack: fully parallel, a lane takes 4 consecutive samples (one dword store)
+ * so a field is 30 waves and the serial chain per wave is 753 x 4 instructions.  Same arithmetic, exact 32-bit
+ * multiplies throughout.  RGB-input systems only (the NES's table encoder is cheap as it is). */
+template <class S, bool NOISE, bool CLAMP>
+__global__ void __launch_bounds__(64)
+k_active_row(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
+             signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
+             const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1)
+{
+    constexpr int R = 8, TS = 64, CCS = S::CCS;
+    __shared__ int s_f[R][3][TS + 1];                    /* YIQ of the tile, then (in place) the low-passed values */
+
+    const int lane = threadIdx.x;
+    const int rows = P.desth, total = n_fields * rows;
+    const int w = P.w, destw = P.destw, in_bpp = P.in_bpp;
+    const unsigned isel = input_selector(P.format);
+
+    /* the wave's rows: global row g0 + r.  Per-lane copies for the phases' lane -> row mappings */
+    const int g0 = blockIdx.x * R;
+    auto row_info = [&](int r, int &f, int &y, bool &live) {
+        const int gid = g0 + r;
+        live = gid < total;
+        f = live ? gid / rows : 0;
+        y = live ? gid - f * rows : 0;
+    };
+
+    /* phase B role: lane = 3 * row + channel */
+    const int b_row = lane / 3, b_ch = lane - b_row * 3;
+    const bool b_lane = lane < 3 * R;
+    const int b_coef = b_ch == 0 ? P.iir_c[0] : b_ch == 1 ? P.iir_c[1] : P.iir_c[2];
+    int hstate = 0;
+
+    /* phase C role: 16 lanes per row, 4 rows per pass, R / 4 passes; per pass the row's constants */
+    constexpr int CP = R / 4;
+    const int c_rp = lane >> 4, c_j = lane & 15;
+    int c_live[CP], c_start[CP], c_cI[CP][CCS], c_cQ[CP][CCS];
+    unsigned c_rn0[CP];
+    unsigned long long c_dst[CP];
+#pragma unroll
+    for (int ps = 0; ps < CP; ps++) {
+        int f, y; bool live;
+        row_info(ps * 4 + c_rp, f, y, live);
+        const crthip_state st = state[f];
+        c_live[ps] = live;
+        c_start[ps] = (y + P.yo) * S::HRES + P.xo;
+        c_dst[ps] = (unsigned long long) (dst + (size_t) f * fstride + c_start[ps]);
+        c_rn0[ps] = (unsigned) st.rn;
+        const int crow = carrier_row<S>(y + P.yo, st.field, st.frame, st.aux);
+#pragma unroll
+        for (int k = 0; k < CCS; k++) { c_cI[ps][k] = P.modI[crow][k]; c_cQ[ps][k] = P.modQ[crow][k]; }
+    }
+    /* phase A: source row pointers of all R rows (wave-uniform values, computed by every lane) */
+    unsigned long long a_src[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int f, y; bool live;
+        row_info(r, f, y, live);
+        const int field = live ? state[f].field & 1 : 0;
+        const int sy = source_row<S>(P, y, field);
+        a_src[r] = (unsigned long long) (images + (size_t) f * istride + (size_t) sy * w * in_bpp);
+    }
+    const int white = P.white, ire_base = P.ire_base, noise = P.noise;
+
+    for (int t0 = 0; t0 < destw; t0 += TS) {
+        /* ---- A: fetch + convert, lane = sample t0 + lane of every row ---- */
+        {
+            const int x = t0 + lane;
+            const int col = x < destw ? (int) ((unsigned) x * (unsigned) w / (unsigned) destw) : 0;   /* crt_ntsc.c:276 */
+            unsigned px[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned long long a = a_src[r] + (size_t) col * in_bpp;
+                if (in_bpp == 4) px[r] = gload32(a);
+                else px[r] = gload8(a) | gload8(a + 1) << 8 | gload8(a + 2) << 16;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned rgb = __builtin_amdgcn_perm(px[r], px[r], isel);
+                const int rr = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, bb = rgb & 255;
+                s_f[r][0][lane] = (19595 * rr + 38470 * gg + 7471 * bb) >> 14;
+                s_f[r][1][lane] = (39059 * rr - 18022 * gg - 21103 * bb) >> 14;
+                s_f[r][2][lane] = (13894 * rr - 34275 * gg + 20382 * bb) >> 14;
+            }
+        }
+        wave_lds_fence();
+        /* ---- B: the low-passes, lane = (row, channel) ---- */
+        if (S::BANDLIMIT) {
+            if (b_lane) {
+                int *fp = &s_f[b_row][b_ch][0];
+#pragma unroll 1
+                for (int h0 = 0; h0 < TS; h0 += 16) {
+                    int v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) v[k] = fp[h0 + k];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        hstate += ((v[k] - hstate) * b_coef) >> 11;                /* iirf, crt_ntsc.c:117-126 */
+                        v[k] = hstate;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; k++) fp[h0 + k] = v[k];
+                }
+            }
+            wave_lds_fence();
+        }
+        /* ---- C: modulate + noise + store, lane = 4 consecutive samples of one of 4 rows ---- */
+#pragma unroll
+        for (int ps = 0; ps < CP; ps++) {
+            const int r = ps * 4 + c_rp;
+            const int x0 = t0 + 4 * c_j;
+            unsigned rn = 0;
+            if (NOISE) {
+                const int idx = c_start[ps] + x0;
+                const uint2 j = jump16[idx >> 4], q = jump1[idx & 15];
+                rn = q.x * (j.x * c_rn0[ps] + j.y) + q.y;
+            }
+            int smp[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xl = 4 * c_j + k;
+                const int hy = s_f[r][0][xl], hi = s_f[r][1][xl], hq = s_f[r][2][xl];
+                const int ph = CCS == 4 ? k : (x0 + k) % CCS;      /* xo is a multiple of CCS: phase (x + xo) % CCS == x % CCS */
+                int ccI = c_cI[ps][0], ccQ = c_cQ[ps][0];
+#pragma unroll
+                for (int m = 1; m < CCS; m++) if (ph == m) { ccI = c_cI[ps][m]; ccQ = c_cQ[ps][m]; }
+                const int mi = (hi * ccI) >> 4, mq = (hq * ccQ) >> 4;
+                int ire = ire_base + (((hy + mi + mq) * white) >> 10);
+                ire = clampi(ire, 0, 110);
+                if (NOISE) { rn = lcg_step(rn); ire = noisy(ire, rn, noise); }
+                else if (CLAMP) ire = clampi(ire, -127, 127);
+                smp[k] = ire;
+            }
+            if (c_live[ps] && x0 < destw) {
+                const unsigned long long d = c_dst[ps] + x0;
+                if (x0 + 4 <= destw) {
+                    gstore32(d, pack4(smp[0], smp[1], smp[2], smp[3]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (x0 + k < destw) gstore8(d + k, (unsigned) smp[k]);
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* M5, NES flavour (crt_nes.c:162-193) with a lookup table                     */
 /* ------------------------------------------------------------------------- */
 /* A composite sample of the NES is  ((BLACK + black_point + sum_{k<4} square(p, phase+k)) * white_point / 100) >> 12
@@ -683,8 +838,17 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
             return;
         }
     }
-    const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
     const bool noise = FULL && p->noise != 0;
+    if constexpr (!S::IS_NES) {
+        /* kernel shape (crthip_set_shape): small batches take the scanline-parallel encoder */
+        if (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS)) {
+            const dim3 rgrid((total + 7) / 8);
+            if (noise) hipLaunchKernelGGL((k_active_row<S, true, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_jump1);
+            else hipLaunchKernelGGL((k_active_row<S, false, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_jump1);
+            return;
+        }
+    }
+    const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
     const bool wide_in = c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
     do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \

@@ -703,6 +703,26 @@ int crthip_download(crthip_ctx *c, void *h, const void *d, size_t bytes)
     return CRTHIP_OK;
 }
 
+int crthip_host_register(crthip_ctx *c, void *h, size_t bytes)
+{
+    if (!c || !h || !bytes) return CRTHIP_E_ARG;
+    if (hipHostRegister(h, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        return CRTHIP_E_HIP;
+    }
+    return CRTHIP_OK;
+}
+
+int crthip_host_unregister(crthip_ctx *c, void *h)
+{
+    if (!c || !h) return CRTHIP_E_ARG;
+    if (hipHostUnregister(h) != hipSuccess) {
+        (void) hipGetLastError();
+        return CRTHIP_E_HIP;
+    }
+    return CRTHIP_OK;
+}
+
 int crthip_memset(crthip_ctx *c, void *d, int value, size_t bytes)
 {
     if (!c) return CRTHIP_E_ARG;

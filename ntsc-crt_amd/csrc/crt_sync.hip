@@ -683,9 +683,9 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
         hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
-        /* one wave per field is the latency shape; with thousands of fields the 16-lanes-per-field kernel uses the
-         * vector unit four times better in the burst chain (4 fields per instruction) */
-        if (c->legacy_sync || (c->sync_kernel == 0 && n > 1024) || c->sync_kernel == 1)
+        /* k_hsync (16 lanes per field) is kept for A/B measurements (CRTHIP_SYNC_KERNEL=1): the wave-per-field kernel
+         * is faster at every batch size measured (profiles/r02_sync_kernels.txt) */
+        if (c->legacy_sync || c->sync_kernel == 1)
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         else
             hipLaunchKernelGGL((k_hsync_wave<S>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
