@@ -407,10 +407,17 @@ crt_reset(struct CRT *v)
 extern void
 crt_init(struct CRT *v, int w, int h, int f, unsigned char *out)
 {
+    int i;
+
     memset(v, 0, sizeof(struct CRT));
     crt_resize(v, w, h, f, out);
     crt_reset(v);
     v->rn = 194;
+    for (i = 0; i < MAX_SLOTS; i++) {           /* lazy mirror: a re-initialised set starts from its host copies again */
+        if (g_slots[i].host == v) {
+            g_slots[i].analog_valid = g_slots[i].out_valid = 0;
+        }
+    }
     /* the equaliser coefficients the reference sets up here are derived per call on the host
      * (crthip_params_finalize); nothing else to do until the first modulate / demodulate */
 }

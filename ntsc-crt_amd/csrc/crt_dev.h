@@ -294,6 +294,8 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * crossover of the decoders between 128 and 256 fields (profiles/r02_shape_sweep.txt) */
 #define ROWS_SHAPE_MAX_FIELDS 128
 
+#define CRTHIP_MAX_CHUNKS 64               /* crthip_set_overlap */
+
 /* sizes shared between kernels and the context */
 #define NES_TAB_SIZE (512 * 12)            /* NES composite-sample table: 9-bit pixel x phase mod 12 */
 #define SKEL_VARIANTS 12                   /* cached clean skeleton fields (k_skeleton): (field, frame) or field x dot_crawl_offset */
@@ -346,7 +348,7 @@ struct crthip_ctx {
     int ac_tile;                /* encoder tile, same convention, by input width */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
-    hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_fork, ev_join, ev_chunk[CRTHIP_MAX_CHUNKS];
     bool prof;
     double prof_ms[CRTHIP_K_COUNT];
     int prof_n[CRTHIP_K_COUNT];

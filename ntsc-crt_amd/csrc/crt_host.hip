@@ -255,7 +255,10 @@ void crthip_destroy(crthip_ctx *c)
     hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->npend; i++) { hipEventDestroy(c->pend[i].a); hipEventDestroy(c->pend[i].b); }
     free(c->pend);
-    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
+    if (c->aux_stream) {
+        hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join);
+        for (int k = 0; k < CRTHIP_MAX_CHUNKS; k++) hipEventDestroy(c->ev_chunk[k]);
+    }
     if (c->d_jump16) hipFree(c->d_jump16);
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
     if (c->d_seq) hipFree(c->d_seq);
@@ -385,8 +388,9 @@ int crthip_decode(crthip_ctx *c, const crthip_params *p, int n, const signed cha
     return rc;
 }
 
-/* one chunk of a batch: fields [first, first+n) on the context's current stream */
-static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n,
+/* one chunk of a batch, fields [first, first+n), on the context's current stream.  `part`: 1 = everything up to the
+ * line table (encoder, channel noise, sync chain), 2 = the decoder, 3 = both */
+static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n, int part,
                            const void *d_images, size_t istride, void *d_out, size_t ostride, crthip_state *d_state)
 {
     const unsigned char *img = (const unsigned char *) d_images + (size_t) first * istride;
@@ -395,47 +399,44 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     signed char *inp = c->d_inp + (size_t) first * c->fstride;
     signed char *analog = c->d_analog + (size_t) first * c->fstride;
     crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
-        /* VHS noise follows the C library's rand() stream, not the LCG: the fused encoder (margins + active
-         * rectangle = every sample of the field) runs with noise 0 into analog[], then the dedicated noise
-         * kernels (which also produce rn) */
-        int r = CRTHIP_OK;
-        if (enc == 0) {
-            crthip_params clean = *p;
-            clean.noise = 0;
-            r = crt_run_encoder(c, &clean, n, img, istride, analog, st, true, 1, true);
+    int rc = CRTHIP_OK;
+    if (part & 1) {
+        if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+            /* VHS noise follows the C library's rand() stream, not the LCG: the fused encoder (margins + active
+             * rectangle = every sample of the field) runs with noise 0 into analog[], then the dedicated noise
+             * kernels (which also produce rn) */
+            if (enc == 0) {
+                crthip_params clean = *p;
+                clean.noise = 0;
+                rc = crt_run_encoder(c, &clean, n, img, istride, analog, st, true, 1, true);
+            } else {
+                hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);   /* crt_modulate refused the format */
+            }
+            if (rc) return rc;
+            if (p->out_bpp == 0) return CRTHIP_OK;
+            unsigned *saved = c->d_vhs_hist;
+            c->d_vhs_hist = saved + (size_t) first * 32;
+            rc = crthip_noise(c, p, n, analog, inp, st);
+            c->d_vhs_hist = saved;
+            if (rc) return rc;
+            rc = crt_run_sync(c, p, n, inp, st, ln, 0);
         } else {
-            hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);   /* crt_modulate refused the format */
+            if (enc == 0) {
+                /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
+                rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, true);
+            } else {
+                /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise
+                 * (rn is advanced by k_vsync below) */
+                hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
+                rc = crt_run_noise(c, p, n, analog, inp, st, false);
+            }
+            if (rc) return rc;
+            if (p->out_bpp != 0) rc = crt_run_sync(c, p, n, inp, st, ln, 1);
         }
-        if (r) return r;
-        if (p->out_bpp == 0) return CRTHIP_OK;
-        unsigned *saved = c->d_vhs_hist;
-        c->d_vhs_hist = saved + (size_t) first * 32;
-        r = crthip_noise(c, p, n, analog, inp, st);
-        c->d_vhs_hist = saved;
-        if (r) return r;
-        r = crt_run_sync(c, p, n, inp, st, ln, 0);
-        if (r) return r;
-        return crt_run_decode(c, p, n, inp, ln, out, ostride);
-    }
-    int rc;
-    if (enc == 0) {
-        /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
-        rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, true);
-    } else {
-        /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise
-         * (rn is advanced by k_vsync below) */
-        hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
-        rc = crt_run_noise(c, p, n, analog, inp, st, false);
-    }
-    if (rc) return rc;
-    if (p->out_bpp != 0) {
-        rc = crt_run_sync(c, p, n, inp, st, ln, 1);
-        if (rc) return rc;
-        rc = crt_run_decode(c, p, n, inp, ln, out, ostride);
         if (rc) return rc;
     }
-    return CRTHIP_OK;
+    if ((part & 2) && p->out_bpp != 0) rc = crt_run_decode(c, p, n, inp, ln, out, ostride);
+    return rc;
 }
 
 int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
@@ -469,25 +470,38 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     if (want_chunks == 0) want_chunks = ((long) p->outw * p->outh >= 1280L * 720L && n >= 1024) ? 4 : 1;
     const int nchunks = (want_chunks > 1 && n >= 256 * want_chunks && !c->prof) ? want_chunks : 1;
     if (nchunks == 1) {
-        rc = fieldpass_chunk(c, p, enc, 0, n, d_images, istride, d_out, ostride, d_state);
+        rc = fieldpass_chunk(c, p, enc, 0, n, 3, d_images, istride, d_out, ostride, d_state);
     } else {
+        /* Two-stage software pipeline over the chunks: the encoder + sync chain of ALL chunks run back to back on an
+         * internal stream, the decoders on the caller's stream, decoder k waiting for the event behind sync chain k.
+         * While decoder k streams its picture out (HBM-write bound at 1080p), the vector-bound encoder of chunk k+1
+         * and the latency-bound sync chain run beside it.  (Alternating whole chunks between two streams, the first
+         * version of this, ends up running decoder next to decoder: profiles/r02_overlap_timeline_1080p.txt.) */
         if (!c->aux_stream) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            for (int k = 0; k < CRTHIP_MAX_CHUNKS; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
         }
         hipStream_t main_stream = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
         HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
         const int per = ((n + nchunks - 1) / nchunks + 3) & ~3;
+        c->stream = c->aux_stream;
+        int used = 0;
         for (int k = 0, first = 0; first < n && rc == CRTHIP_OK; k++, first += per) {
             const int cnt = n - first < per ? n - first : per;
-            c->stream = (k & 1) ? c->aux_stream : main_stream;
-            rc = fieldpass_chunk(c, p, enc, first, cnt, d_images, istride, d_out, ostride, d_state);
+            rc = fieldpass_chunk(c, p, enc, first, cnt, 1, d_images, istride, d_out, ostride, d_state);
+            if (rc == CRTHIP_OK && hipEventRecord(c->ev_chunk[k], c->aux_stream) != hipSuccess) rc = CRTHIP_E_HIP;
+            used = k + 1;
         }
         c->stream = main_stream;
-        HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
-        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+        for (int k = 0, first = 0; k < used && rc == CRTHIP_OK; k++, first += per) {
+            const int cnt = n - first < per ? n - first : per;
+            HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_chunk[k], 0));
+            rc = fieldpass_chunk(c, p, enc, first, cnt, 2, d_images, istride, d_out, ostride, d_state);
+        }
+        /* the caller's stream has waited for every event of the internal stream: nothing is left running there */
     }
     if (rc) return rc;
     HIPCHK(c, hipGetLastError());
@@ -624,7 +638,7 @@ int crthip_set_shape(crthip_ctx *c, int shape)
 
 int crthip_set_overlap(crthip_ctx *c, int chunks)
 {
-    if (!c || chunks < 0 || chunks > 64) return CRTHIP_E_ARG;
+    if (!c || chunks < 0 || chunks > CRTHIP_MAX_CHUNKS) return CRTHIP_E_ARG;
     c->overlap_chunks = chunks;
     return CRTHIP_OK;
 }

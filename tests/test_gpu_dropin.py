@@ -244,6 +244,64 @@ def test_unchanged_crt_main_driver(tmp_path, flags, outw, outh, noise, hue):
     assert outs[0] == outs[1], "driver output differs between the reference and the HIP library"
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("flags,noise", [("-o", 24), ("-op", 0), ("-or", 12)])
+def test_unchanged_crt_main_driver_lazy_mirror(tmp_path, flags, noise, mode):
+    """CRTHIP_LAZY_MIRROR: analog[] / the output image stay on the device between calls, the same
+    picture is not uploaded 8 times -- the image crt_main.c writes must not change"""
+    ref_cli = os.path.join(R.REF_DIR, "ntsc_cli")
+    hip_cli = os.path.join(R.PKG_LIB, "ntsc_cli_hip")
+    if not (os.path.exists(ref_cli) and os.path.exists(hip_cli)):
+        pytest.skip("driver binaries not prebuilt (they are built where /root/reference exists)")
+    src = str(tmp_path / "in.ppm")
+    _write_ppm(src, 600, 200, 5)
+    outs = []
+    for exe, tag, env in ((ref_cli, "ref", {}), (hip_cli, "hip", {"CRTHIP_LAZY_MIRROR": mode})):
+        out = str(tmp_path / ("out_%s.ppm" % tag))
+        r = subprocess.run([exe, flags, "640", "480", str(noise), "0", src, out], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1], "lazy mirror mode %s changed the driver's output (%s)" % (mode, flags)
+
+
+def test_lazy_mirror_sees_caller_edits():
+    """lazy mode re-uploads analog[] / the picture when the caller's copy changed (memset(crt.analog, 0, ...) of the live
+    driver, a repainted output buffer): run in a subprocess because the mode is read once per process"""
+    import sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+import crtref as R
+hip, chk = R.RefLib("ntsc", dropin=True), (R.RefLib("ntsc") if R.have_ref("ntsc") else R.Oracle("ntsc"))
+img = R.synth_image(320, 200, 4, 5)
+# odd fields of a raw image read image row h (crt_ntsc.c:263): give the reference a defined (zero) row there, which is
+# what the drop-in library's device copy has
+img = np.concatenate([img, np.zeros_like(img[-1:])])
+a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+for c in (a, b):
+    c.set("blend", 1)
+    c.settings(img, format=R.FMT_BGRA, w=320, h=200, as_color=1, raw=1)
+for step in range(5):
+    for c in (a, b):
+        if step == 2:
+            c.analog[:] = 0                   # the live driver's memset
+            c.out[:] = 77                     # repaint the picture
+        if step == 3:
+            c.sset("raw", 0)
+        c.modulate()
+        c.demodulate(20)
+        c.sset("field", c.sget("field") ^ 1)
+    assert np.array_equal(a.out, b.out), "step %%d" %% step
+    for f in ("hsync", "vsync", "rn"):
+        assert a.get(f) == b.get(f)
+print("ok")
+""" % os.path.join(R.ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CRTHIP_LAZY_MIRROR="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("flags", ["-or", "-of", "-opf", "-opm"])
 def test_unchanged_crt_main_driver_more_flags(tmp_path, flags):
     """the remaining switches of crt_main.c: raw (no scaling), odd field first, progressive + field, monochrome"""
