@@ -463,11 +463,13 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         rc = crt_run_encoder_prepare(c, p, true);
         if (rc) return rc;
     }
-    /* 0 = automatic: pictures that lean on HBM write bandwidth (1080p) gain from running the VALU / latency bound
-     * encoder + sync chain of one chunk under the decoder of the previous one; narrow pictures are VALU bound in
-     * every kernel and gain nothing */
+    /* 0 = automatic.  The idea: run the vector / latency bound encoder + sync chain of one chunk under the HBM-write
+     * bound decoder of the previous one.  Measured on MI355X (profiles/r02_overlap_sweep.txt): at 1080p the encoder's
+     * image reads and the decoder's picture writes already saturate what HBM delivers for this access mix, running
+     * them side by side is slower than one after the other (2 chunks -3 %, 8 chunks -19 %); at 640x480 every kernel is
+     * vector bound and chunks only add latency.  So automatic means: one chunk. */
     int want_chunks = c->overlap_chunks;
-    if (want_chunks == 0) want_chunks = ((long) p->outw * p->outh >= 1280L * 720L && n >= 1024) ? 4 : 1;
+    if (want_chunks == 0) want_chunks = 1;       /* measured: no configuration gains (profiles/r02_overlap_sweep.txt) */
     const int nchunks = (want_chunks > 1 && n >= 256 * want_chunks && !c->prof) ? want_chunks : 1;
     if (nchunks == 1) {
         rc = fieldpass_chunk(c, p, enc, 0, n, 3, d_images, istride, d_out, ostride, d_state);
@@ -510,9 +512,9 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
 
 int crthip_set_pixel_tile(crthip_ctx *c, int px)
 {
-    if (!c || (px != 0 && px != 16 && px != 32)) return CRTHIP_E_ARG;
+    if (!c || (px != 0 && px != 16 && px != 32 && px != 64)) return CRTHIP_E_ARG;
     c->px_tile = px;
-    c->ac_tile = px;
+    c->ac_tile = px == 64 ? 32 : px;
     return CRTHIP_OK;
 }
 

@@ -455,40 +455,71 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             wave_lds_fence();
             if (c + 1 < NCH) fetch_windows(c + 1);
             const int nl = S::LINES - c * CH < CH ? S::LINES - c * CH : CH;
-            /* everything about a line that does not depend on hsync, one lane per line, as bit masks for the loop */
+            /* The recurrence hsync_l = F_l(hsync_{l-1}) is solved as a FIXED POINT, one lane per line: every pass
+             * evaluates all 64 lines of the chunk in parallel, line l starting from the previous pass's result of line
+             * l-1 (the chunk's first line from the carried-in value).  After pass k the first k lines are final, so it
+             * terminates with the serial loop's result (at worst after 64 passes); but F_l hardly depends on its
+             * argument -- the search window slides, the sync edge it finds does not -- so a steady picture needs 2
+             * passes and a noisy one a handful (crt_core.c:437-450). */
             const int my_line = S::TOP + c * CH + lane;
             const int my_beg = (int) ((unsigned) (my_line - S::TOP) * span / (unsigned) S::LINES + (unsigned) field_rows);
             new_skip = lane >= nl || my_beg >= P.outh;                                   /* D4, crt_core.c:428-432 */
             const int my_lidx = lidx_of(my_line < S::BOT ? my_line : S::TOP);
-            const unsigned long long m_skip = __ballot(new_skip);
-            const unsigned long long m_own = __ballot(my_lidx * S::HRES + WOFF - WBACK >= 0);       /* window not clipped at 0 */
-            const unsigned long long m_next = __ballot(my_line + 1 <= S::BOT && my_lidx + 1 < S::VRES);   /* row i+1 = next analog line */
-            for (int i = 0; i < nl; i++) {
-                if ((m_skip >> i) & 1ull) { if (lane == i) new_hs = hsync; continue; }
-                /* D5, crt_core.c:437-450: the 2*HWIN bytes from ln + hsync + SYNC_BEG - HWIN */
-                int a = -1;                                                              /* byte offset in s_win */
-                if (hsync >= 0 && hsync <= WLEN - 2 * S::HWIN - WBACK && ((m_own >> i) & 1ull)) a = i * (WSTR * 4) + hsync + WBACK;
-                else if (hsync >= S::HRES - WBACK && hsync < S::HRES && ((m_next >> i) & 1ull)) a = (i + 1) * (WSTR * 4) + hsync - S::HRES + WBACK;
-                int sv = 0;
-                if (a >= 0) {
-                    if (lane < 2 * S::HWIN) sv = ((const signed char *) s_win)[a + lane];
-                } else {
-                    const long ga = (long) lidx_of(S::TOP + c * CH + i) * S::HRES + hsync + WOFF + lane;
-                    if (lane < 2 * S::HWIN && ga >= 0 && ga < (long) fstride) sv = in[ga];
+            const bool own_ok = my_lidx * S::HRES + WOFF - WBACK >= 0;                   /* my window is not clipped at 0 */
+            const bool next_ok = my_line + 1 <= S::BOT && my_lidx + 1 < S::VRES;         /* row lane+1 = the next analog line */
+            int h_in = hsync;                                                            /* every line starts from the carried-in value */
+            for (int pass = 0; pass <= CH; pass++) {
+                int h_out = h_in;
+                if (!new_skip) {
+                    /* the 2*HWIN bytes from ln + h_in + SYNC_BEG - HWIN: from my parked window, the next line's (wrapped
+                     * hsync), or -- rarely -- from memory */
+                    int a = -1;
+                    if (h_in >= 0 && h_in <= WLEN - 2 * S::HWIN - WBACK && own_ok) a = lane * (WSTR * 4) + h_in + WBACK;
+                    else if (h_in >= S::HRES - WBACK && h_in < S::HRES && next_ok) a = (lane + 1) * (WSTR * 4) + h_in - S::HRES + WBACK;
+                    unsigned w0, w1, w2, w3;
+                    if (a >= 0) {
+                        const unsigned *q = (const unsigned *) s_win + (a >> 2);
+                        const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                        const unsigned sh = (unsigned) (a & 3);
+                        w0 = __builtin_amdgcn_alignbyte(d1, d0, sh); w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                        w2 = __builtin_amdgcn_alignbyte(d3, d2, sh); w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                    } else {
+                        const long ga = (long) my_lidx * S::HRES + h_in + WOFF;
+                        v4i g = { 0, 0, 0, 0 };
+                        if (ga >= 0 && ga + 16 <= (long) fstride) g = load16u(in + ga);
+                        w0 = (unsigned) g.x; w1 = (unsigned) g.y; w2 = (unsigned) g.z; w3 = (unsigned) g.w;
+                    }
+                    /* running sum biased by -(HTHR + 1): its sign bit says "sum <= HTHR"; the sign bits are shifted into
+                     * a mask, first sample in the highest position */
+                    const unsigned wd[4] = { w0, w1, w2, w3 };
+                    int run = -(S::HTHR + 1);
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int k = 0; k < 2 * S::HWIN; k++) {
+                        run += (int) (wd[k >> 2] << (24 - 8 * (k & 3))) >> 24;
+                        mask = __builtin_amdgcn_alignbit(mask, (unsigned) run, 31);
+                    }
+                    /* sample k sits at bit 2*HWIN-1-k: the first crossing is the highest set bit */
+                    const int hi = mask ? (31 - (int) __builtin_clz(mask)) : -1;
+                    const int idx = mask ? (2 * S::HWIN - 1 - hi) - S::HWIN : S::HWIN;
+                    int h = idx + h_in;                                                  /* POSMOD(i + hsync, HRES), :447 */
+                    if (h_in >= 0 && h_in < S::HRES) {                                   /* |idx| <= HWIN: one wrap either way */
+                        if (h < 0) h += S::HRES;
+                        if (h >= S::HRES) h -= S::HRES;
+                    } else {
+                        h = posmod(h, S::HRES);
+                    }
+                    h_out = h;
                 }
-                const int pref = row_incl_scan(sv);
-                const unsigned m16 = (unsigned) __ballot(lane < 2 * S::HWIN && pref <= S::HTHR) & 0xffffu;
-                const int hi = m16 ? (__ffs((int) m16) - 1 - S::HWIN) : S::HWIN;
-                int h = hi + hsync;                                                      /* POSMOD(i + hsync, HRES), :447 */
-                if (hsync >= 0 && hsync < S::HRES) {                                     /* |hi| <= HWIN: one wrap either way */
-                    if (h < 0) h += S::HRES;
-                    if (h >= S::HRES) h -= S::HRES;
-                } else {
-                    h = posmod(h, S::HRES);
-                }
-                hsync = h;
-                if (lane == i) new_hs = hsync;
+                new_hs = h_out;
+                /* next pass: line l starts from this pass's line l-1 */
+                int h_next = __shfl_up(h_out, 1);
+                if (lane == 0) h_next = hsync;
+                const bool changed = h_next != h_in;
+                h_in = h_next;
+                if (__ballot(changed) == 0ull) break;
             }
+            hsync = __builtin_amdgcn_readlane(new_hs, nl - 1);
         }
         /* ================= pass 2 of chunk c - 1: the burst integrators ================= */
         if (c > 0) {
