@@ -191,7 +191,9 @@ typedef __attribute__((address_space(1))) unsigned char g_u8;
 __device__ __forceinline__ v4i gload16u(unsigned long long a) { return ((const g_unaligned16 *) a)->v; }
 __device__ __forceinline__ void gstore16u(unsigned long long a, v4i v) { ((g_unaligned16 *) a)->v = v; }
 /* streaming variants for data nobody touches again on the device (the input image, the decoded picture) */
-typedef __attribute__((address_space(1))) v4i g_v4i;
+/* the streamed rows are only 4-byte aligned (odd output widths, row pitch): say so in the type */
+typedef v4i v4i_a4 __attribute__((aligned(4)));
+typedef __attribute__((address_space(1))) v4i_a4 g_v4i;
 __device__ __forceinline__ void gstore16u_nt(unsigned long long a, v4i v) { __builtin_nontemporal_store(v, (g_v4i *) a); }
 __device__ __forceinline__ v4i gload16u_nt(unsigned long long a) { return __builtin_nontemporal_load((const g_v4i *) a); }
 __device__ __forceinline__ unsigned gload32(unsigned long long a) { return *(const g_u32 *) a; }
