@@ -25,7 +25,7 @@
 
 #define DPP_ROW_SHR4 0x114
 
-template <class S, bool NARROW, bool BPP3>
+template <class S, bool NARROW, bool BPP3, int TS_>
 __global__ void __launch_bounds__(64)
 k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
              const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride,
@@ -34,7 +34,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int LPL = NARROW ? 16 : 32;               /* lanes per scanline */
     constexpr int LPW = 64 / LPL;                       /* scanlines per wavefront */
     constexpr int CCS = S::CCS;
-    constexpr int TS = 32, RING = 64;                   /* samples per tile; LDS ring length (two tiles) */
+    constexpr int TS = TS_, RING = 2 * TS_;             /* samples per tile; LDS ring length (two tiles) */
     constexpr int WINB = ((S::AV_LEN + 31) / 16) * 16;  /* bytes of a line's sample window in LDS */
     __shared__ __attribute__((aligned(16))) signed char s_inp[LPW][WINB];
     __shared__ int s_u[LPW][3][RING + 1];                 /* filter inputs per channel */
@@ -116,7 +116,8 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     /* In the wave-wide phases (prep, combine, pixels) a scanline keeps its LPL lanes: lane jl of the scanline handles
      * samples / pixels jl, jl + LPL, ... of it, so every per-scanline quantity is simply the lane's own copy. */
     const int jl = lane & (LPL - 1);
-    constexpr int SPL = TS / LPL;                        /* samples per lane and tile in prep / combine (2 or 1) */
+    constexpr int SPL = TS >= LPL ? TS / LPL : 1;        /* samples per lane and tile in prep / combine */
+    const bool jl_on = jl * SPL < TS;                    /* (a 32-lane scanline has idle lanes when the tile is 16 samples) */
     constexpr int bpp = BPP3 ? 3 : 4;
     const size_t pitch = (size_t) P.outw * bpp;
     const unsigned long long dst_row = (unsigned long long) (outp + (size_t) f * ostride + (size_t) lp.beg * pitch);
@@ -154,6 +155,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
         /* ---- prep: filter inputs of samples [t0, t0 + TS) of my scanline, all three channels ---- */
 #pragma unroll
         for (int k = 0; k < SPL; k++) {
+            if (!jl_on) break;
             const int xl = t0 + jl * SPL + k;
             const int sm = xl < WINB ? s_inp[ls][xl] : 0;
             int wi = wIk[k], wq = wQk[k];
@@ -187,7 +189,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
 #pragma unroll
         for (int k = 0; k < SPL; k++) {
             const int x = cdone + jl * SPL + k;
-            if (x < xready) {
+            if (x < xready && jl_on) {
                 const int sl = (x + 3) & (RING - 1), sp = (x - 3) & (RING - 1);
                 const int ylo = s_c[ls][0][sl], yhi = s_c[ls][1][sl], ihi = s_c[ls][C_IHI][sl], qhi = s_c[ls][C_QHI][sl];
                 const int uy = x >= 3 ? s_u[ls][0][sp] : 0;
@@ -296,11 +298,14 @@ int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const sign
         unsigned char *o = (unsigned char *) d_out;
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
-#define CRTHIP_LAUNCH_ROWS(B3) \
-    do { if (narrow_ok) hipLaunchKernelGGL((k_decode_row<S, true, B3>), dim3((total + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, 0); \
-         hipLaunchKernelGGL((k_decode_row<S, false, B3>), dim3((total + 1) / 2), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, narrow_ok ? 0 : 1); } while (0)
-            if (p->out_bpp == 3) CRTHIP_LAUNCH_ROWS(true); else CRTHIP_LAUNCH_ROWS(false);
-#undef CRTHIP_LAUNCH_ROWS
+#define CRTHIP_LAUNCH_ROWS_T(B3, TSV) \
+    do { if (narrow_ok) hipLaunchKernelGGL((k_decode_row<S, true, B3, TSV>), dim3((total + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, 0); \
+         hipLaunchKernelGGL((k_decode_row<S, false, B3, TSV>), dim3((total + 1) / 2), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, narrow_ok ? 0 : 1); } while (0)
+            /* tile of 16 samples: 9 KB of LDS per wave instead of 14 (4 waves per SIMD instead of 2.75), twice the
+             * per-tile overheads: CRTHIP_ROW_TILE=16 (A/B switch; measurements in profiles/r02_shape_sweep.txt) */
+            if (c->row_tile == 16) { if (p->out_bpp == 3) CRTHIP_LAUNCH_ROWS_T(true, 16); else CRTHIP_LAUNCH_ROWS_T(false, 16); }
+            else { if (p->out_bpp == 3) CRTHIP_LAUNCH_ROWS_T(true, 32); else CRTHIP_LAUNCH_ROWS_T(false, 32); }
+#undef CRTHIP_LAUNCH_ROWS_T
         }
         return CRTHIP_OK;
     });

@@ -338,6 +338,7 @@ struct crthip_ctx {
     bool skel_valid;
     int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
     int shape;                  /* crthip_set_shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel */
+    int row_tile;               /* CRTHIP_ROW_TILE: samples per tile of the scanline-parallel decoder, 32 (default) or 16 */
     int sync_kernel;            /* CRTHIP_SYNC_KERNEL: 0 by batch size, 1 k_hsync (4 fields per wave), 2 k_hsync_wave (field per wave) */
     bool legacy_sync;           /* CRTHIP_LEGACY_SYNC=1 in the environment: the 16-lanes-per-field sync kernel (A/B measurements) */
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
