@@ -375,8 +375,12 @@ __device__ __forceinline__ int burst_step(int acc, int s)
     return (acc + s) - (acc >> 7) - (int) ((int) ((unsigned) acc & 0x8000007fu) > 0);
 }
 
-template <class S>
-__global__ void __launch_bounds__(64)
+/* FPB = fields (= waves) per workgroup.  1: the latency shape, everything wave-synchronous.  4 (large batches): the
+ * burst integrators of the workgroup's 4 fields are stepped by ONE wave, 4 fields x CC_VPER x CC_SAMPLES lanes at a
+ * time, while the other three wait at a barrier -- the chain is the only part that keeps the vector unit busy for long,
+ * and with 4 of 64 lanes working per field it costs a quarter this way. */
+template <class S, int FPB>
+__global__ void __launch_bounds__(64 * FPB)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
              crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
 {
@@ -387,14 +391,19 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int WSTR = 21;                             /* dwords per window row (84 bytes: odd stride, no bank conflicts) */
     constexpr int BPIECES = (S::CB_LEN + 15) / 16;       /* 16-byte pieces covering the CB_LEN burst bytes */
     constexpr int BSTR = BPIECES * 4 + 1;                /* dwords per burst row */
-    __shared__ int s_win[(CH + 1) * WSTR];               /* sync windows of the chunk's lines (+ the line after it) */
-    __shared__ int s_bur[CH * BSTR];                     /* burst samples, one row per non-skipped line, grouped by line class */
-    __shared__ int s_acc[CH][CCS == 4 ? 4 : 8];          /* the class's integrators after each of those lines */
-    __shared__ int s_cnt[VPER], s_off[VPER];
+    __shared__ int s_win_[FPB][(CH + 1) * WSTR];               /* sync windows of the chunk's lines (+ the line after it) */
+    __shared__ int s_bur_[FPB][CH * BSTR];                     /* burst samples, one row per non-skipped line, grouped by line class */
+    __shared__ int s_acc_[FPB][CH][CCS == 4 ? 4 : 8];          /* the class's integrators after each of those lines */
+    __shared__ int s_cnt_[FPB][VPER], s_off_[FPB][VPER];
 
-    const int lane = threadIdx.x;
-    const int f = blockIdx.x;
-    if (f >= n_fields) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f_raw = blockIdx.x * FPB + wv;
+    const bool live = f_raw < n_fields;                  /* a wave without a field shadows the last one and stores nothing */
+    const int f = live ? f_raw : n_fields - 1;
+    int *const s_win = s_win_[wv], *const s_bur = s_bur_[wv];
+    int (*const s_acc)[CCS == 4 ? 4 : 8] = s_acc_[wv];
+    int *const s_cnt = s_cnt_[wv], *const s_off = s_off_[wv];
+#define HSW_SYNC() do { if (FPB > 1) __syncthreads(); else wave_lds_fence(); } while (0)
     const signed char *in = inp + (size_t) f * fstride;
     crthip_state *st = state + f;
     int hsync = __builtin_amdgcn_readfirstlane(st->hsync);
@@ -403,12 +412,16 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     const unsigned span = (unsigned) P.outh + P.v_fac;
     crthip_line *out_lines = lines + (size_t) f * S::LINES;
 
-    /* chain lanes: lane = r * CCS + p integrates carrier phase p of line class r */
-    const int my_r = lane / CCS, my_p = lane - my_r * CCS;
-    const bool chain_lane = lane < VPER * CCS;
-    int acc = chain_lane ? st->ccf[my_r][my_p] : 0;
+    /* chain lanes (wave 0 of the workgroup): lane = (field slot * VPER + r) * CCS + p integrates carrier phase p of line
+     * class r of the workgroup's field `slot` */
+    constexpr int LPF = VPER * CCS;                      /* chain lanes per field */
+    const int my_slot = lane / LPF, my_rp = lane - my_slot * LPF;
+    const int my_r = my_rp / CCS, my_p = my_rp - my_r * CCS;
+    const bool chain_lane = wv == 0 && my_slot < FPB && blockIdx.x * FPB + my_slot < n_fields;
+    crthip_state *st_chain = state + (chain_lane ? blockIdx.x * FPB + my_slot : 0);
+    int acc = chain_lane ? st_chain->ccf[my_r][my_p] : 0;
     const bool big = chain_lane && (acc >= (1 << 23) || acc <= -(1 << 23));
-    const bool exact_mul = __ballot(big) != 0ull;        /* caller-supplied garbage in ccf: keep the wrapping multiply */
+    const bool exact_mul = __ballot(big) != 0ull;        /* caller-supplied garbage in ccf: keep the wrapping multiply (wave 0 only) */
     const int k0 = CCS == 4 ? ((my_p - S::CB_BEG) & 3) : ((my_p - S::CB_BEG) % CCS + CCS) % CCS;
 
     auto lidx_of = [&](int line) { int l = line + vsync; return l >= S::VRES ? l - S::VRES : l; };   /* 0 <= vsync < VRES */
@@ -533,13 +546,14 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                     d[0] = breg[q].x; d[1] = breg[q].y; d[2] = breg[q].z; d[3] = breg[q].w;
                 }
             }
-            wave_lds_fence();
-            const int n_mine = chain_lane ? s_cnt[my_r] : 0;
-            const int row0 = chain_lane ? s_off[my_r] : 0;
+            HSW_SYNC();
+            if (wv == 0) {
+            const int n_mine = chain_lane ? s_cnt_[my_slot][my_r] : 0;
+            const int row0 = chain_lane ? s_off_[my_slot][my_r] : 0;
             int n_max = n_mine;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(n_max, o); n_max = v > n_max ? v : n_max; }
-            const signed char *bp = (const signed char *) (s_bur + row0 * BSTR) + k0;
+            const signed char *bp = (const signed char *) (s_bur_[chain_lane ? my_slot : 0] + row0 * BSTR) + k0;
             int cur[NB], nxt[NB];
 #pragma unroll
             for (int q = 0; q < NB; q++) { cur[q] = n_mine > 0 ? bp[CCS * q] : 0; nxt[q] = 0; }
@@ -557,14 +571,15 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
 #pragma unroll
                         for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, cur[q]);
                     }
-                    s_acc[row0 + j][my_p] = acc;
+                    s_acc_[my_slot][row0 + j][my_p] = acc;
                 }
 #pragma unroll
                 for (int q = 0; q < NB; q++) cur[q] = nxt[q];
             }
-            wave_lds_fence();
+            }
+            HSW_SYNC();
             /* ================= pass 3 of chunk c - 1: the line table, one lane per line ================= */
-            if (lane < nl) {
+            if (lane < nl && live) {
                 const int i = lane, line = S::TOP + cc * CH + i;
                 const int hs = rec_hs;
                 const bool skip = rec_skip;
@@ -662,8 +677,9 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             wave_lds_fence();
         }
     }
-    if (chain_lane) st->ccf[my_r][my_p] = acc;
-    if (lane == 0) st->hsync = hsync;
+    if (chain_lane) st_chain->ccf[my_r][my_p] = acc;
+    if (lane == 0 && live) st->hsync = hsync;
+#undef HSW_SYNC
 }
 
 /* CRT_DO_BLOOM (crt_core.c:399-402, 512-526): the beam energy of every decoded line (sum of its AV_LEN samples)
@@ -718,8 +734,10 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
          * is faster at every batch size measured (profiles/r02_sync_kernels.txt) */
         if (c->legacy_sync || c->sync_kernel == 1)
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+        else if (n >= 512 && 64 / (S::VPER * S::CCS) >= 4)          /* 4 fields per workgroup share one wave for their burst chains */
+            hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         else
-            hipLaunchKernelGGL((k_hsync_wave<S>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+            hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         if (p->bloom)
             hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;
