@@ -207,7 +207,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     barrier()
     # The launch sequence of two consecutive steps (the even and the odd field of the interlaced pair: they differ in
     # the frame flip) is captured into a HIP graph and replayed: same kernels, same work, no per-launch host overhead
-    # between them.  --no-graph (or a capture failure) times the eager launches instead.
+    # between them.  Opt-in (--graph): measured equal to the eager launches (the queue never drains at these batch sizes).
     graph = None
     if wl.get("graph", False) and not wl.get("sequence") and steps >= 2 and not system.startswith("vhs"):
         try:

@@ -302,9 +302,9 @@ int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const sign
     do { if (narrow_ok) hipLaunchKernelGGL((k_decode_row<S, true, B3, TSV>), dim3((total + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, 0); \
          hipLaunchKernelGGL((k_decode_row<S, false, B3, TSV>), dim3((total + 1) / 2), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, narrow_ok ? 0 : 1); } while (0)
             /* tile of 16 samples: 9 KB of LDS per wave instead of 14 (4 waves per SIMD instead of 2.75) but twice the
-             * per-tile overheads: better as soon as the launch has more waves than the chip has SIMDs (measured: batch 64
-             * -23 %, batch 1 +10 %, profiles/r02_shape_sweep.txt); CRTHIP_ROW_TILE=16|32 overrides */
-            if (c->row_tile == 16 || (c->row_tile == 0 && n >= 16)) { if (p->out_bpp == 3) CRTHIP_LAUNCH_ROWS_T(true, 16); else CRTHIP_LAUNCH_ROWS_T(false, 16); }
+             * per-tile overheads: better once the launch has a few waves per SIMD (measured: batch 64
+             * -22 %, batch 16 and batch 1 +10 %, profiles/r02_shape_sweep.txt); CRTHIP_ROW_TILE=16|32 overrides */
+            if (c->row_tile == 16 || (c->row_tile == 0 && n >= 48)) { if (p->out_bpp == 3) CRTHIP_LAUNCH_ROWS_T(true, 16); else CRTHIP_LAUNCH_ROWS_T(false, 16); }
             else { if (p->out_bpp == 3) CRTHIP_LAUNCH_ROWS_T(true, 32); else CRTHIP_LAUNCH_ROWS_T(false, 32); }
 #undef CRTHIP_LAUNCH_ROWS_T
         }

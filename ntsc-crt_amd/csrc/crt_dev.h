@@ -291,10 +291,11 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
     return rn;
 }
 
-/* fields per launch up to which the scanline-parallel kernel shape (k_active_row, k_decode_row) is chosen automatically:
- * lane-per-scanline needs n * 240 / 64 wavefronts >= a few per SIMD (1024 SIMDs) to hide its serial chains; measured
- * crossover of the decoders between 128 and 256 fields (profiles/r02_shape_sweep.txt) */
-#define ROWS_SHAPE_MAX_FIELDS 128
+/* fields per launch up to which the scanline-parallel kernel shapes are chosen automatically: lane-per-scanline needs
+ * n * 240 / 64 wavefronts >= a few per SIMD (1024 SIMDs) to hide its serial chains.  Measured crossovers
+ * (profiles/r02_shape_sweep.txt): decoders between 128 and 256 fields, encoders between 512 and 1024 */
+#define ROWS_SHAPE_MAX_FIELDS 128          /* k_decode_row */
+#define ROWS_SHAPE_MAX_FIELDS_ENC 512      /* k_active_row */
 
 #define CRTHIP_MAX_CHUNKS 64               /* crthip_set_overlap */
 

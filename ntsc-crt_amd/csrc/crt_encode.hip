@@ -841,7 +841,7 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const bool noise = FULL && p->noise != 0;
     if constexpr (!S::IS_NES) {
         /* kernel shape (crthip_set_shape): small batches take the scanline-parallel encoder */
-        if (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS)) {
+        if (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS_ENC)) {
             const dim3 rgrid((total + 7) / 8);
             if (noise) hipLaunchKernelGGL((k_active_row<S, true, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_jump1);
             else hipLaunchKernelGGL((k_active_row<S, false, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_jump1);

@@ -380,7 +380,7 @@ __device__ __forceinline__ int burst_step(int acc, int s)
  * time, while the other three wait at a barrier -- the chain is the only part that keeps the vector unit busy for long,
  * and with 4 of 64 lanes working per field it costs a quarter this way. */
 template <class S, int FPB>
-__global__ void __launch_bounds__(64 * FPB)
+__global__ void __launch_bounds__(64 * FPB, 4)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
              crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
 {
@@ -731,10 +731,12 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         ProfScope ps(c, CRTHIP_K_SYNC);
         hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
         /* k_hsync (16 lanes per field) is kept for A/B measurements (CRTHIP_SYNC_KERNEL=1): the wave-per-field kernel
-         * is faster at every batch size measured (profiles/r02_sync_kernels.txt) */
+         * is faster at every batch size measured (profiles/r02_shape_sweep.txt, rows L against A).
+         * CRTHIP_SYNC_KERNEL=2 / 3 force 1 / 4 fields per workgroup */
+        constexpr bool FPB4_OK = 64 / (S::VPER * S::CCS) >= 4;
         if (c->legacy_sync || c->sync_kernel == 1)
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
-        else if (n >= 512 && 64 / (S::VPER * S::CCS) >= 4)          /* 4 fields per workgroup share one wave for their burst chains */
+        else if (FPB4_OK && c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3))        /* 4 fields per workgroup share one wave for their burst chains */
             hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         else
             hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
