@@ -299,13 +299,29 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     } else {
                         yy = (mulq_vs<FAST>(py, L) >> 2) + (mulq_vs<FAST>(cy, R) >> 2);
                     }
-                    const int ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq_vs<FAST>(ci, R) >> 14);
-                    const int qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq_vs<FAST>(cq, R) >> 14);
-                    int r = mulq<FAST>((yy + mulq<FAST>(3879, ii) + mulq<FAST>(2556, qq)) >> 12, contrast) >> 8;
-                    int g = mulq<FAST>((yy - mulq<FAST>(1126, ii) - mulq<FAST>(2605, qq)) >> 12, contrast) >> 8;
-                    int b = mulq<FAST>((yy - mulq<FAST>(4530, ii) + mulq<FAST>(7021, qq)) >> 12, contrast) >> 8;
+                    int ii, qq;
+                    if (TIER <= 1) {
+                        /* crt_core.c:557-558: (pi * L >> 14) + (ci * R >> 14).  With the weights scaled by 4 each shift
+                         * is "take the high word", and both ride on the add.  |chroma| <= 2^13 inside the tier's
+                         * envelope (|wave| <= 120000: inputs |s * wave >> 9| < 2^15, outputs >> 3), weights < 2^14 */
+                        ii = add_hiwords(mulq_vs<true>(pi, L << 2), mulq_vs<true>(ci, R << 2));
+                        qq = add_hiwords(mulq_vs<true>(pq, L << 2), mulq_vs<true>(cq, R << 2));
+                    } else {
+                        ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq_vs<FAST>(ci, R) >> 14);
+                        qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq_vs<FAST>(cq, R) >> 14);
+                    }
+                    int r, g, b;
+                    if (FAST) {
+                        r = mulq<true>(mad24_vs(qq, 2556, mad24_vs(ii, 3879, yy)) >> 12, contrast) >> 8;
+                        g = mulq<true>(mad24_vs(qq, -2605, mad24_vs(ii, -1126, yy)) >> 12, contrast) >> 8;
+                        b = mulq<true>(mad24_vs(qq, 7021, mad24_vs(ii, -4530, yy)) >> 12, contrast) >> 8;
+                    } else {
+                        r = ((yy + 3879 * ii + 2556 * qq) >> 12) * contrast >> 8;
+                        g = ((yy - 1126 * ii - 2605 * qq) >> 12) * contrast >> 8;
+                        b = ((yy - 4530 * ii + 7021 * qq) >> 12) * contrast >> 8;
+                    }
                     r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
-                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = (unsigned) (((r << 8 | g) << 8) | b);
+                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = lshl_or(lshl_or((unsigned) r, 8, (unsigned) g), 8, (unsigned) b);
                     if ((px & (PX_TILE - 1)) == PX_TILE - 1 || px == outw - 1) {
                         /* drain the pixel tile: pixels [px0, px0+cnt) of every row, + D10 duplicates (:661-664) */
                         const int px0 = px & ~(PX_TILE - 1);

@@ -52,6 +52,7 @@ struct SysCommon {
     static constexpr bool IS_VHS = false;
     static constexpr bool LINE_ROWS = false;            /* carrier row = line class + dot_crawl_offset */
     static constexpr bool BANDLIMIT = true;             /* CRT_DO_BANDLIMITING */
+    static constexpr bool IIR_Y_NEAR = true;            /* luma low-pass coefficient >= 1024 (Q11): every system but VHS */
     static constexpr bool FIELD_ROWS = true;            /* source row offset by field parity, crt_ntsc.c:258 */
     static constexpr int EQU_A_LO = 0, EQU_A_HI = 3, EQU_B_LO = 7, EQU_B_HI = 9;   /* crt_ntsc.c:211 */
     static constexpr int VS_LO = 4, VS_HI = 6;          /* crt_ntsc.c:217 */
@@ -93,8 +94,8 @@ struct NesTiming : SysCommon {   /* crt_nes.h:30-126, crt_nesrgb.h, crt_snes.h (
 };
 struct SysNTSC : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 1; };
 struct SysNTSC0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 0; };
-struct SysVHS : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 1; static constexpr bool IS_VHS = true; };
-struct SysVHS0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 0; static constexpr bool IS_VHS = true; };
+struct SysVHS : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 1; static constexpr bool IS_VHS = true, IIR_Y_NEAR = false; };
+struct SysVHS0 : RgbTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSCVHS, PATTERN = 0; static constexpr bool IS_VHS = true, IIR_Y_NEAR = false; };
 struct SysNES2 : NesTiming<2273> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 2; };
 struct SysNES1 : NesTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 1; };
 struct SysNES0 : NesTiming<2280> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NES, PATTERN = 0; };
@@ -275,6 +276,37 @@ __device__ __forceinline__ int mad24_vv(int v, int s_uniform, int acc_v)
 {
     int r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(s_uniform), "v"(acc_v));
+    return r;
+}
+/* v_mad_i64_i32: vgpr * sgpr + 64-bit register pair (used as "multiply, shift and accumulate in one instruction": the
+ * state of a one-pole filter lives in the HIGH half of a pair, the multiplier is pre-shifted so that the wanted
+ * quotient bits land there; see eq_step64 in crt_decode.hip and the encoder's low-passes in crt_encode.hip) */
+__device__ __forceinline__ long mad64_vs(int d, int m_uniform, long acc)
+{
+    long r, carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(d), "s"(m_uniform), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ int pair_hi(long v) { return (int) (v >> 32); }
+/* a + (b >> 16), b taken as a signed 32-bit value: one SDWA add (the high word of b, sign-extended) */
+__device__ __forceinline__ int add_hiword(int a, int b)
+{
+    int r;
+    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+/* (a >> 16) + (b >> 16), both taken as signed 32-bit values */
+__device__ __forceinline__ int add_hiwords(int a, int b)
+{
+    int r;
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+/* (a << sh) | b in one instruction */
+__device__ __forceinline__ unsigned lshl_or(unsigned a, int sh, unsigned b)
+{
+    unsigned r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(sh), "v"(b));
     return r;
 }
 __device__ __forceinline__ int noisy(int sample, unsigned rn, int noise)

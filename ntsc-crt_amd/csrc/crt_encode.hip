@@ -118,6 +118,14 @@ __device__ __forceinline__ unsigned input_selector(int format)
     }
 }
 
+/* the same without the permute: colour bytes moved to bits 0-23 (one shift for the two alpha-first orders) and the
+ * RGB->YIQ coefficients of crt_ntsc.c:307-309 ordered by byte position instead */
+__device__ __forceinline__ bool format_alpha_first(int format) { return format == CRTHIP_FMT_ARGB || format == CRTHIP_FMT_ABGR; }
+__device__ __forceinline__ bool format_blue_low(int format)
+{
+    return format == CRTHIP_FMT_BGR || format == CRTHIP_FMT_BGRA || format == CRTHIP_FMT_ABGR;
+}
+
 /* NES PPU square wave, crt_nes.c:21-61 */
 __device__ __forceinline__ int ppu_level(int p, int phase)
 {
@@ -351,17 +359,36 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         const int crow = carrier_row<S>(y + P.yo, st.field, st.frame, st.aux);
         int cI[S::CCS], cQ[S::CCS];
 #pragma unroll
-        for (int k = 0; k < S::CCS; k++) { cI[k] = P.modI[crow][k]; cQ[k] = P.modQ[crow][k]; }
+        for (int k = 0; k < S::CCS; k++) { cI[k] = P.modI[crow][k] * (FAST ? 4096 : 1); cQ[k] = P.modQ[crow][k] * (FAST ? 4096 : 1); }
         const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
-        const unsigned isel = input_selector(P.format);
         const int white = P.white, ire_base = P.ire_base, noise = P.noise;
         int hy = 0, hi = 0, hq = 0;
         int cph = 0;                                              /* x % CCS for the 5-sample system (wave-uniform) */
+        /* RGB -> YIQ coefficients by byte position (wave-uniform) */
+        const bool alpha_first = format_alpha_first(P.format), blue_low = format_blue_low(P.format);
+        const int ky0 = blue_low ? 7471 : 19595, ky1 = 38470, ky2 = blue_low ? 19595 : 7471;
+        const int ki0 = blue_low ? -21103 : 39059, ki1 = -18022, ki2 = blue_low ? 39059 : -21103;
+        const int kq0 = blue_low ? 20382 : 13894, kq1 = -34275, kq2 = blue_low ? 13894 : 20382;
+
+        /* FAST + cooperative tiles: the three one-pole low-passes (iirf, crt_ntsc.c:117-126) as one v_mad_i64_i32
+         * each.  h' = h + ((c*(s-h)) >> 11) is the high half of (c << 21)*(s-h) + {0, h}; for c >= 1024 the
+         * multiplier would not fit 32 bits, but h + (s-h) = s gives the equivalent ((c-2048) << 21)*(s-h) + {0, s}.
+         * The 64-bit product is exact where the reference's 32-bit one wraps: equal inside the FAST envelope
+         * (|c*(s-h)| < 2^31: |s-h| <= 2*1275, c <= 2048).  Which form a channel takes is a property of the system
+         * (IIR_Y_NEAR), checked against the actual coefficients at launch. */
+        constexpr bool I64 = FAST && IN4 && S::BANDLIMIT;
+        const int my_ = (S::IIR_Y_NEAR ? cy_ - 2048 : cy_) << 21, mi_ = ci_ << 21, mq_ = cq_ << 21;
+        long hyp = 0, hip = 0, hqp = 0, fyp = 0;                   /* state (and the luma input) in the high halves */
+        constexpr long HI_HALF = (long) 0xffffffff00000000ul;
 
         if (IN4) tiles.start();
         /* loop invariants the compiler would otherwise re-materialise per sample (constant-bus limit of VOP3) */
         int neg_noise127 = -0x7f * noise;
         asm volatile("" : "+v"(neg_noise127));
+        int neg_noise127_256 = -0x7f * noise * 256, ire_base_1024 = ire_base << 10;
+        asm volatile("" : "+v"(neg_noise127_256));
+        asm volatile("" : "+v"(ire_base_1024));
+        const int noise256 = noise * 256;
         v2u lcg_add = { LCG_ADD, 0u };
         asm volatile("" : "+v"(lcg_add));
         int fy = 0, fi = 0, fq = 0, have_col = -1;                 /* YIQ of source column have_col (wave-uniform) */
@@ -382,14 +409,25 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                             pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
                             if (in_bpp == 4) pixel |= (unsigned) pp[3] << 24;
                         }
-                        const unsigned rgb = __builtin_amdgcn_perm(pixel, pixel, isel);
-                        const int r = (rgb >> 16) & 255, gg = (rgb >> 8) & 255, b = rgb & 255;
-                        fy = (19595 * r + 38470 * gg + 7471 * b) >> 14;
-                        fi = (39059 * r - 18022 * gg - 21103 * b) >> 14;
-                        fq = (13894 * r - 34275 * gg + 20382 * b) >> 14;
+                        if (alpha_first) {                         /* scalar branch (the asm keeps it one) */
+                            pixel >>= 8;
+                            asm volatile("" : "+v"(pixel));
+                        }
+                        const int c0 = pixel & 255, c1 = (pixel >> 8) & 255, c2 = (pixel >> 16) & 255;
+                        const int y_ = (ky0 * c0 + ky1 * c1 + ky2 * c2) >> 14;
+                        if (I64) fyp = (fyp & ~HI_HALF) | (long) ((unsigned long) (unsigned) y_ << 32);
+                        else fy = y_;
+                        fi = (ki0 * c0 + ki1 * c1 + ki2 * c2) >> 14;
+                        fq = (kq0 * c0 + kq1 * c1 + kq2 * c2) >> 14;
                         have_col = col;
                     }
-                    if (S::BANDLIMIT) {
+                    if (I64) {
+                        if (S::IIR_Y_NEAR) hyp = mad64_vs(pair_hi(fyp) - pair_hi(hyp), my_, fyp);
+                        else hyp = mad64_vs(pair_hi(fyp) - pair_hi(hyp), my_, hyp & HI_HALF);
+                        hip = mad64_vs(fi - pair_hi(hip), mi_, hip & HI_HALF);
+                        hqp = mad64_vs(fq - pair_hi(hqp), mq_, hqp & HI_HALF);
+                        hy = pair_hi(hyp); hi = pair_hi(hip); hq = pair_hi(hqp);
+                    } else if (S::BANDLIMIT) {
                         hy += mulq<FAST>(fy - hy, cy_) >> 11;       /* iirf, crt_ntsc.c:117-126 */
                         hi += mulq<FAST>(fi - hi, ci_) >> 11;
                         hq += mulq<FAST>(fq - hq, cq_) >> 11;
@@ -405,16 +443,30 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         ccQ = cph == 0 ? cQ[0] : cph == 1 ? cQ[1] : cph == 2 ? cQ[2] : cph == 3 ? cQ[3] : cQ[4];
                         cph = cph == S::CCS - 1 ? 0 : cph + 1;
                     }
-                    const int mi = mulq<FAST>(hi, ccI) >> 4;
-                    const int mq = mulq<FAST>(hq, ccQ) >> 4;
-                    int ire = ire_base + (mulq<FAST>(hy + mi + mq, white) >> 10);
+                    int ire;
+                    if (FAST) {
+                        /* (h * cc) >> 4 twice: the carriers are pre-scaled by 2^12 (cI / cQ above), so that each
+                         * shift is "take the high word" and both ride on the add;
+                         * base + (v * white >> 10) == (v * white + (base << 10)) >> 10: one multiply-add */
+                        const int miq = add_hiwords(__mul24(hi, ccI), __mul24(hq, ccQ));
+                        ire = mad24_vv(hy + miq, white, ire_base_1024) >> 10;
+                    } else {
+                        const int mi = (hi * ccI) >> 4;
+                        const int mq = (hq * ccQ) >> 4;
+                        ire = ire_base + (((hy + mi + mq) * white) >> 10);
+                    }
                     ire = clampi(ire, 0, 110);
                     if (NOISE) {
                         rn = lcg_step_mad64(rn, lcg_add);
-                        /* (byte - 0x7f) * noise, distributed: the byte select rides on the multiply-add */
                         const int nb = (int) ((rn >> 16) & 0xffu);
-                        const int nz = FAST ? mad24_vv(nb, noise, neg_noise127) : nb * noise + neg_noise127;
-                        ire = clampi(ire + (nz >> 8), -127, 127);
+                        if (FAST) {
+                            /* ((byte - 0x7f) * noise) >> 8 added to ire: the product scaled by 256 so that the
+                             * shift becomes "take the high word" and rides on the add (|noise| < 2^15 on this path) */
+                            ire = add_hiword(ire, mad24_vv(nb, noise256, neg_noise127_256));
+                        } else {
+                            ire += (nb * noise + neg_noise127) >> 8;
+                        }
+                        ire = clampi(ire, -127, 127);
                     }
                     tiles.put_byte(g, k, ire);
                     col += qstep; err += rstep;
@@ -812,11 +864,19 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     }
 }
 
+template <class S>
 static bool encoder_fast_ok(const crthip_params *p)
 {
     const int wh = p->white < 0 ? -p->white : p->white;
     const int nz = p->noise < 0 ? -p->noise : p->noise;
-    return wh < (1 << 23) && nz < (1 << 23);
+    bool ok = wh < (1 << 23) && nz < (1 << 15);                   /* noise * 256 is a 24-bit multiplier in k_active */
+    for (int r = 0; r < CRTHIP_CARRIER_ROWS; r++)                  /* ... and so are the carriers * 4096 */
+        for (int k = 0; k < CRTHIP_MAX_CCS; k++)
+            ok = ok && p->modI[r][k] > -2048 && p->modI[r][k] < 2048 && p->modQ[r][k] > -2048 && p->modQ[r][k] < 2048;
+    if (S::BANDLIMIT)                                              /* the forms of the 64-bit low-passes (k_active) */
+        ok = ok && p->iir_c[0] > 0 && p->iir_c[0] <= 2048 && (p->iir_c[0] >= 1024) == S::IIR_Y_NEAR &&
+             p->iir_c[1] > 0 && p->iir_c[1] < 1024 && p->iir_c[2] > 0 && p->iir_c[2] < 1024;
+    return ok;
 }
 
 template <class S, bool FULL, bool FAST>
@@ -884,7 +944,7 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
         hipLaunchKernelGGL((k_template<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
                            *p, n, dst, c->fstride, d_state, nes_setup);
     }
-    if (encoder_fast_ok(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
+    if (encoder_fast_ok<S>(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
     else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state);
     return CRTHIP_OK;
 }
