@@ -909,7 +909,7 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
         }
     }
     const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
-    const bool wide_in = c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
+    const bool wide_in = c->ac_tile_env ? c->ac_tile_env == 32 : c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
     do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
          else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)

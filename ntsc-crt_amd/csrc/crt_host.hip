@@ -187,7 +187,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
     { const char *e = getenv("CRTHIP_SYNC_KERNEL"); c->sync_kernel = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_ROW_TILE"); c->row_tile = e ? atoi(e) : 0; }
-    { const char *e = getenv("CRTHIP_AC_TILE"); if (e && (atoi(e) == 16 || atoi(e) == 32)) c->ac_tile = atoi(e); }   /* A/B switch, k_active */
+    { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;
