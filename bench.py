@@ -79,6 +79,21 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_time_workload(system, w, h, outw, outh, noise, scanlines, budget_s):
     """Time the reference (or the oracle port) on the calling thread on a bounded sample; returns (fps, reps, kind)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -132,6 +147,9 @@ def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s, all_cores
             except (ValueError, IndexError):
                 pass
         out["all_cores"] = {"value": sum(rates), "unit": "frames/sec", "cores": len(rates),
+                            # what the processes got out of the box: a container quota or SMT siblings show up here
+                            "effective_cores": sum(rates) / fps if fps > 0 else None,
+                            "cpu_quota_cores": cpu_quota_cores(),
                             "sample": "%d independent processes x %.0f s of the same workload (wall %.1f s)"
                                       % (len(rates), sec, time.perf_counter() - t0)}
     return out
