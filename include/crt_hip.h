@@ -140,7 +140,10 @@ typedef struct crthip_params {
     int eq_kernel;                 /* 0 or the FIR taps from flags (validated)   */
     int bloom;                     /* flags & CRTHIP_F_BLOOM                     */
     int bloom_max_e;               /* crt_core.c:400                             */
-    int reserved[6];
+    /* source column of destination sample x, crt_ntsc.c:272: x * w / destw == (x * col_step) >> 32 with
+     * col_step = ceil(2^32 * w / destw), exact while x * destw < 2^32 */
+    unsigned col_step_lo, col_step_hi;
+    int reserved[4];
 } crthip_params;
 
 /*

@@ -57,7 +57,7 @@ class Params(C.Structure):
         ("eq_g", (C.c_int * 3) * 3), ("huesn", C.c_int), ("huecs", C.c_int),
         ("bright", C.c_int), ("white", C.c_int), ("ire_base", C.c_int), ("dx", C.c_int),
         ("ratio", C.c_int), ("eq_kernel", C.c_int), ("bloom", C.c_int), ("bloom_max_e", C.c_int),
-        ("reserved", C.c_int * 6)]
+        ("col_step_lo", C.c_uint), ("col_step_hi", C.c_uint), ("reserved", C.c_int * 4)]
 
 
 def bpp4fmt(fmt):

@@ -392,11 +392,19 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         v2u lcg_add = { LCG_ADD, 0u };
         asm volatile("" : "+v"(lcg_add));
         int fy = 0, fi = 0, fq = 0, have_col = -1;                 /* YIQ of source column have_col (wave-uniform) */
+        /* source column on the scalar unit: one 64-bit add per sample (crthip_params.col_step), instead of the
+         * incremental quotient / remainder pair (8 scalar instructions as compiled) */
+        const unsigned long long cstep = ((unsigned long long) P.col_step_hi << 32) | P.col_step_lo;
+        unsigned long long cpos = 0;
         for (int g = 0; g < ngroups; g++) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = 4 * g + k;
-                if (x < destw) {
+                /* With the cooperative tiles the up to 3 samples behind the line end are simply computed: they land
+                 * in the tile and are never stored (drain clips to destw), their pixel reads stay inside the row
+                 * (piece_offset) -- one compare and branch per sample less */
+                if (IN4 || x < destw) {
+                    if constexpr (!S::IS_NES) col = (int) (cpos >> 32);
                     /* an upscaled line (w < destw) samples some source pixels twice: all 64 lanes are at the same
                      * column, so "same pixel as before" is a scalar branch that skips the fetch and the conversion */
                     if (col != have_col) {
@@ -469,8 +477,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         ire = clampi(ire, -127, 127);
                     }
                     tiles.put_byte(g, k, ire);
-                    col += qstep; err += rstep;
-                    if (err >= destw) { err -= destw; col++; }
+                    cpos += cstep;
                 } else {
                     tiles.put_byte(g, k, 0);
                 }

@@ -509,6 +509,23 @@ crthip_params_finalize(crthip_params *p)
     p->ire_base = d.black_level + p->black_point;
     p->dx = ((d.av_len - 1) << 12) / p->outw;
     p->ratio = (((p->outh << 16) / d.lines) + 32768) >> 16;
+    {   /* ceil(2^32 * w / destw) by long division (C89: no 64-bit type) */
+        unsigned dw = (unsigned) (p->destw > 0 ? p->destw : 1), r = (unsigned) p->w % dw, lo = 0;
+        int i;
+        p->col_step_hi = (unsigned) p->w / dw;
+        for (i = 0; i < 32; i++) {
+            r <<= 1;
+            lo <<= 1;
+            if (r >= dw) {
+                r -= dw;
+                lo |= 1u;
+            }
+        }
+        if (r != 0 && ++lo == 0) {
+            p->col_step_hi++;
+        }
+        p->col_step_lo = lo;
+    }
     p->bloom_max_e = (128 + (p->noise / 2)) * d.av_len;         /* crt_core.c:400 */
     if (p->bloom && p->bloom_max_e <= 0) {
         return CRTHIP_E_ARG;                                    /* the reference would divide by zero (:522) */
