@@ -109,6 +109,26 @@ __device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, 
     return r;
 }
 
+/* Tier 0, chroma: the equaliser input u = (s * wave) >> 9 is handed over as the product with the carrier pre-scaled by
+ * 2^7, ut = s * (wave << 7) = u * 2^16 + fraction, and every consumer takes its high word inside the subtraction it
+ * feeds (SDWA): the shift costs no instruction.  |wave| <= 65 532 in this tier, so wave << 7 is a 24-bit multiplier and
+ * |ut| < 2^31.  The 3-deep input history (crt_core.c:229-231) holds the products likewise. */
+template <int G2>
+__device__ __forceinline__ int eq_step64_chroma0(Eq64 &f, const int hfm, const int ut)
+{
+    f.hi0 = rearm(mad64(sub_hiword(ut, hi32(f.hi0)), hfm, f.hi0));
+    f.hi1 = rearm(mad64(hi32(f.hi0) - hi32(f.hi1), hfm, f.hi1));
+    f.hi2 = rearm(mad64(hi32(f.hi1) - hi32(f.hi2), hfm, f.hi2));
+    f.hi3 = rearm(mad64(hi32(f.hi2) - hi32(f.hi3), hfm, f.hi3));
+    const int hi3 = hi32(f.hi3);
+    int r = hi3;                                            /* low + mid band, see eq_step64 (LOSKIP) */
+    if (G2 != 0) {
+        r += __mul24(sub_hiword(f.h2, hi3), G2) >> 16;
+        f.h2 = f.h1; f.h1 = f.h0; f.h0 = ut;
+    }
+    return r;
+}
+
 /* eqf of a USE_CONVOLUTION build of the reference (crt_core.c:119-147): a symmetric FIR kernel over a 7-deep
  * input history.  The four kernels factor into running sums,
  *     4 taps  1 1 1 1        = box4
@@ -207,7 +227,9 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     s_nrows[lane] = nrows;
     wave_lds_fence();
 
-    const int w0 = lp.wave0, w1 = lp.wave1, nw0 = -lp.wave0, nw1 = -lp.wave1;
+    /* tier 0 multiplies by the carriers scaled by 2^7 (eq_step64_chroma0) */
+    constexpr int WSCALE = TIER == 0 ? 128 : 1;
+    const int w0 = lp.wave0 * WSCALE, w1 = lp.wave1 * WSCALE, nw0 = -lp.wave0 * WSCALE, nw1 = -lp.wave1 * WSCALE;
     const int bright = P.bright, contrast = P.contrast;
     const int ylf = P.eq_lf[0], yhf = P.eq_hf[0], ilf = P.eq_lf[1], ihf = P.eq_hf[1], qlf = P.eq_lf[2], qhf = P.eq_hf[2];
     const unsigned psel = pack_selector(P.out_format), usel = unpack_selector(P.out_format);
@@ -273,7 +295,11 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
                 const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
                 int cy, ci, cq;
-                if (TIER <= 1) {
+                if (TIER == 0) {
+                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
+                    ci = eq_step64_chroma0<1311>(wi_, ihfm, __mul24(s, wi)) >> 3;       /* wi, wq: carriers << 7 here */
+                    cq = eq_step64_chroma0<0>(wq_, qhfm, __mul24(s, wq)) >> 3;
+                } else if (TIER == 1) {
                     /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
                     cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
                     ci = eq_step64<false, 65536, 1311, LOSKIP>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;

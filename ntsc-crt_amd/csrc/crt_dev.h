@@ -295,6 +295,13 @@ __device__ __forceinline__ int add_hiword(int a, int b)
     asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+/* (a >> 16) - b, a taken as a signed 32-bit value */
+__device__ __forceinline__ int sub_hiword(int a, int b)
+{
+    int r;
+    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 /* (a >> 16) + (b >> 16), both taken as signed 32-bit values */
 __device__ __forceinline__ int add_hiwords(int a, int b)
 {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: tests/test_gpu_parity.py's random configurations (HIP vs oracle, bit-exact) over a seed range,
 also for the VHS / NES / FIR variants.  usage: tools/soak_random.py first_seed count"""
+# seeds alternate systems (NTSC, FIR builds, pattern 0, SNES, template, NES-RGB, PV-1000) and both kernel shapes
 import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ntsc-crt_amd"), ROOT):
@@ -13,13 +14,19 @@ bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     case = list(T._random_case(rng))
-    variant = seed % 4
+    variant = seed % 8
+    shape = 2 if seed & 16 else 1                     # both kernel shapes
     if variant == 1:
-        case[0] = "ntscfir%d" % (4 + seed % 4)
+        case[0] = "ntscfir%d" % (4 + (seed >> 3) % 4)
+        shape = 1                                     # the FIR decoder exists in the lane-per-scanline shape only
     elif variant == 2:
         case[0] = "ntscp0"
+    elif variant in (4, 5, 6, 7):                     # SURVEY 8(f) f4 systems
+        case[0] = ("snes", "temp", "nesrgb", "pv1k")[variant - 4]
+        if case[0] == "pv1k":
+            shape = 0                                 # 5 samples per chroma cycle: scanline-parallel decoder only
     try:
-        T._run_case(crtlib, tuple(case), fused=bool(seed & 8), steps=2, n=2)
+        T._run_case(crtlib, tuple(case), fused=bool(seed & 8), steps=2, n=2, shape=shape)
     except Exception as e:
         bad += 1
         print("SEED", seed, case[:8], "FAILED:", str(e).splitlines()[0][:200])
