@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ntsc-crt_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
+VALU_SIMDS = 1024             # 256 CUs x 4 SIMDs
+VALU_CLOCK_HZ = 2.4e9          # peak engine clock (MI355X_MICROARCH.md); the kernels run at 2.2-2.3 GHz (GRBM_GUI_ACTIVE / duration)
 
 
 def geometry(system, w, h, outw, outh, scanlines, bloom=False):
@@ -281,12 +283,28 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
     own_gbs = own[dom] * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
     traffic = None
-    if traffic_file and os.path.exists(traffic_file):        # PMC passes (tools/prof_pmc.sh) on this very workload
+    valu = None
+    if traffic_file and os.path.exists(traffic_file):        # PMC passes (tools/prof_bench.sh, prof_sq.sh) on this very workload
         try:
             tj = json.load(open(traffic_file))
             if tj.get("workload") == wl["name"]:
                 traffic = tj.get("k_" + dom + "_bytes_per_field")
                 traffic = traffic * n if traffic else None
+                # the vector-ALU side of the same kernels: wave64 instructions (SQ_INSTS_VALU from the committed counter
+                # passes) over the time measured HERE, against one instruction per 4 cycles and SIMD -- the rate these
+                # instruction mixes issue at on gfx950 (profiles/r02_valu_mixed_sequences.txt)
+                names = ("template", "active", "sync", "decode")
+                per = {k: tj.get("k_%s_valu_per_field" % k) for k in names}
+                if all(per.values()):
+                    peak = VALU_SIMDS * VALU_CLOCK_HZ / 4.0
+                    busy_ms = sum(kern_ms.get(k, 0.0) for k in names) + kern_ms.get("noise", 0.0)
+                    valu = {"wave_instr_per_field": sum(per.values()),
+                            "kernel": {k: {"wave_instr_per_field": per[k],
+                                           "achieved": per[k] * n / (kern_ms[k] * 1e-3) / 1e9 if kern_ms.get(k) else None}
+                                       for k in names},
+                            "achieved": sum(per.values()) * n / (busy_ms * 1e-3) / 1e9, "peak": peak / 1e9,
+                            "unit": "G wave64 instr/s", "frac": sum(per.values()) * n / (busy_ms * 1e-3) / peak,
+                            "peak_is": "%d SIMDs x %.1f GHz / 4 cycles per instruction" % (VALU_SIMDS, VALU_CLOCK_HZ / 1e9)}
         except Exception:
             traffic = None
     rec = {
@@ -300,6 +318,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                      # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
+                     "valu": valu,
                      "algorithmic_bytes_per_field": abytes,
                      "kernel_ms": kern_ms,
                      # the dominant kernel on the bytes it moves itself

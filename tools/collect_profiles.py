@@ -39,6 +39,22 @@ def per_field(*prefixes):
 
 
 total = sum(d["hbm_bytes_per_field"] for d in out.values())
+
+# SQ counter passes (tools/prof_sq.sh), if they were run for this tag
+sq = os.path.join(root, "gpurun_out", "sq_" + tag)
+sqagg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+if os.path.isdir(sq):
+    for f in glob.glob(sq + "/p*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void k_"):
+                a = sqagg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+
+
+def valu_per_field(*prefixes):
+    v = sum(d["SQ_INSTS_VALU"][0] / d["SQ_INSTS_VALU"][1] for k, d in sqagg.items()
+            if any(k.startswith("void " + p) for p in prefixes) and "SQ_INSTS_VALU" in d)
+    return v / fields if v else None
 json.dump({"bench": bench_cmd, "fields_per_launch": fields,
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (raw counter = KB); HBM bytes per field = "
                      "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / fields: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
@@ -50,21 +66,18 @@ if workload:
                "k_decode_bytes_per_field": per_field("k_decode"), "k_active_bytes_per_field": per_field("k_active"),
                "k_template_bytes_per_field": per_field("k_margin", "k_skeleton", "k_template"),
                "k_sync_bytes_per_field": per_field("k_hsync", "k_vsync", "k_bloom"),
-               "all_kernels_bytes_per_field": total},
+               "all_kernels_bytes_per_field": total,
+               # wave64 vector instructions per field (SQ_INSTS_VALU), for bench.py's roofline.valu
+               "k_decode_valu_per_field": valu_per_field("k_decode"), "k_active_valu_per_field": valu_per_field("k_active"),
+               "k_template_valu_per_field": valu_per_field("k_margin", "k_skeleton", "k_template"),
+               "k_sync_valu_per_field": valu_per_field("k_hsync", "k_vsync", "k_bloom")},
               open(os.path.join(dst, "traffic.json" if workload == "headline" else "traffic_%s.json" % workload), "w"), indent=1)
 
-sq = os.path.join(root, "gpurun_out", "sq_" + tag)
-if os.path.isdir(sq):
-    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-    for f in glob.glob(sq + "/p*/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
-            if k.startswith("void k_"):
-                a = agg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+if sqagg:
     json.dump({"bench": bench_cmd, "fields_per_launch": fields,
                "note": "rocprofv3 --pmc SQ counters per launch, 3 separate passes (tools/prof_sq.sh); SQ_*_CYCLES / "
                        "SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)",
-               "kernels": {k: {c: v / n_ for c, (v, n_) in d.items()} for k, d in agg.items()}},
+               "kernels": {k: {c: v / n_ for c, (v, n_) in d.items()} for k, d in sqagg.items()}},
               open(os.path.join(dst, name + "_sq_counters.json"), "w"), indent=1)
 print("HBM bytes per field, all kernels: %.0f" % total)
 for k, d in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_field"])[:6]:
