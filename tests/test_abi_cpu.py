@@ -114,6 +114,22 @@ def test_host_setup_matches_oracle(lib, name):
     assert p.dx == ((orc.av_len - 1) << 12) // 832
 
 
+@pytest.mark.parametrize("name", ["ntsc", "vhs", "snes", "pv1k", "temp", "nesrgb"])
+def test_source_column_step_is_exact(lib, name):
+    """crthip_params.col_step: the encoder's source column (x * w) / destw (crt_ntsc.c:272) as the high word of a running
+    64-bit sum, one add per sample -- checked for every sample of odd, tiny and huge image widths, raw mode included"""
+    for w in (1, 2, 3, 7, 16, 64, 255, 256, 320, 639, 640, 641, 753, 754, 832, 1283, 1920, 4096, 16383):
+        for raw in (0, 1):
+            p = lib.make_params(name, w=w, h=32, outw=640, outh=480, raw=raw)
+            step = (p.col_step_hi << 32) | p.col_step_lo
+            destw = p.destw
+            assert destw > 0 and step == -((-(w << 32)) // destw)            # ceil(2^32 * w / destw)
+            pos = 0
+            for x in range(destw + 3):                                       # the tiled path runs up to 3 samples over
+                assert pos >> 32 == (x * w) // destw, (w, raw, x)
+                pos += step
+
+
 def test_fir_flag_is_validated_by_finalize(lib):
     """CRTHIP_F_EQ_FIR(taps): 0 (stock equaliser) and the four kernels of crt_core.c:130-147 only"""
     for taps in (0, 4, 5, 6, 7):
