@@ -39,7 +39,73 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
-/* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR */
+/* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR.  Wave-wide: all 2 * VWIN candidate lines
+ * are fetched up front, then searched in order with a prefix sum across the wave.  Returns the line found (the last
+ * candidate if none) and j (HRES if none), the same in every lane. */
+template <class S>
+__device__ __forceinline__ void vsync_search(const signed char *__restrict__ in, const int vsync, const int lane, int &vline, int &vj)
+{
+    vline = 0; vj = S::HRES;
+    constexpr int PIECES = (S::HRES + 1023) / 1024;      /* 64 lanes x 16 samples per piece; 2 pieces for the PV-1000's 1920 */
+    constexpr int GROUP = PIECES > 1 ? S::VWIN : 2 * S::VWIN;   /* candidate lines in flight at once (register budget) */
+    bool found = false;
+#pragma unroll
+    for (int g0 = 0; g0 < 2 * S::VWIN; g0 += GROUP) {
+        if (found) break;
+        v4i cand[GROUP][PIECES];
+#pragma unroll
+        for (int i = 0; i < GROUP; i++) {
+            const int l = posmod(vsync + g0 + i - S::VWIN, S::VRES);
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) cand[i][pc] = load16u(in + l * S::HRES + pc * 1024 + lane * 16);
+        }
+        /* all of them in flight together: without this the compiler sinks each load into the conditional block that
+         * uses it, one memory round trip per candidate line (13 in a row in the steady state) */
+#pragma unroll
+        for (int i = 0; i < GROUP; i++) {
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) asm volatile("" : "+v"(cand[i][pc]));
+        }
+#pragma unroll
+        for (int i = 0; i < GROUP; i++) {
+            int carry = 0;                                   /* sum of the line's earlier pieces */
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) {
+                if (!found) {
+                    vline = posmod(vsync + g0 + i - S::VWIN, S::VRES);
+                    const int wds[4] = { cand[i][pc].x, cand[i][pc].y, cand[i][pc].z, cand[i][pc].w };
+                    const int s0 = pc * 1024 + lane * 16;
+                    int pre[16];
+                    int run = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
+                        if (s0 + k >= S::HRES) s = 0;
+                        run += s;
+                        pre[k] = run;
+                    }
+                    const int incl = wave_incl_scan(run);
+                    const int excl = carry + incl - run;
+                    int first = 16;
+#pragma unroll
+                    for (int k = 15; k >= 0; k--) {
+                        if (s0 + k < S::HRES && excl + pre[k] <= S::VTHR) first = k;
+                    }
+                    const unsigned long long m = __ballot(first < 16);
+                    if (m) {
+                        const int L = __ffsll((long long) m) - 1;
+                        vj = pc * 1024 + L * 16 + __builtin_amdgcn_readlane(first, L);
+                        found = true;
+                    }
+                    carry += __builtin_amdgcn_readlane(incl, 63);
+                }
+            }
+        }
+    }
+    if (!found) vj = S::HRES;
+}
+
+/* D2 as a kernel of its own (the 16-lanes-per-field k_hsync needs it; k_hsync_wave searches for itself) */
 template <class S>
 __global__ void __launch_bounds__(64)
 k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
@@ -48,55 +114,9 @@ k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthi
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     if (f >= n_fields) return;
-    const signed char *in = inp + (size_t) f * fstride;
     crthip_state *st = state + f;
-    const int vsync = st->vsync;
-    int vline = 0, vj = S::HRES;
-    constexpr int PIECES = (S::HRES + 1023) / 1024;      /* 64 lanes x 16 samples per piece; 2 pieces for the PV-1000's 1920 */
-    v4i cand[2 * S::VWIN][PIECES];
-#pragma unroll
-    for (int i = 0; i < 2 * S::VWIN; i++) {
-        const int l = posmod(vsync + i - S::VWIN, S::VRES);
-#pragma unroll
-        for (int pc = 0; pc < PIECES; pc++) cand[i][pc] = load16u(in + l * S::HRES + pc * 1024 + lane * 16);
-    }
-    bool found = false;
-#pragma unroll
-    for (int i = 0; i < 2 * S::VWIN; i++) {
-        int carry = 0;                                   /* sum of the line's earlier pieces */
-#pragma unroll
-        for (int pc = 0; pc < PIECES; pc++) {
-            if (!found) {
-                vline = posmod(vsync + i - S::VWIN, S::VRES);
-                const int wds[4] = { cand[i][pc].x, cand[i][pc].y, cand[i][pc].z, cand[i][pc].w };
-                const int s0 = pc * 1024 + lane * 16;
-                int pre[16];
-                int run = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
-                    if (s0 + k >= S::HRES) s = 0;
-                    run += s;
-                    pre[k] = run;
-                }
-                const int incl = wave_incl_scan(run);
-                const int excl = carry + incl - run;
-                int first = 16;
-#pragma unroll
-                for (int k = 15; k >= 0; k--) {
-                    if (s0 + k < S::HRES && excl + pre[k] <= S::VTHR) first = k;
-                }
-                const unsigned long long m = __ballot(first < 16);
-                if (m) {
-                    const int L = __ffsll((long long) m) - 1;
-                    vj = pc * 1024 + L * 16 + __builtin_amdgcn_readlane(first, L);
-                    found = true;
-                }
-                carry += __builtin_amdgcn_readlane(incl, 63);
-            }
-        }
-    }
-    if (!found) vj = S::HRES;
+    int vline, vj;
+    vsync_search<S>(inp + (size_t) f * fstride, st->vsync, lane, vline, vj);
     if (lane == 0) {
         st->vsync = vline;
         st->odd_field = vj > S::HRES / 2;
@@ -382,7 +402,7 @@ __device__ __forceinline__ int burst_step(int acc, int s)
 template <class S, int FPB>
 __global__ void __launch_bounds__(64 * FPB, 4)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-             crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
+             crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn)
 {
     constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS, VPER = S::VPER;
     constexpr int WOFF = S::SYNC_BEG - S::HWIN;          /* first byte of the search window relative to ln + hsync */
@@ -407,8 +427,18 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     const signed char *in = inp + (size_t) f * fstride;
     crthip_state *st = state + f;
     int hsync = __builtin_amdgcn_readfirstlane(st->hsync);
-    const int vsync = __builtin_amdgcn_readfirstlane(st->vsync);
-    const int field_rows = __builtin_amdgcn_readfirstlane(st->odd_field) * (P.ratio / 2);      /* crt_core.c:407 */
+    /* D2: the vertical sync search of this field, by the field's own wave (one launch and one trip through memory less
+     * than a kernel of its own; what a single field-pass costs is mostly this chain's latency) */
+    int vsync, vj_;
+    vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
+    vsync = __builtin_amdgcn_readfirstlane(vsync);
+    const int odd_field = __builtin_amdgcn_readfirstlane(vj_) > S::HRES / 2;
+    if (live && lane == 0) {
+        st->vsync = vsync;
+        st->odd_field = odd_field;
+        if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
+    }
+    const int field_rows = odd_field * (P.ratio / 2);                                          /* crt_core.c:407 */
     const unsigned span = (unsigned) P.outh + P.v_fac;
     crthip_line *out_lines = lines + (size_t) f * S::LINES;
 
@@ -729,17 +759,21 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
-        hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
+        const bool legacy = c->legacy_sync || c->sync_kernel == 1;
+        if (legacy)
+            hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
         /* k_hsync (16 lanes per field) is kept for A/B measurements (CRTHIP_SYNC_KERNEL=1): the wave-per-field kernel
          * is faster at every batch size measured (profiles/r02_shape_sweep.txt, rows L against A).
          * CRTHIP_SYNC_KERNEL=2 / 3 force 1 / 4 fields per workgroup */
         constexpr bool FPB4_OK = 64 / (S::VPER * S::CCS) >= 4;
-        if (c->legacy_sync || c->sync_kernel == 1)
+        if (legacy)
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         else if (FPB4_OK && c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3))        /* 4 fields per workgroup share one wave for their burst chains */
-            hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+            hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                               c->whole_field, advance_rn);
         else
-            hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
+            hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                               c->whole_field, advance_rn);
         if (p->bloom)
             hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;
