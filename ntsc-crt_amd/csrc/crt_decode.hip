@@ -455,7 +455,6 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
      * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
     const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
     const bool wide = c->px_tile ? c->px_tile >= 32 : p->outw >= 1280;
-    const bool wide64 = c->px_tile == 64;            /* 256-byte store runs per row (tier 0, 4-byte pixels only): an experiment switch */
     /* lines per output row when the picture is shorter than the raster: one pass per rank */
     const unsigned span = (unsigned) p->outh + p->v_fac;
     const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
@@ -470,8 +469,7 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_DECODE(T, B3) \
-    do { if (wide64 && T == 0 && !B3) hipLaunchKernelGGL((k_decode<S, 0, false, 64>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
-         else if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
+    do { if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
          else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); } while (0)
             /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */
             if (p->out_bpp == 3) {

@@ -514,9 +514,9 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
 
 int crthip_set_pixel_tile(crthip_ctx *c, int px)
 {
-    if (!c || (px != 0 && px != 16 && px != 32 && px != 64)) return CRTHIP_E_ARG;
+    if (!c || (px != 0 && px != 16 && px != 32)) return CRTHIP_E_ARG;
     c->px_tile = px;
-    c->ac_tile = px == 64 ? 32 : px;
+    c->ac_tile = px;
     return CRTHIP_OK;
 }
 
