@@ -387,6 +387,7 @@ struct crthip_ctx {
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
     int vhs_chunks;
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
+    unsigned *d_vhs_next;       /* VHS: where k_vhs_tail leaves the histories while k_vhs_noise still reads the old ones */
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
     int ac_tile;                /* encoder tile, same convention, by input width */
     int ac_tile_env;            /* CRTHIP_AC_TILE: overrides both (A/B measurements) */
@@ -481,6 +482,22 @@ struct ProfScope {
     }
 };
 
+
+/* the internal second stream and its fork / join events (created on first use) */
+static inline int crt_ensure_aux(crthip_ctx *c)
+{
+    if (c->aux_stream) return CRTHIP_OK;
+    /* highest priority: what runs here are short latency-bound kernels beside a wide one on the caller's stream, and they
+     * only help if their workgroups are dispatched at once instead of queueing behind the wide kernel's */
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { c->aux_stream = nullptr; return CRTHIP_E_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return CRTHIP_E_HIP;
+    for (int k = 0; k < CRTHIP_MAX_CHUNKS; k++)
+        if (hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming) != hipSuccess) return CRTHIP_E_HIP;
+    return CRTHIP_OK;
+}
 
 /* launch entry points of the other translation units (enqueue on c->stream; no synchronisation) */
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,

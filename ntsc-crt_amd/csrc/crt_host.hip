@@ -263,6 +263,7 @@ void crthip_destroy(crthip_ctx *c)
     }
     if (c->d_jump16) hipFree(c->d_jump16);
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
+    if (c->d_vhs_next) hipFree(c->d_vhs_next);
     if (c->d_seq) hipFree(c->d_seq);
     if (c->d_nes_tab) hipFree(c->d_nes_tab);
     if (c->d_skel) hipFree(c->d_skel);
@@ -301,12 +302,16 @@ int crthip_reserve(crthip_ctx *c, int n)
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
-    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->cap_fields = 0;
+    if (c->d_vhs_next) hipFree(c->d_vhs_next);
+    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->d_vhs_next = 0; c->cap_fields = 0;
     const size_t bytes = c->fstride * (size_t) n + 4096;
     if (hipMalloc((void **) &c->d_inp, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc inp", hipSuccess);
     if (hipMalloc((void **) &c->d_analog, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc analog", hipSuccess);
     if (hipMalloc((void **) &c->d_lines, sizeof(crthip_line) * (size_t) n * c->sd.lines) != hipSuccess)
         return set_err(c, CRTHIP_E_NOMEM, "hipMalloc lines", hipSuccess);
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS &&
+        hipMalloc((void **) &c->d_vhs_next, sizeof(unsigned) * 32 * (size_t) n) != hipSuccess)
+        return set_err(c, CRTHIP_E_NOMEM, "hipMalloc VHS histories", hipSuccess);
     HIPCHK(c, hipMemsetAsync(c->d_inp, 0, bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_analog, 0, bytes, c->stream));
     c->cap_fields = n;
@@ -481,12 +486,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
          * While decoder k streams its picture out (HBM-write bound at 1080p), the vector-bound encoder of chunk k+1
          * and the latency-bound sync chain run beside it.  (Alternating whole chunks between two streams, the first
          * version of this, ends up running decoder next to decoder: profiles/r02_overlap_timeline_1080p.txt.) */
-        if (!c->aux_stream) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-            for (int k = 0; k < CRTHIP_MAX_CHUNKS; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
-        }
+        if (crt_ensure_aux(c) != CRTHIP_OK) return set_err(c, CRTHIP_E_HIP, "internal stream", hipGetLastError());
         hipStream_t main_stream = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
         HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));

@@ -174,7 +174,7 @@ template <class S>
 __global__ void __launch_bounds__(64)
 k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
            signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
-           unsigned *__restrict__ hist, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows)
+           const unsigned *hist, unsigned *hist_out, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows)
 {
     constexpr int N = S::INPUT_SIZE, H = S::HRES, B = VHS_BLK;
     constexpr int T0 = vhs_tail_start(N, H);
@@ -187,7 +187,10 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     if (f >= n_fields) return;
-    unsigned *h = hist + (size_t) f * 32;
+    /* one wave per field and a long dependent chain: when it shares a SIMD with the parallel region's waves (see
+     * crt_run_noise) it should win the instruction arbitration, or its latency is multiplied by the occupancy */
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned *h = hist + (size_t) f * 32;
     const signed char *src = analog + (size_t) f * fstride;
     signed char *dst = inp + (size_t) f * fstride;
     const int noise = P.noise;
@@ -332,7 +335,9 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
         __syncthreads();
         seg_start += n_s;
     }
-    if (lane < 31) h[lane] = s_h[lane];                            /* the generator's state after the field */
+    /* the generator's state after the field (word 31 of a slot is padding: carried over, so that hist_out can be a
+     * side buffer that is copied back whole) */
+    if (lane < 32) hist_out[(size_t) f * 32 + lane] = lane < 31 ? s_h[lane] : h[31];
     if (lane == 0) {
         state[f].rn = (int) s_misc[1];                             /* crt_core.c:367 */
         signed char *tail = dst + N;
@@ -507,12 +512,35 @@ int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed cha
             using S = decltype(tag);
             ProfScope ps(c, CRTHIP_K_NOISE);
             if constexpr (S::IS_VHS) {
-                /* the tail kernel rewrites the histories the parallel region reads: stream order keeps them apart */
-                hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, c->stream,
+                /* The parallel region (throughput bound) and the tail (one wave per field, pure latency) write disjoint
+                 * parts of the field and both start from the field's generator history, which the tail also advances:
+                 * it leaves the new history in a side buffer, runs on the internal stream BESIDE the parallel region,
+                 * and a copy after the join publishes the histories.  (Without the internal stream: one after the
+                 * other, in place.) */
+                const bool side = c->d_vhs_next && n <= c->cap_fields && crt_ensure_aux(c) == CRTHIP_OK && c->stream != c->aux_stream &&
+                                  hipEventRecord(c->ev_fork, c->stream) == hipSuccess &&
+                                  hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0) == hipSuccess;
+                /* The tail goes first and on the caller's stream, the parallel region on the internal one: behind its event
+                 * wait it starts a few microseconds later, by when the tail's lone waves are resident.  The other way
+                 * round the tail's workgroups queue behind the parallel region's 60 000 and run when those are done
+                 * (measured: 1.06 ms side by side = 0.51 + 0.55 one after the other). */
+                hipStream_t ns = side ? c->aux_stream : c->stream;
+                if (side)
+                    hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
+                                       *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_next,
+                                       c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
+                hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, ns,
                                    *p, n, d_analog, d_inp, c->fstride, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks);
-                hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
-                                   *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist,
-                                   c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
+                if (!side)
+                    hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
+                                       *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_hist,
+                                       c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
+                if (side) {
+                    if (hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess ||
+                        hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess ||
+                        hipMemcpyAsync(c->d_vhs_hist, c->d_vhs_next, sizeof(unsigned) * 32 * (size_t) n, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                        return CRTHIP_E_HIP;
+                }
             }
             return CRTHIP_OK;
         });
