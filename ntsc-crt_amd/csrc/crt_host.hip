@@ -334,6 +334,8 @@ static int check_params(crthip_ctx *c, const crthip_params *p, int n)
 static int check_encoder(crthip_ctx *c, const crthip_params *p)
 {
     if (c->system != CRTHIP_SYSTEM_NES && p->in_bpp == 0) return 1;   /* silent no-op, crt_ntsc.c:190-193 */
+    if (p->col_step_hi == 0 && p->col_step_lo == 0)                    /* ceil(2^32 * w / destw) is never 0 */
+        return set_err(c, CRTHIP_E_ARG, "params were finalized by an older library (no col_step): call crthip_params_finalize again", hipSuccess);
     const long long end = (long long) p->yo * c->sd.hres + p->xo + (long long) (p->desth - 1) * c->sd.hres + p->destw;
     if (p->xo < 0 || p->yo < 0 || p->destw <= 0 || p->desth <= 0 || p->destw > c->sd.hres || end > c->sd.input_size)
         return set_err(c, CRTHIP_E_ARG, "active rectangle leaves analog[] (xoffset/yoffset out of contract)", hipSuccess);
