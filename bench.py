@@ -335,6 +335,8 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
         rec["cpu_baseline"] = cpu_baseline(system + ("fir%d" % fir if fir else ""), w, h, outw, outh, noise, scanlines, cpu_seconds,
                                            all_cores=wl.get("cpu_all_cores", False))
         rec["gpu_over_cpu"] = fps / rec["cpu_baseline"]["value"]
+        if rec["cpu_baseline"].get("all_cores", {}).get("value"):
+            rec["gpu_over_cpu_all_cores"] = fps / rec["cpu_baseline"]["all_cores"]["value"]
     return rec
 
 
