@@ -459,7 +459,7 @@ def main():
             "config": rec["config"], "roofline": rec["roofline"],
             "world_size": world, "world_size_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
         }
-        for k in ("settings_blob_crc32_per_rank", "cpu_baseline", "gpu_over_cpu"):
+        for k in ("settings_blob_crc32_per_rank", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
             if k in rec:
                 out[k] = rec[k]
         if extras:
