@@ -109,19 +109,32 @@ __device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, 
     return r;
 }
 
-/* Tier 0, chroma: the equaliser input u = (s * wave) >> 9 is handed over as the product with the carrier pre-scaled by
- * 2^7, ut = s * (wave << 7) = u * 2^16 + fraction, and every consumer takes its high word inside the subtraction it
- * feeds (SDWA): the shift costs no instruction.  |wave| <= 65 532 in this tier, so wave << 7 is a 24-bit multiplier and
- * |ut| < 2^31.  The 3-deep input history (crt_core.c:229-231) holds the products likewise. */
-template <int G2>
-__device__ __forceinline__ int eq_step64_chroma0(Eq64 &f, const int hfm, const int ut)
+/* Tiers 0 and 1, chroma: the equaliser input u = (s * wave) >> 9 is handed over as the product with the carrier pre-scaled
+ * by 2^7, ut = s * (wave << 7) = u * 2^16 + fraction, and every consumer takes its high word inside the subtraction it
+ * feeds (SDWA): the shift costs no instruction.  |ut| <= 127 * 120 000 * 128 < 2^31 in these tiers; in tier 0
+ * (|wave| <= 65 532) wave << 7 is still a 24-bit multiplier.  The 3-deep input history (crt_core.c:229-231) holds the
+ * products likewise.  LO = with the low cascade (tier 1; see eq_step64 for when it can be dropped). */
+template <bool LO, int G2>
+__device__ __forceinline__ int eq_step64_chroma(Eq64 &f, const int lfm, const int hfm, const int ut)
 {
+    if (LO) {
+        f.lo0 = rearm(mad64(sub_hiword(ut, hi32(f.lo0)), lfm, f.lo0));
+        f.lo1 = rearm(mad64(hi32(f.lo0) - hi32(f.lo1), lfm, f.lo1));
+        f.lo2 = rearm(mad64(hi32(f.lo1) - hi32(f.lo2), lfm, f.lo2));
+        f.lo3 = rearm(mad64(hi32(f.lo2) - hi32(f.lo3), lfm, f.lo3));
+    }
     f.hi0 = rearm(mad64(sub_hiword(ut, hi32(f.hi0)), hfm, f.hi0));
     f.hi1 = rearm(mad64(hi32(f.hi0) - hi32(f.hi1), hfm, f.hi1));
     f.hi2 = rearm(mad64(hi32(f.hi1) - hi32(f.hi2), hfm, f.hi2));
     f.hi3 = rearm(mad64(hi32(f.hi2) - hi32(f.hi3), hfm, f.hi3));
     const int hi3 = hi32(f.hi3);
-    int r = hi3;                                            /* low + mid band, see eq_step64 (LOSKIP) */
+    int r;
+    if (LO) {                                               /* gains 65536, 65536: sign-extended low halves (crt_core.c:203-206) */
+        const int lo3 = hi32(f.lo3);
+        r = ((lo3 * 65536) >> 16) + (((hi3 - lo3) * 65536) >> 16);
+    } else {
+        r = hi3;                                            /* low + mid band, see eq_step64 (LOSKIP) */
+    }
     if (G2 != 0) {
         r += __mul24(sub_hiword(f.h2, hi3), G2) >> 16;
         f.h2 = f.h1; f.h1 = f.h0; f.h0 = ut;
@@ -227,8 +240,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     s_nrows[lane] = nrows;
     wave_lds_fence();
 
-    /* tier 0 multiplies by the carriers scaled by 2^7 (eq_step64_chroma0) */
-    constexpr int WSCALE = TIER == 0 ? 128 : 1;
+    /* tiers 0 and 1 multiply by the carriers scaled by 2^7 (eq_step64_chroma) */
+    constexpr int WSCALE = TIER <= 1 ? 128 : 1;
     const int w0 = lp.wave0 * WSCALE, w1 = lp.wave1 * WSCALE, nw0 = -lp.wave0 * WSCALE, nw1 = -lp.wave1 * WSCALE;
     const int bright = P.bright, contrast = P.contrast;
     const int ylf = P.eq_lf[0], yhf = P.eq_hf[0], ilf = P.eq_lf[1], ihf = P.eq_hf[1], qlf = P.eq_lf[2], qhf = P.eq_hf[2];
@@ -296,14 +309,14 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
                 int cy, ci, cq;
                 if (TIER == 0) {
-                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
-                    ci = eq_step64_chroma0<1311>(wi_, ihfm, __mul24(s, wi)) >> 3;       /* wi, wq: carriers << 7 here */
-                    cq = eq_step64_chroma0<0>(wq_, qhfm, __mul24(s, wq)) >> 3;
-                } else if (TIER == 1) {
                     /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
                     cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
-                    ci = eq_step64<false, 65536, 1311, LOSKIP>(wi_, ilfm, ihfm, pair_of(mulq<true>(s, wi) >> 9)) >> 3;
-                    cq = eq_step64<false, 65536, 0, LOSKIP>(wq_, qlfm, qhfm, pair_of(mulq<true>(s, wq) >> 9)) >> 3;
+                    ci = eq_step64_chroma<false, 1311>(wi_, ilfm, ihfm, __mul24(s, wi)) >> 3;   /* wi, wq: carriers << 7 here */
+                    cq = eq_step64_chroma<false, 0>(wq_, qlfm, qhfm, __mul24(s, wq)) >> 3;
+                } else if (TIER == 1) {
+                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
+                    ci = eq_step64_chroma<true, 1311>(wi_, ilfm, ihfm, s * wi) >> 3;            /* 32-bit product: |wi| < 2^24 */
+                    cq = eq_step64_chroma<true, 0>(wq_, qlfm, qhfm, s * wq) >> 3;
                 } else if (FIR) {
                     const int uy = s + bright, ui = mulq<FAST>(s, wi) >> 9, uq = mulq<FAST>(s, wq) >> 9;
 #define CRT_FIR3(M) do { cy = fir_step<M>(fy, uy, k) << 4; ci = fir_step<M>(fi, ui, k) >> 3; cq = fir_step<M>(fq, uq, k) >> 3; } while (0)
