@@ -768,12 +768,19 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         constexpr bool FPB4_OK = 64 / (S::VPER * S::CCS) >= 4;
         if (legacy)
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
-        else if (FPB4_OK && c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3))        /* 4 fields per workgroup share one wave for their burst chains */
-            hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                               c->whole_field, advance_rn);
-        else
-            hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                               c->whole_field, advance_rn);
+        else {
+            bool done = false;
+            if constexpr (FPB4_OK) {                     /* 4 fields per workgroup share one wave for their burst chains */
+                if (c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {
+                    hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                                       c->whole_field, advance_rn);
+                    done = true;
+                }
+            }
+            if (!done)
+                hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                                   c->whole_field, advance_rn);
+        }
         if (p->bloom)
             hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;
