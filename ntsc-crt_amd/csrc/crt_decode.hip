@@ -204,7 +204,6 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
          int want_rank)
 {
     constexpr bool FAST = TIER <= 2 || TIER == 4;   /* 24-bit multiplies outside the filter stages */
-    constexpr bool LOSKIP = TIER == 0;
     constexpr bool FIR = TIER >= 4;
     constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
     __shared__ unsigned s_in[64 * IN_STRIDE];
