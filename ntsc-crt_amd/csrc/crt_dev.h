@@ -332,9 +332,8 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
 
 /* fields per launch up to which the scanline-parallel kernel shapes are chosen automatically: lane-per-scanline needs
  * n * 240 / 64 wavefronts >= a few per SIMD (1024 SIMDs) to hide its serial chains.  Measured crossovers
- * (profiles/r02_shape_sweep.txt): decoders between 128 and 256 fields; the encoders draw at 512 (0.223 vs 0.226 ms), but
- * behind the row-shaped encoder the lane-shaped decoder loses the L2 locality it has behind its lane-shaped twin (same
- * 64-scanline workgroups, same block numbering, hence the same XCD): 0.40 instead of 0.32 ms at 512 fields */
+ * (profiles/r02_shape_sweep.txt): decoders between 128 and 256 fields, encoders between 256 and 512 (a field-pass of
+ * 512 fields: 0.672 ms with the lane-shaped encoder, 0.734 with the row-shaped one) */
 #define ROWS_SHAPE_MAX_FIELDS 128          /* k_decode_row */
 #define ROWS_SHAPE_MAX_FIELDS_ENC 256      /* k_active_row */
 
