@@ -377,7 +377,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
          * (|c*(s-h)| < 2^31: |s-h| <= 2*1275, c <= 2048).  Which form a channel takes is a property of the system
          * (IIR_Y_NEAR), checked against the actual coefficients at launch. */
         constexpr bool I64 = FAST && IN4 && S::BANDLIMIT;
-        const int my_ = (S::IIR_Y_NEAR ? cy_ - 2048 : cy_) << 21, mi_ = ci_ << 21, mq_ = cq_ << 21;
+        const int my_ = (S::IIR_Y_NEAR ? cy_ - 2048 : cy_) * (1 << 21), mi_ = ci_ * (1 << 21), mq_ = cq_ * (1 << 21);   /* (may be negative: no <<) */
         long hyp = 0, hip = 0, hqp = 0, fyp = 0;                   /* state (and the luma input) in the high halves */
         constexpr long HI_HALF = (long) 0xffffffff00000000ul;
 
@@ -385,7 +385,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         /* loop invariants the compiler would otherwise re-materialise per sample (constant-bus limit of VOP3) */
         int neg_noise127 = -0x7f * noise;
         asm volatile("" : "+v"(neg_noise127));
-        int neg_noise127_256 = -0x7f * noise * 256, ire_base_1024 = ire_base << 10;
+        int neg_noise127_256 = -0x7f * noise * 256, ire_base_1024 = ire_base * 1024;
         asm volatile("" : "+v"(neg_noise127_256));
         asm volatile("" : "+v"(ire_base_1024));
         const int noise256 = noise * 256;
