@@ -242,6 +242,19 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     /* tiers 0 and 1 multiply by the carriers scaled by 2^7 (eq_step64_chroma) */
     constexpr int WSCALE = TIER <= 1 ? 128 : 1;
     const int w0 = lp.wave0 * WSCALE, w1 = lp.wave1 * WSCALE, nw0 = -lp.wave0 * WSCALE, nw1 = -lp.wave1 * WSCALE;
+    /* 5 samples per chroma cycle (PV-1000, crt_core.c:497-505, 544-549): the line table carries dci / dcq, the carriers
+     * of the five sample phases follow from them with the blob's cos / sin tables; the phase of a sample is wave-uniform */
+    int w5i[5] = { 0, 0, 0, 0, 0 }, w5q[5] = { 0, 0, 0, 0, 0 };
+    if constexpr (S::CCS == 5) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            w5i[i] = ((lp.wave0 * P.dem_cs[0][i] + lp.wave1 * P.dem_sn[0][i]) >> 15) * P.saturation;
+            w5q[i] = ((lp.wave0 * P.dem_cs[1][i] + lp.wave1 * P.dem_sn[1][i]) >> 15) * P.saturation;
+        }
+    }
+    int ph5 = 0;                                   /* sample index % 5 */
+    /* luma band gains of the build, crt_core.c:272-286 */
+    constexpr int GY1 = S::CCS == 5 ? 12192 : 8192, GY2 = S::CCS == 5 ? 7775 : 9175;
     const int bright = P.bright, contrast = P.contrast;
     const int ylf = P.eq_lf[0], yhf = P.eq_hf[0], ilf = P.eq_lf[1], ihf = P.eq_hf[1], qlf = P.eq_lf[2], qhf = P.eq_hf[2];
     const unsigned psel = pack_selector(P.out_format), usel = unpack_selector(P.out_format);
@@ -304,8 +317,13 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 const int x = xq * 4 + k;
                 const int s = (word << (24 - 8 * k)) >> 24;
                 /* D8, crt_core.c:539-543; wave[] = {w0, w1, -w0, -w1}: I uses wave[x&3], Q wave[(x+3)&3] */
-                const int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
-                const int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
+                int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
+                int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
+                if constexpr (S::CCS == 5) {
+                    wi = ph5 == 0 ? w5i[0] : ph5 == 1 ? w5i[1] : ph5 == 2 ? w5i[2] : ph5 == 3 ? w5i[3] : w5i[4];
+                    wq = ph5 == 0 ? w5q[0] : ph5 == 1 ? w5q[1] : ph5 == 2 ? w5q[2] : ph5 == 3 ? w5q[3] : w5q[4];
+                    ph5 = ph5 == 4 ? 0 : ph5 + 1;
+                }
                 int cy, ci, cq;
                 if (TIER == 0) {
                     /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
@@ -322,7 +340,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     if (fir_m == 3) CRT_FIR3(3); else if (fir_m == 2) CRT_FIR3(2); else if (fir_m == 1) CRT_FIR3(1); else CRT_FIR3(0);
 #undef CRT_FIR3
                 } else {
-                    cy = eq_step<FAST, 8192, 9175>(ey, ylf, yhf, s + bright) << 4;
+                    cy = eq_step<FAST, GY1, GY2>(ey, ylf, yhf, s + bright) << 4;
                     ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
                     cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
                 }
@@ -445,7 +463,7 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 {
     const int b = p->bright < 0 ? -p->bright : p->bright;
     const int ct = p->contrast < 0 ? -p->contrast : p->contrast;
-    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23)) return 3;
+    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23) || c->sd.cc_samples != 4) return 3;   /* 5-sample system: exact kernel only */
     const bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
                          p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
                          p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
@@ -458,9 +476,21 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
 {
     if (p->dx <= 0)     /* more than 4096 output pixels per sample: the resampler's step (crt_core.c:528) rounds to 0 */
         return set_err(c, CRTHIP_E_ARG, "outw too large for the 12-bit resampler (dx == 0)", hipSuccess);
-    /* kernel shape (crthip_set_shape): bloom and the 5-sample system have per-scanline resampler geometry / carrier
-     * tables and only exist in the scanline-parallel shape; the FIR build only in the lane-per-scanline shape */
-    const bool rows_only = p->bloom || c->sd.cc_samples != 4;
+    /* kernel shape (crthip_set_shape): bloom has a per-scanline resampler geometry and only exists in the
+     * scanline-parallel shape; the FIR build only in the lane-per-scanline shape; the 5-sample system (PV-1000) runs the
+     * lane-per-scanline shape with the exact-arithmetic kernel only */
+    const bool rows_only = p->bloom != 0;
+    if (c->sd.cc_samples != 4 && p->eq_kernel)
+        return set_err(c, CRTHIP_E_ARG, "the FIR decoder (USE_CONVOLUTION build) is not available for the 5-sample system", hipSuccess);
+    {
+        /* k_decode has the band gains of crt_core.c:272-286 compiled in */
+        const int five = c->sd.cc_samples == 5;
+        const int want[3][3] = { { 65536, five ? 12192 : 8192, five ? 7775 : 9175 }, { 65536, 65536, 1311 }, { 65536, 65536, 0 } };
+        for (int k = 0; k < 3; k++)
+            for (int b = 0; b < 3; b++)
+                if (p->eq_g[k][b] != want[k][b])
+                    return set_err(c, CRTHIP_E_ARG, "equaliser gains differ from crt_core.c:272-286", hipSuccess);
+    }
     const bool rows_shape = rows_only || (!p->eq_kernel && (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS)));
     if (rows_shape) return crt_run_decode_rows(c, p, n, d_inp, d_lines, d_out, ostride);
     /* FIR build: the filters only add, their outputs stay inside the hull of the inputs, so the 24-bit envelope
@@ -472,16 +502,15 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
     const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
-        if constexpr (S::CCS != 4) {
-            return CRTHIP_E_ARG;                      /* unreachable: rows_only above */
-        } else {
+        {
         const int total = n * S::LINES;
         const dim3 grid((total + 63) / 64), block(64);
         unsigned char *o = (unsigned char *) d_out;
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_DECODE(T, B3) \
-    do { if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
+    do { if constexpr (S::CCS != 4 && T != 3) break; /* the 5-sample system only has the exact kernel (min_tier 3) */ \
+         else if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
          else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); } while (0)
             /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */
             if (p->out_bpp == 3) {

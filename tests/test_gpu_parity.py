@@ -231,8 +231,8 @@ F4_CASES = [
 @pytest.mark.parametrize("name", ["snes", "temp", "pv1k"])
 def test_f4_systems_parity(crtlib, name, case, fused):
     """crt_snes.c / crt_template.c / crt_pv1k.c + the shared decoder (PV-1000: the 5-sample branch,
-    crt_core.c:480-510,544-549).  SNES and the template also run the lane-per-scanline decoder (even cases)."""
-    shape = 2 if name == "pv1k" or case % 2 else 1
+    crt_core.c:480-510,544-549).  Even cases run the lane-per-scanline decoder, odd ones the scanline-parallel one."""
+    shape = 2 if case % 2 else 1
     _run_case(crtlib, (name,) + F4_CASES[case], fused=fused, shape=shape, steps=3)
 
 

@@ -23,8 +23,6 @@ for seed in range(first, first + count):
         case[0] = "ntscp0"
     elif variant in (4, 5, 6, 7):                     # SURVEY 8(f) f4 systems
         case[0] = ("snes", "temp", "nesrgb", "pv1k")[variant - 4]
-        if case[0] == "pv1k":
-            shape = 0                                 # 5 samples per chroma cycle: scanline-parallel decoder only
     try:
         T._run_case(crtlib, tuple(case), fused=bool(seed & 8), steps=2, n=2, shape=shape)
     except Exception as e:
