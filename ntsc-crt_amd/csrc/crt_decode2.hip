@@ -10,9 +10,9 @@
  * more issued instructions per scanline, so large batches stay on the lane-per-scanline kernels.
  *
  * Because the pixels are no longer produced inside a lane's serial loop but by the whole wavefront from an LDS ring
- * of y/i/q samples, the resampler geometry may differ per scanline: this kernel is also the decoder of the
- * CRT_DO_BLOOM build (per-line dx / scanL, crt_core.c:512-526) and of the 5-samples-per-cycle system (PV-1000,
- * crt_core.c:480-510, 544-549).  All arithmetic is the reference's wrapping 32-bit arithmetic (v_mul_lo_u32), no
+ * of y/i/q samples, the resampler geometry may differ per scanline: this kernel is also THE decoder of the
+ * CRT_DO_BLOOM build (per-line dx / scanL, crt_core.c:512-526) at every batch size, and it knows the
+ * 5-samples-per-cycle system (PV-1000, crt_core.c:480-510, 544-549), whose large batches go to k_decode's exact tier.  All arithmetic is the reference's wrapping 32-bit arithmetic (v_mul_lo_u32), no
  * operand envelope is needed; the NARROW variant only drops the I/Q low cascades where DESIGN.md proves them dead.
  *
  * Work of a wavefront per tile of TS samples (everything wave-synchronous, workgroup = one wave):
