@@ -198,6 +198,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
     p = crt.params(s, noise)
     blob_crcs = None
+    crc_root = zlib.crc32(bytes(p))                              # rank 0's blob as built on the host, before any collective
     if dist is not None:
         shard.broadcast_params(p, dist, dev)
         crc = torch.tensor([zlib.crc32(bytes(p))], dtype=torch.int64, device=dev)
@@ -304,7 +305,12 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                                        for k in names},
                             "achieved": sum(per.values()) * n / (busy_ms * 1e-3) / 1e9, "peak": peak / 1e9,
                             "unit": "G wave64 instr/s", "frac": sum(per.values()) * n / (busy_ms * 1e-3) / peak,
-                            "peak_is": "%d SIMDs x %.1f GHz / 4 cycles per instruction" % (VALU_SIMDS, VALU_CLOCK_HZ / 1e9)}
+                            "peak_is": "%d SIMDs x %.1f GHz / 4 cycles per instruction (what these instruction mixes issue at, "
+                                       "profiles/r02_valu_mixed_sequences.txt)" % (VALU_SIMDS, VALU_CLOCK_HZ / 1e9),
+                            # the chip's nominal rate: one wave64 VALU instruction per 2 cycles and SIMD
+                            "frac_of_2_cycle_peak": sum(per.values()) * n / (busy_ms * 1e-3) / (2.0 * peak),
+                            "instr_count_source": "static: %s (SQ_INSTS_VALU of a committed rocprofv3 --pmc run); "
+                                                  "kernel times measured in this run" % os.path.relpath(traffic_file, ROOT)}
         except Exception:
             traffic = None
     rec = {
@@ -318,6 +324,10 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                      # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
+                     # NOT measured in this run: PMC passes need rocprofv3 around the process (tools/prof_bench.sh)
+                     "traffic_source": ("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same workload, "
+                                        "calibrated per access pattern: profiles/r03_pmc_calibration.json)"
+                                        % os.path.relpath(traffic_file, ROOT)) if traffic is not None else None,
                      "valu": valu,
                      "algorithmic_bytes_per_field": abytes,
                      "kernel_ms": kern_ms,
@@ -331,6 +341,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     }
     if blob_crcs is not None:
         rec["settings_blob_crc32_per_rank"] = blob_crcs
+        rec["settings_blob_crc32_rank0_before_broadcast"] = crc_root
     if with_cpu:
         rec["cpu_baseline"] = cpu_baseline(system + ("fir%d" % fir if fir else ""), w, h, outw, outh, noise, scanlines, cpu_seconds,
                                            all_cores=wl.get("cpu_all_cores", False))
@@ -374,6 +385,9 @@ def main():
     ap.add_argument("--shape", type=int, default=0, help="kernel shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel")
     ap.add_argument("--graph", action="store_true", help="time a replayed HIP graph of two steps instead of eager launches (measured: no difference)")
     ap.add_argument("--dry-run", action="store_true", help="(tests) exercise launch / collectives / JSON without a GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run every collective of the multi-GPU path (settings broadcast, "
+                         "CRC all_gather, MAX all-reduce, barriers) even with ONE rank -- exercises RCCL on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -395,9 +409,11 @@ def main():
     if args.dry_run:
         return dry_run(args, torch, shard, rank, world)
     import crtlib
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:          # --force-dist outside torch.distributed.run: a one-rank rendezvous
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == world
     torch.cuda.set_device(local)
@@ -457,17 +473,28 @@ def main():
             "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": rec["config"], "roofline": rec["roofline"],
-            "world_size": world, "world_size_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
+            "world_size": world,
+            # dist.get_world_size() of the live process group; None = no process group was initialised (one rank, no --force-dist)
+            "world_size_seen_by_rccl": (dist.get_world_size() if dist is not None else None),
+            "collectives": {"backend": dist.get_backend() if dist is not None else None, "initialized": dist is not None,
+                            "ran": ["broadcast(settings blob)", "all_gather(blob crc)", "all_reduce(MAX elapsed)", "barrier"]
+                                   if dist is not None else []},
         }
-        for k in ("settings_blob_crc32_per_rank", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
+        for k in ("settings_blob_crc32_per_rank", "settings_blob_crc32_rank0_before_broadcast", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
             if k in rec:
                 out[k] = rec[k]
         if extras:
             out["extra_workloads"] = extras
-        print(json.dumps(out))
+    else:
+        out = None
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # RCCL may print its own lines (library path) here: keep the JSON the LAST line
+    if out is not None:
+        # RCCL printf()s its library path into C stdio's buffer, which would be flushed at exit AFTER this line
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 def dry_run(args, torch, shard, rank, world):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 2
+#define CRTHIP_ABI_VERSION 3
 
 /* CRT_SYSTEM_* of crt_core.h:30-36 */
 #define CRTHIP_SYSTEM_NTSC    0
@@ -250,6 +250,28 @@ int  crthip_sequence(crthip_ctx *ctx, const crthip_params *p, int n,
                      const void *d_images, size_t image_stride,
                      void *d_out, size_t out_stride, const void *d_out_init,
                      crthip_state *d_state, int *passes);
+
+/*
+ * The phases of crthip_sequence, for hosts that cut ONE video over several contexts / devices / processes
+ * (include/crt_hip_node.h; ntsc-crt_amd/shard.py over torch.distributed).  A shard holds the n consecutive fields
+ * [first_index, first_index + n) of the video; crthip_sequence == encode(0, rn0) + sync + decode + weave on one context.
+ *   encode : state[k].rn = the set's generator before field first_index + k (closed form from rn0, the generator before
+ *            field 0 of the VIDEO); all fields encoded, noise fused.  VHS: first_index must be 0 (one rand() stream).
+ *   sync   : the sync chain from the incoming (hsync_in, vsync_in) = the set's state before the shard's first field;
+ *            returns the pair after its last field.  May be called again with another incoming pair (the predecessor
+ *            shard's final state became known): it then restarts from its previous finals.
+ *   decode : rn after each field, every field decoded (without blend).
+ *   weave  : image k = the output buffer after field k, given d_out_init = the buffer before the shard's first field
+ *            (NULL = zeros).  patch_only != 0 (blend == 0 only): the images were woven before with a placeholder init;
+ *            only the rows no field of the shard wrote are taken from d_out_init now.
+ */
+int  crthip_seq_encode(crthip_ctx *ctx, const crthip_params *p, int n, int first_index, int rn0,
+                       const void *d_images, size_t image_stride, crthip_state *d_state);
+int  crthip_seq_sync(crthip_ctx *ctx, const crthip_params *p, int n, crthip_state *d_state, int hsync_in, int vsync_in,
+                     int *hsync_out, int *vsync_out, int *passes);
+int  crthip_seq_decode(crthip_ctx *ctx, const crthip_params *p, int n, void *d_out, size_t out_stride, crthip_state *d_state);
+int  crthip_seq_weave(crthip_ctx *ctx, const crthip_params *p, int n, void *d_out, size_t out_stride,
+                      const void *d_out_init, int patch_only);
 
 /*
  * Stage-level entry points (used by the drop-in layer, which must keep the host's

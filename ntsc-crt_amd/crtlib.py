@@ -72,7 +72,8 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(LIBDIR, "libcrthip.so")
+    # CRTHIP_LIBDIR: another build of the same library (A/B measurements of a kernel change against the previous build)
+    path = os.path.join(os.environ.get("CRTHIP_LIBDIR") or LIBDIR, "libcrthip.so")
     if not os.path.exists(path):
         raise RuntimeError("native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % path)
@@ -108,6 +109,10 @@ def load_library():
     L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_set_shape.argtypes = [vp, ci]
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
+    L.crthip_seq_encode.argtypes = [vp, PP, ci, ci, ci, vp, sz, vp]
+    L.crthip_seq_sync.argtypes = [vp, PP, ci, vp, ci, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.crthip_seq_decode.argtypes = [vp, PP, ci, vp, sz, vp]
+    L.crthip_seq_weave.argtypes = [vp, PP, ci, vp, sz, vp, ci]
     L.crthip_set_pixel_tile.argtypes = [vp, ci]
     L.crthip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ci)]
     _LIB = L
@@ -351,6 +356,35 @@ class CRT:
         self._check(rc, "crthip_sequence")
         s.initialized = 1
         return passes.value
+
+    # the phases of sequence(), for a video cut over several CRT objects / ranks (shard.sequence_sharded)
+    def seq_encode(self, s, noise, first_index, rn0):
+        """This object's n fields are fields [first_index, first_index + n) of the video; rn0 = the set's rn before field 0."""
+        self._seq_p = self.params(s, noise)
+        self._load_field_state(s)
+        self._check(self.L.crthip_seq_encode(self.ctx, C.byref(self._seq_p), self.n, int(first_index), int(rn0) if rn0 < 2 ** 31 else int(rn0) - 2 ** 32,
+                                             C.c_void_p(s.data.data_ptr()), self._image_stride(s), C.c_void_p(self.state.data_ptr())),
+                    "crthip_seq_encode")
+        s.initialized = 1
+
+    def seq_sync(self, hsync_in, vsync_in):
+        """The sync chain from the incoming pair; returns (hsync, vsync) after this object's last field."""
+        ho, vo, ps = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self.L.crthip_seq_sync(self.ctx, C.byref(self._seq_p), self.n, C.c_void_p(self.state.data_ptr()), int(hsync_in), int(vsync_in),
+                                           C.byref(ho), C.byref(vo), C.byref(ps)), "crthip_seq_sync")
+        return ho.value, vo.value
+
+    def seq_decode(self):
+        self._check(self.L.crthip_seq_decode(self.ctx, C.byref(self._seq_p), self.n, C.c_void_p(self.out.data_ptr()), self.out.stride(0),
+                                             C.c_void_p(self.state.data_ptr())), "crthip_seq_decode")
+
+    def seq_weave(self, out_init=None, patch_only=False):
+        self._check(self.L.crthip_seq_weave(self.ctx, C.byref(self._seq_p), self.n, C.c_void_p(self.out.data_ptr()), self.out.stride(0),
+                                            C.c_void_p(out_init.data_ptr()) if out_init is not None else None, int(bool(patch_only))),
+                    "crthip_seq_weave")
+
+    def last_picture(self):
+        return self.out[self.n - 1]
 
     # ------------------------------------------------------------------ observation
     def srand(self, seeds):

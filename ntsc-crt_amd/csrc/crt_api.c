@@ -14,10 +14,16 @@
  * output image become authoritative between calls.  What the caller does NOT get any more: crt.analog after
  * crt_modulate and crt.inp after crt_demodulate are not refreshed on the host (crt_main.c's -a dump needs the strict
  * mode).  What stays safe: analog[] and the output image are re-uploaded whenever the host copy differs from what this
- * layer last saw there -- judged by a hash of the buffer, sampled (1: every 16th 64-byte block + both ends: catches
- * memset / repaint / a new picture, not a sparse edit) or complete (2) -- and the input image is re-uploaded unless
- * pointer, geometry and hash are unchanged (crt_main.c modulates the same picture 8 times).  The caller's image and
- * output buffers are page-locked on first sight (hipHostRegister) so that the remaining copies run as direct DMA.
+ * layer last saw there.  analog[] is compared byte for byte with a shadow copy of what this layer last saw (all of it,
+ * in both modes); because a lazy crt_modulate leaves the host copy stale, it also stamps a 16-byte marker into
+ * crt.analog[0..15], so that a caller's memset / repaint is seen even when it restores the very bytes the stale copy
+ * held (crt_main.c:430 after crt_init).  Marker gone = the caller replaced the field: upload it all; marker intact but
+ * other bytes changed = the caller edited samples of a field whose current content lives on the device: exactly the
+ * changed bytes are patched into the device copy.  The output image and the input image are judged by a hash, sampled
+ * (1: every 16th 64-byte block + both ends) or complete (2); the input image is re-uploaded unless pointer, geometry
+ * and hash are unchanged (crt_main.c modulates the same picture 8 times).  The caller's image and output buffers are
+ * page-locked on first sight (hipHostRegister) so that the remaining copies run as direct DMA; the registrations are
+ * dropped again on crt_init / crt_resize of that set and when its slot is recycled.
  *
  * Errors: the reference API is all-void and has no error channel.  A HIP failure or a missing
  * gfx950 device is reported on stderr and the process aborts -- there is no CPU fallback.
@@ -70,7 +76,9 @@ struct slot {
     size_t img_cap, out_cap;
     /* lazy mirror: what the host copies looked like when this layer last read or wrote them */
     int analog_valid, out_valid, img_valid;
-    unsigned long analog_hash, out_hash, img_hash;
+    int analog_dev_newer;                 /* lazy: the device copy holds a crt_modulate result the host copy does not */
+    signed char *analog_shadow;           /* lazy: crt.analog[] as this layer last saw / left it on the host */
+    unsigned long out_hash, img_hash;
     const void *img_ptr, *out_ptr, *pinned_img, *pinned_out;
     size_t img_bytes, out_bytes, pinned_img_bytes, pinned_out_bytes;
 };
@@ -146,6 +154,26 @@ pin_buffer(const void **pinned, size_t *pinned_bytes, const void *ptr, size_t by
 static struct slot g_slots[MAX_SLOTS];
 static size_t g_fstride;
 
+/* drop the page-lock registrations of a slot (the caller may free or reallocate those buffers: crt_init, crt_resize, a
+ * recycled slot); failures are ignored -- an address that is no longer mapped cannot be unregistered */
+static void
+unpin_slot(struct slot *sl, int img_too)
+{
+    if (g_ctx == 0) {
+        return;
+    }
+    if (sl->pinned_out) {
+        (void) crthip_host_unregister(g_ctx, (void *) sl->pinned_out);
+        sl->pinned_out = 0;
+        sl->pinned_out_bytes = 0;
+    }
+    if (img_too && sl->pinned_img) {
+        (void) crthip_host_unregister(g_ctx, (void *) sl->pinned_img);
+        sl->pinned_img = 0;
+        sl->pinned_img_bytes = 0;
+    }
+}
+
 static void
 fatal(const char *what, int rc)
 {
@@ -194,9 +222,11 @@ get_slot(struct CRT *v)
     if (free_slot == 0) {
         /* recycle slot 0: its buffers stay allocated and are simply re-filled on the next call */
         free_slot = &g_slots[0];
+        unpin_slot(free_slot, 1);
     }
     free_slot->host = v;
     free_slot->analog_valid = free_slot->out_valid = free_slot->img_valid = 0;
+    free_slot->analog_dev_newer = 0;
     if (free_slot->d_analog == 0) {
         free_slot->d_analog = (signed char *) dev_alloc(g_fstride + 4096);
         free_slot->d_inp = (signed char *) dev_alloc(g_fstride + 4096);
@@ -351,21 +381,61 @@ write_libc_rand(int *lib, const unsigned hist[31])
 }
 #endif
 
-/* analog[] before a kernel reads it: strict mode uploads the caller's copy every time; lazy mode only when the caller's
- * copy is not what this layer last saw there (memset(crt.analog, 0, ...) of the live driver, crt_init, a fresh struct) */
+/* analog[] before a kernel reads it: strict mode uploads the caller's copy every time; lazy mode only what the caller
+ * changed since this layer last looked (see the header comment) */
+static const unsigned char LAZY_MARK[16] = { 'c', 'r', 't', 'h', 'i', 'p', 0x7f, 0x80, 'l', 'a', 'z', 'y', 0x81, 0x7e, 0x5a, 0xa5 };
+
 static void
 sync_analog_to_device(struct slot *sl, const struct CRT *v)
 {
-    const int lazy = lazy_mode();
-    if (lazy) {
-        const unsigned long h = buf_hash(v->analog, CRT_INPUT_SIZE, lazy);
-        if (sl->analog_valid && sl->analog_hash == h) {
-            return;
+    if (!lazy_mode()) {
+        CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
+        return;
+    }
+    if (sl->analog_shadow == 0) {
+        sl->analog_shadow = (signed char *) malloc(CRT_INPUT_SIZE);
+        if (sl->analog_shadow == 0) {
+            fatal("malloc (analog shadow)", CRTHIP_E_NOMEM);
         }
-        sl->analog_hash = h;
-        sl->analog_valid = 1;
+        sl->analog_valid = 0;
+    }
+    if (sl->analog_valid && memcmp(v->analog, sl->analog_shadow, CRT_INPUT_SIZE) == 0) {
+        return;                                     /* untouched since this layer last saw it */
+    }
+    if (sl->analog_valid && sl->analog_dev_newer && memcmp(v->analog, LAZY_MARK, sizeof(LAZY_MARK)) == 0) {
+        /* marker intact: sparse edits on top of a stale host copy -> patch exactly the changed bytes into the device copy */
+        static signed char *tmp;
+        long i;
+        if (tmp == 0) {
+            tmp = (signed char *) malloc(CRT_INPUT_SIZE);
+            if (tmp == 0) {
+                fatal("malloc (analog patch buffer)", CRTHIP_E_NOMEM);
+            }
+        }
+        CHECK(crthip_download(g_ctx, tmp, sl->d_analog, CRT_INPUT_SIZE));
+        for (i = 0; i < CRT_INPUT_SIZE; i++) {
+            if (v->analog[i] != sl->analog_shadow[i]) {
+                tmp[i] = v->analog[i];
+            }
+        }
+        CHECK(crthip_upload(g_ctx, sl->d_analog, tmp, CRT_INPUT_SIZE));
+        memcpy(sl->analog_shadow, v->analog, CRT_INPUT_SIZE);
+        return;                                     /* the device copy stays newer than the host's */
     }
     CHECK(crthip_upload(g_ctx, sl->d_analog, v->analog, CRT_INPUT_SIZE));
+    memcpy(sl->analog_shadow, v->analog, CRT_INPUT_SIZE);
+    sl->analog_valid = 1;
+    sl->analog_dev_newer = 0;
+}
+
+/* after a lazy crt_modulate: crt.analog on the host is stale from here on.  The marker makes that visible to this layer
+ * (and to anyone who dumps the array); the reference would have written the new field there */
+static void
+mark_analog_stale(struct slot *sl, struct CRT *v)
+{
+    memcpy(v->analog, LAZY_MARK, sizeof(LAZY_MARK));
+    memcpy(sl->analog_shadow, LAZY_MARK, sizeof(LAZY_MARK));
+    sl->analog_dev_newer = 1;
 }
 
 /* ---- public API ---------------------------------------------------------------------------- */
@@ -385,6 +455,13 @@ crt_sincos14(int *s, int *c, int n)
 extern void
 crt_resize(struct CRT *v, int w, int h, int f, unsigned char *out)
 {
+    int i;
+
+    for (i = 0; i < MAX_SLOTS; i++) {           /* a new output buffer: the old one may be freed by the caller */
+        if (g_slots[i].host == v && (const void *) out != g_slots[i].pinned_out) {
+            unpin_slot(&g_slots[i], 0);
+        }
+    }
     v->outw = w;
     v->outh = h;
     v->out_format = f;
@@ -415,7 +492,9 @@ crt_init(struct CRT *v, int w, int h, int f, unsigned char *out)
     v->rn = 194;
     for (i = 0; i < MAX_SLOTS; i++) {           /* lazy mirror: a re-initialised set starts from its host copies again */
         if (g_slots[i].host == v) {
-            g_slots[i].analog_valid = g_slots[i].out_valid = 0;
+            g_slots[i].analog_valid = g_slots[i].out_valid = g_slots[i].img_valid = 0;
+            g_slots[i].analog_dev_newer = 0;
+            unpin_slot(&g_slots[i], 1);
         }
     }
     /* the equaliser coefficients the reference sets up here are derived per call on the host
@@ -447,7 +526,9 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     if (!s->field_initialized) {
         p.flags |= CRTHIP_F_NES_SETUP;
     }
-    s->field_initialized = 1;
+    /* crt_nes.c:118-121 / crt_nesrgb.c:63-66 write the skeleton before any of their early returns; here it is written
+     * by the launch below, so field_initialized is only set once that launch is certain: a call that returns early
+     * (unknown pixel format, empty image) leaves it 0 and the next valid call writes the skeleton */
 #endif
 #if (CRT_SYSTEM == CRT_SYSTEM_NES)
     img_bytes = (size_t) s->w * (size_t) s->h * 2;
@@ -459,8 +540,10 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     s->iirs_initialized = 1;
 #endif
     if (crt_setup_bpp4fmt(s->format) == 0) {
-        return;     /* like the reference: nothing else happens for an unknown pixel format */
+        return;     /* like the reference: nothing else happens for an unknown pixel format (NES-RGB: the skeleton is
+                       then written by the first call with a valid one, field_initialized stays 0) */
     }
+
 #if (CRT_SYSTEM != CRT_SYSTEM_NESRGB)
     s->field &= 1;
     s->frame &= 1;
@@ -495,6 +578,9 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
         return;
     }
 
+#if (CRT_SYSTEM == CRT_SYSTEM_NES) || (CRT_SYSTEM == CRT_SYSTEM_NESRGB)
+    s->field_initialized = 1;
+#endif
     lib = park_libc_rand();
     sl = get_slot(v);
     /* The reference clamps the source row with `if (sy >= h) sy = h` (crt_ntsc.c:263) and so reads the image row
@@ -530,6 +616,8 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
     CHECK(crthip_modulate(g_ctx, &p, 1, sl->d_img, 0, sl->d_analog, sl->d_state));
     if (!lazy_mode()) {
         CHECK(crthip_download(g_ctx, v->analog, sl->d_analog, CRT_INPUT_SIZE));
+    } else {
+        mark_analog_stale(sl, v);
     }
     state_from_device(sl, v, 0);
     unpark_libc_rand(lib);

@@ -279,9 +279,13 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const unsigned ppos_end = ppos_all < scan_r ? (unsigned) ppos_all : scan_r;
     const unsigned dx = (unsigned) P.dx;
     unsigned ppos = 0;
-    int next_x = 1;                                /* sample after which pixel px becomes computable */
-    int px = 0;
     const int outw = P.outw;
+    int px = 0, px0 = 0;                           /* next pixel; first pixel of the tile being filled */
+    int tile_end = PX_TILE < outw ? PX_TILE : outw;
+    /* tiers 0 / 1: contrast as a pre-shifted 64-bit-mad multiplier, the opaque alpha riding on the red row */
+    const int contrast12 = contrast * 4096;
+    long alpha_pair = (long) 0xff00ul << 32;
+    asm volatile("" : "+v"(alpha_pair));
 
     /* cooperative input tile: piece = 16 bytes, IN_PIECES pieces per row, 64 / IN_PIECES rows per load instruction */
     const int in_row = lane / IN_PIECES, in_piece = lane % IN_PIECES;
@@ -344,8 +348,12 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     ci = eq_step<FAST, 65536, 1311>(ei, ilf, ihf, mulq<FAST>(s, wi) >> 9) >> 3;
                     cq = eq_step<FAST, 65536, 0>(eq, qlf, qhf, mulq<FAST>(s, wq) >> 9) >> 3;
                 }
-                /* D9: every output pixel whose left tap is sample x-1 is now computable */
-                while (x == next_x && ppos < ppos_end) {
+                /* D9: every output pixel whose left tap is sample x-1 is now computable: pixel px sits at ppos = px * dx and
+                 * needs samples ppos >> 12 and (ppos >> 12) + 1, i.e. it is emitted at the first x with ppos < x << 12
+                 * (pixels are emitted in order, so everything below (x - 1) << 12 is already out) */
+                const unsigned lim_x = (unsigned) x << 12;
+                const unsigned lim = lim_x < ppos_end ? lim_x : ppos_end;
+                while (ppos < lim) {
                     const int R = (int) (ppos & 0xfffu), L = 0xfff - R;
                     int yy;
                     if (TIER <= 1) {
@@ -355,33 +363,50 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                     } else {
                         yy = (mulq_vs<FAST>(py, L) >> 2) + (mulq_vs<FAST>(cy, R) >> 2);
                     }
-                    int ii, qq;
+                    unsigned rgb;
                     if (TIER <= 1) {
                         /* crt_core.c:557-558: (pi * L >> 14) + (ci * R >> 14).  With the weights scaled by 4 each shift
                          * is "take the high word", and both ride on the add.  |chroma| <= 2^13 inside the tier's
-                         * envelope (|wave| <= 120000: inputs |s * wave >> 9| < 2^15, outputs >> 3), weights < 2^14 */
-                        ii = add_hiwords(mulq_vs<true>(pi, L << 2), mulq_vs<true>(ci, R << 2));
-                        qq = add_hiwords(mulq_vs<true>(pq, L << 2), mulq_vs<true>(cq, R << 2));
+                         * envelope (|wave| <= 120000: inputs |s * wave >> 9| < 2^15, outputs >> 3), weights < 2^14.
+                         * Both results fit 16 bits, so they are formed PACKED -- q in the low half, i in the high half
+                         * (the second add writes only WORD_1) -- and each colour row of crt_core.c:560-562 is one
+                         * v_dot2_i32_i16 by its packed coefficient pair on top of the luma. */
+                        int iq = add_hiwords(mulq_vs<true>(pq, L << 2), mulq_vs<true>(cq, R << 2));
+                        iq = add_hiwords_to_hi(iq, mulq_vs<true>(pi, L << 2), mulq_vs<true>(ci, R << 2));
+                        const int vr = dot2_vs(iq, (3879 << 16) | 2556, yy);
+                        const int vg = dot2_vs(iq, (int) (((unsigned) -1126 << 16) | ((unsigned) -2605 & 0xffffu)), yy);
+                        const int vb = dot2_vs(iq, (int) (((unsigned) -4530 << 16) | 7021u), yy);
+                        /* ((v >> 12) * contrast) >> 8 == hi32((v & ~0xfff) * (contrast << 12)): one v_mad_i64_i32 instead of
+                         * shift, multiply, shift.  The 64-bit product is exact where the reference's 32-bit one wraps: equal
+                         * inside the envelope (|v| < 2^27.3, |contrast| <= 32768, host-checked).  The red row carries the
+                         * opaque alpha along: + 0xff00 through the addend, clamped to [0xff00, 0xffff]. */
+                        int r = pair_hi(mad64_vs(vr & ~0xfff, contrast12, alpha_pair));
+                        int g = pair_hi(mad64_vs0(vg & ~0xfff, contrast12));
+                        int b = pair_hi(mad64_vs0(vb & ~0xfff, contrast12));
+                        r = clampi(r, 0xff00, 0xffff); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
+                        rgb = lshl_or(lshl_or((unsigned) r, 8, (unsigned) g), 8, (unsigned) b);       /* 0xffRRGGBB */
                     } else {
-                        ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq_vs<FAST>(ci, R) >> 14);
-                        qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq_vs<FAST>(cq, R) >> 14);
+                        const int ii = (mulq_vs<FAST>(pi, L) >> 14) + (mulq_vs<FAST>(ci, R) >> 14);
+                        const int qq = (mulq_vs<FAST>(pq, L) >> 14) + (mulq_vs<FAST>(cq, R) >> 14);
+                        int r, g, b;
+                        if (FAST) {
+                            r = mulq<true>(mad24_vs(qq, 2556, mad24_vs(ii, 3879, yy)) >> 12, contrast) >> 8;
+                            g = mulq<true>(mad24_vs(qq, -2605, mad24_vs(ii, -1126, yy)) >> 12, contrast) >> 8;
+                            b = mulq<true>(mad24_vs(qq, 7021, mad24_vs(ii, -4530, yy)) >> 12, contrast) >> 8;
+                        } else {
+                            r = ((yy + 3879 * ii + 2556 * qq) >> 12) * contrast >> 8;
+                            g = ((yy - 1126 * ii - 2605 * qq) >> 12) * contrast >> 8;
+                            b = ((yy - 4530 * ii + 7021 * qq) >> 12) * contrast >> 8;
+                        }
+                        r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
+                        rgb = lshl_or(lshl_or((unsigned) r, 8, (unsigned) g), 8, (unsigned) b);
                     }
-                    int r, g, b;
-                    if (FAST) {
-                        r = mulq<true>(mad24_vs(qq, 2556, mad24_vs(ii, 3879, yy)) >> 12, contrast) >> 8;
-                        g = mulq<true>(mad24_vs(qq, -2605, mad24_vs(ii, -1126, yy)) >> 12, contrast) >> 8;
-                        b = mulq<true>(mad24_vs(qq, 7021, mad24_vs(ii, -4530, yy)) >> 12, contrast) >> 8;
-                    } else {
-                        r = ((yy + 3879 * ii + 2556 * qq) >> 12) * contrast >> 8;
-                        g = ((yy - 1126 * ii - 2605 * qq) >> 12) * contrast >> 8;
-                        b = ((yy - 4530 * ii + 7021 * qq) >> 12) * contrast >> 8;
-                    }
-                    r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
-                    s_px[lane * PX_STRIDE + (px & (PX_TILE - 1))] = lshl_or(lshl_or((unsigned) r, 8, (unsigned) g), 8, (unsigned) b);
-                    if ((px & (PX_TILE - 1)) == PX_TILE - 1 || px == outw - 1) {
+                    s_px[lane * PX_STRIDE + (px - px0)] = rgb;
+                    ppos += dx;
+                    px++;
+                    if (px == tile_end) {
                         /* drain the pixel tile: pixels [px0, px0+cnt) of every row, + D10 duplicates (:661-664) */
-                        const int px0 = px & ~(PX_TILE - 1);
-                        const int cnt = px - px0 + 1;
+                        const int cnt = px - px0;
                         wave_lds_fence();
                         if (!BPP3) {
                             const int orow_ = lane / PX_PIECES, piece = lane % PX_PIECES;  /* 4 pixels = 16 bytes per piece */
@@ -404,16 +429,19 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                             }
                                         }
                                     }
+                                    if (TIER > 1 || blend) {                       /* tiers 0 / 1 carry the alpha byte already */
 #pragma unroll
-                                    for (int c = 0; c < 4; c++) {
-                                        const unsigned full = 0xff000000u | v[c];
-                                        v[c] = __builtin_amdgcn_perm(full, full, psel);
+                                        for (int c = 0; c < 4; c++) v[c] |= 0xff000000u;
+                                    }
+                                    if (psel != 0x03020100u) {                     /* BGRA is the in-register order */
+#pragma unroll
+                                        for (int c = 0; c < 4; c++) v[c] = __builtin_amdgcn_perm(v[c], v[c], psel);
                                     }
                                     for (int dup = 0; dup < nr; dup++) {
                                         const unsigned long long dd = d + (size_t) dup * pitch;
                                         if (have >= 4) {
                                             v4i o; o.x = (int) v[0]; o.y = (int) v[1]; o.z = (int) v[2]; o.w = (int) v[3];
-                                            gstore16u_nt(dd, o);
+                                            gstore16u_nt(dd, o);   /* nontemporal: plain stores measured 5 % slower here and slow the encoder down too (profiles/r03_1080p_experiments.txt) */
                                         } else {
                                             gstore32(dd, v[0]);
                                             if (have > 1) gstore32(dd + 4, v[1]);
@@ -430,26 +458,25 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                 const int nr = s_nrows[rr_];
                                 if (nr > 0 && c < cnt) {
                                     const unsigned long long d = s_dst[rr_] + (size_t) (px0 + c) * 3;
-                                    int rgb = (int) s_px[rr_ * PX_STRIDE + c];
+                                    int rgb3 = (int) s_px[rr_ * PX_STRIDE + c];
                                     if (blend) {
                                         const int o0 = (int) gload8(d), o1 = (int) gload8(d + 1), o2 = (int) gload8(d + 2);
                                         const int old = rgb_order ? (o0 << 16 | o1 << 8 | o2) : (o2 << 16 | o1 << 8 | o0);
-                                        rgb = ((rgb & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
+                                        rgb3 = ((rgb3 & 0xfefeff) >> 1) + ((old & 0xfefeff) >> 1);
                                     }
-                                    const unsigned char c0 = (unsigned char) (rgb_order ? rgb >> 16 : rgb);
-                                    const unsigned char c2 = (unsigned char) (rgb_order ? rgb : rgb >> 16);
+                                    const unsigned char c0 = (unsigned char) (rgb_order ? rgb3 >> 16 : rgb3);
+                                    const unsigned char c2 = (unsigned char) (rgb_order ? rgb3 : rgb3 >> 16);
                                     for (int dup = 0; dup < nr; dup++) {
                                         const unsigned long long dd = d + (size_t) dup * pitch;
-                                        gstore8(dd, c0); gstore8(dd + 1, (unsigned) (rgb >> 8)); gstore8(dd + 2, c2);
+                                        gstore8(dd, c0); gstore8(dd + 1, (unsigned) (rgb3 >> 8)); gstore8(dd + 2, c2);
                                     }
                                 }
                             }
                         }
                         wave_lds_fence();
+                        px0 = px;
+                        tile_end = px0 + PX_TILE < outw ? px0 + PX_TILE : outw;
                     }
-                    ppos += dx;
-                    next_x = (int) (ppos >> 12) + 1;
-                    px++;
                 }
                 py = cy; pi = ci; pq = cq;
             }
@@ -467,7 +494,8 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
     const bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
                          p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
                          p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
-    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX) return 2;
+    /* ... and |contrast| <= 2^15: tiers 0 / 1 take ((v >> 12) * contrast) >> 8 from an exact 64-bit product (see D9) */
+    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX || ct > 32768) return 2;
     return c->no_loskip ? 1 : 0;
 }
 

@@ -309,6 +309,26 @@ __device__ __forceinline__ int add_hiwords(int a, int b)
     asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+/* a with its HIGH half replaced by the low 16 bits of (b >> 16) + (c >> 16): the second member of a packed pair */
+__device__ __forceinline__ int add_hiwords_to_hi(int a, int b, int c)
+{
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a) : "v"(b), "v"(c));
+    return a;
+}
+/* acc + lo16(v) * lo16(k) + hi16(v) * hi16(k), signed halves, k wave-uniform */
+__device__ __forceinline__ int dot2_vs(int v, int k_uniform, int acc)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(k_uniform), "v"(acc));
+    return r;
+}
+/* v_mad_i64_i32 with a zero addend */
+__device__ __forceinline__ long mad64_vs0(int d, int m_uniform)
+{
+    long r, carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(d), "s"(m_uniform));
+    return r;
+}
 /* (a << sh) | b in one instruction */
 __device__ __forceinline__ unsigned lshl_or(unsigned a, int sh, unsigned b)
 {
@@ -378,6 +398,7 @@ struct crthip_ctx {
     signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields (cached: the burst table they were built from) */
     bool skel_valid;
     int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
+    int skel_yo;                /* ... and the first active line (NES timing: the burst is only on the active lines) */
     int shape;                  /* crthip_set_shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel */
     int row_tile;               /* CRTHIP_ROW_TILE: samples per tile of the scanline-parallel decoder, 32 (default) or 16 */
     int sync_kernel;            /* CRTHIP_SYNC_KERNEL: 0 by batch size, 1 k_hsync (4 fields per wave), 2 k_hsync_wave (field per wave) */
@@ -385,6 +406,7 @@ struct crthip_ctx {
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
+    int seq_guess_n;            /* crthip_seq_sync: the guess array holds the finals of a previous call for this many fields (warm restart) */
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
     int vhs_chunks;
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */

@@ -156,14 +156,19 @@ __device__ __forceinline__ int ppu_level(int p, int phase)
  * own tile row.  Input side: `have` = tile in LDS, stage[] = tile have+1 in flight / in registers.  A piece that
  * would run past the row end is moved back to the row's last 16 bytes, so nothing beyond the row is touched
  * (row_bytes >= 16); moved-back pieces of several lanes overlap and carry identical bytes. */
-template <int ACT>
+/* OT: dwords per row of the OUTPUT (sample) tile.  The wide-input encoder (ACT = 32: whole 128-byte image lines per
+ * piece group) keeps the 16-dword sample tile of the narrow one: 64-byte sample pieces either way, 4 KB less LDS per
+ * wave (11 instead of 8 waves per CU behind the image fetches). */
+template <int ACT, int OT = ACT>
 struct RowTiles {
     static constexpr int TILE = ACT, STRIDE = ACT + 1, PIECES = ACT / 4;     /* 16-byte pieces per tile row */
     static constexpr int ROWS = 64 / PIECES;                                  /* rows per load instruction */
+    static constexpr int OTILE = OT, OSTRIDE = OT + 1, OPIECES = OT / 4, OROWS = 64 / OPIECES;
     unsigned *s_pix, *s_out;
     const unsigned long long *s_src, *s_dst;
-    int lane, prow, piece;
+    int lane, prow, piece, oprow, opiece;
     int row_bytes, last_tile, have;
+    bool shift8;                 /* alpha-first pixel formats: the colour bytes are moved to bits 0-23 once per tile, here */
     v4i stage[PIECES];
 
     __device__ __forceinline__ void init(unsigned *pix, unsigned *out, const unsigned long long *src,
@@ -171,6 +176,8 @@ struct RowTiles {
     {
         s_pix = pix; s_out = out; s_src = src; s_dst = dst;
         lane = lane_; prow = lane_ / PIECES; piece = lane_ % PIECES;
+        oprow = lane_ / OPIECES; opiece = lane_ % OPIECES;
+        shift8 = false;
         row_bytes = row_bytes_;
         last_tile = (row_bytes_ - 1) / (TILE * 4);
         have = 0;
@@ -191,6 +198,13 @@ struct RowTiles {
         /* dword index inside the tile where my (possibly moved-back) piece belongs; may be negative then */
         const int dw0 = (piece_offset(tile) - tile * (TILE * 4)) >> 2;
         __syncthreads();
+        if (shift8) {                                       /* wave-uniform */
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) {
+                stage[i].x = (int) ((unsigned) stage[i].x >> 8); stage[i].y = (int) ((unsigned) stage[i].y >> 8);
+                stage[i].z = (int) ((unsigned) stage[i].z >> 8); stage[i].w = (int) ((unsigned) stage[i].w >> 8);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PIECES; i++) {
             unsigned *d = s_pix + (i * ROWS + prow) * STRIDE;
@@ -218,24 +232,24 @@ struct RowTiles {
         }
     }
     __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[lane * STRIDE + (idx & (TILE - 1))]; }
-    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[lane * STRIDE + (g & (TILE - 1))] = pack; }
+    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[lane * OSTRIDE + (g & (OTILE - 1))] = pack; }
     /* sample k of group g as one LDS byte store: no packing arithmetic on the vector unit */
     __device__ __forceinline__ void put_byte(int g, int k, int v)
     {
-        ((unsigned char *) s_out)[(lane * STRIDE + (g & (TILE - 1))) * 4 + k] = (unsigned char) v;
+        ((unsigned char *) s_out)[(lane * OSTRIDE + (g & (OTILE - 1))) * 4 + k] = (unsigned char) v;
     }
     /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
     __device__ __forceinline__ void drain(int g0, int ng, int destw)
     {
         __syncthreads();
-        const int first = (g0 + piece * 4) * 4;               /* first sample of my piece */
+        const int first = (g0 + opiece * 4) * 4;              /* first sample of my piece */
         const int nbytes = destw - first < 16 ? destw - first : 16;
 #pragma unroll 2
-        for (int i = 0; i < PIECES; i++) {
-            const int r = i * ROWS + prow;
+        for (int i = 0; i < OPIECES; i++) {
+            const int r = i * OROWS + oprow;
             const unsigned long long d = s_dst[r];
-            if (d != 0 && piece * 4 < ng && nbytes > 0) {
-                const unsigned *sp = s_out + r * STRIDE + piece * 4;
+            if (d != 0 && opiece * 4 < ng && nbytes > 0) {
+                const unsigned *sp = s_out + r * OSTRIDE + opiece * 4;
                 v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
                 if (nbytes == 16) {
                     gstore16u(d + first, o);
@@ -253,7 +267,7 @@ struct RowTiles {
     /* after sample group g (4 samples = 1 dword per row): flush when the tile is full or the line ends */
     __device__ __forceinline__ void group_done(int g, int ngroups, int destw)
     {
-        if ((g & (TILE - 1)) == TILE - 1 || g == ngroups - 1) drain(g & ~(TILE - 1), (g & (TILE - 1)) + 1, destw);
+        if ((g & (OTILE - 1)) == OTILE - 1 || g == ngroups - 1) drain(g & ~(OTILE - 1), (g & (OTILE - 1)) + 1, destw);
     }
 };
 
@@ -289,10 +303,10 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
          const uint2 *__restrict__ jump16)
 {
-    using T = RowTiles<ACT>;
+    using T = RowTiles<ACT, 16>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[64 * T::STRIDE];
-    __shared__ unsigned s_out[64 * T::STRIDE];
+    __shared__ unsigned s_out[64 * T::OSTRIDE];
     __shared__ unsigned long long s_src[64], s_dst[64];
 
     const int lane = threadIdx.x;
@@ -381,6 +395,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         long hyp = 0, hip = 0, hqp = 0, fyp = 0;                   /* state (and the luma input) in the high halves */
         constexpr long HI_HALF = (long) 0xffffffff00000000ul;
 
+        tiles.shift8 = IN4 && alpha_first;
         if (IN4) tiles.start();
         /* loop invariants the compiler would otherwise re-materialise per sample (constant-bus limit of VOP3) */
         int neg_noise127 = -0x7f * noise;
@@ -417,7 +432,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                             pixel = (unsigned) pp[0] | (unsigned) pp[1] << 8 | (unsigned) pp[2] << 16;
                             if (in_bpp == 4) pixel |= (unsigned) pp[3] << 24;
                         }
-                        if (alpha_first) {                         /* scalar branch (the asm keeps it one) */
+                        if (!IN4 && alpha_first) {                 /* tiles: shifted once per tile (RowTiles::stash) */
                             pixel >>= 8;
                             asm volatile("" : "+v"(pixel));
                         }
@@ -998,11 +1013,14 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
-        if (fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0)) {
+        /* every input of skeleton(): the burst table and, where the burst sits on the active lines only (NES timing,
+         * crt_nes.c:173-178), the first active line; field / frame / dot crawl select the variant */
+        if (fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0 || c->skel_yo != p->yo)) {
             constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
             ProfScope ps(c, CRTHIP_K_TEMPLATE);
             hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
             memcpy(c->skel_burst, p->burst, sizeof(p->burst));
+            c->skel_yo = p->yo;
             c->skel_valid = true;
         }
         if constexpr (S::IS_NES) {

@@ -16,19 +16,20 @@
  *             recurrence over fields);
  *   weave   : output image k = the single output buffer after field k: rows field k does not write come
  *             from the latest earlier field that wrote them (or the initial buffer). */
-__global__ void k_seq_rn(int n_fields, crthip_state *state, uint2 whole_field)
+/* state[k].rn = J^(first_index + k)(rn0): the set's generator before field first_index + k of the video, rn0 = before
+ * field 0 (a shard of a longer video starts at first_index > 0) */
+__global__ void k_seq_rn(int n_fields, crthip_state *state, uint2 whole_field, unsigned first_index, unsigned rn0)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_fields) return;
-    /* (m, a) = J^k by square and multiply */
+    /* (m, a) = J^e by square and multiply */
     unsigned pm = whole_field.x, pa = whole_field.y, m = 1u, a = 0u;
-    for (unsigned e = (unsigned) k; e; e >>= 1) {
+    for (unsigned e = first_index + (unsigned) k; e; e >>= 1) {
         if (e & 1u) { m = pm * m; a = pm * a + pa; }
         pa = pm * pa + pa;
         pm = pm * pm;
     }
-    const unsigned rn0 = (unsigned) state[0].rn;       /* entry 0 is never written here */
-    if (k > 0) state[k].rn = (int) (m * rn0 + a);
+    state[k].rn = (int) (m * rn0 + a);
 }
 
 /* init_k = (k ? guess[k-1] : first); also remembers nothing else */
@@ -82,12 +83,13 @@ __global__ void k_seq_latest(int n_fields, int outh, const unsigned char *owner,
 /* rows of image k that field k did not write <- the same row of image latest[k][row] (or the initial image) */
 __global__ void __launch_bounds__(256)
 k_seq_weave(int n_fields, int outh, size_t pitch, unsigned char *out, size_t ostride, const unsigned char *init,
-            const int *latest)
+            const int *latest, int patch_only)
 {
     const int row = blockIdx.x % outh, k = blockIdx.x / outh;
     if (k >= n_fields) return;
     const int src_k = latest[(size_t) k * outh + row];
     if (src_k == k) return;
+    if (patch_only && src_k >= 0) return;       /* second visit (cross-shard chain): only the rows nobody here wrote */
     unsigned char *dst = out + (size_t) k * ostride + (size_t) row * pitch;
     const unsigned char *src = src_k >= 0 ? out + (size_t) src_k * ostride + (size_t) row * pitch
                                           : (init ? init + (size_t) row * pitch : nullptr);
@@ -522,44 +524,54 @@ int crthip_set_pixel_tile(crthip_ctx *c, int px)
     return CRTHIP_OK;
 }
 
-int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                    void *d_out, size_t ostride, const void *d_out_init, crthip_state *d_state, int *passes_out)
+/* scratch of the sequence phases: guess[n] (int2), changed flag, owner[n][outh] (u8), latest[n][outh] (int) */
+struct SeqScratch { int2 *guess; int *changed; unsigned char *owner; int *latest; };
+static int seq_scratch(crthip_ctx *c, int n, int outh, SeqScratch *sc)
+{
+    const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh + 256;
+    if (need > c->seq_cap) {
+        if (c->d_seq) hipFree(c->d_seq);
+        c->d_seq = 0; c->seq_cap = 0; c->seq_guess_n = 0;
+        if (hipMalloc((void **) &c->d_seq, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sequence scratch", hipSuccess);
+        c->seq_cap = need;
+    }
+    sc->guess = (int2 *) c->d_seq;
+    sc->changed = (int *) (c->d_seq + sizeof(int2) * (size_t) n);
+    sc->owner = c->d_seq + sizeof(int2) * (size_t) n + 256;
+    sc->latest = (int *) (sc->owner + (((size_t) n * outh + 255) & ~(size_t) 255));
+    return CRTHIP_OK;
+}
+
+static int seq_check(crthip_ctx *c, const crthip_params *p, int n)
 {
     int rc = check_params(c, p, n);
     if (rc) return rc;
-    if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
-    const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS;
-    if (vhs && !c->d_vhs_hist)
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !c->d_vhs_hist)
         return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
     if (p->blend && (unsigned) p->outh + p->v_fac < (unsigned) c->sd.lines)
         return set_err(c, CRTHIP_E_ARG, "sequence mode with blend needs outh + v_fac >= CRT_LINES (one line per output row)", hipSuccess);
-    if (p->out_bpp == 0) return CRTHIP_OK;
+    if (p->out_bpp == 0) return set_err(c, CRTHIP_E_ARG, "sequence mode: unknown output pixel format", hipSuccess);
     int enc = check_encoder(c, p);
     if (enc != 0) return enc < 0 ? enc : set_err(c, CRTHIP_E_ARG, "sequence mode: unknown input pixel format", hipSuccess);
+    return CRTHIP_OK;
+}
+
+/* phase 1: the noise generator of every field in closed form, all fields encoded in parallel (noise fused) */
+int crthip_seq_encode(crthip_ctx *c, const crthip_params *p, int n, int first_index, int rn0,
+                      const void *d_images, size_t istride, crthip_state *d_state)
+{
+    int rc = seq_check(c, p, n);
+    if (rc) return rc;
+    if (!d_images || !d_state || first_index < 0) return CRTHIP_E_ARG;
+    const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS;
+    if (vhs && first_index != 0)
+        return set_err(c, CRTHIP_E_ARG, "VHS: a video shares ONE rand() stream; its fields cannot start in the middle (first_index != 0)", hipSuccess);
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->cap_fields) {
         rc = crthip_reserve(c, n);
         if (rc) return rc;
     }
-    const int outh = p->outh;
-    const size_t pitch = (size_t) p->outw * p->out_bpp;
-    /* scratch: guess[n] (int2), changed flag, owner[n][outh] (u8), latest[n][outh] (int) */
-    const size_t need = sizeof(int2) * (size_t) n + 256 + (size_t) n * outh + 256 + sizeof(int) * (size_t) n * outh + 256;
-    if (need > c->seq_cap) {
-        if (c->d_seq) hipFree(c->d_seq);
-        c->d_seq = 0; c->seq_cap = 0;
-        if (hipMalloc((void **) &c->d_seq, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sequence scratch", hipSuccess);
-        c->seq_cap = need;
-    }
-    int2 *guess = (int2 *) c->d_seq;
-    int *changed = (int *) (c->d_seq + sizeof(int2) * (size_t) n);
-    unsigned char *owner = c->d_seq + sizeof(int2) * (size_t) n + 256;
-    int *latest = (int *) (owner + (((size_t) n * outh + 255) & ~(size_t) 255));
-    const dim3 gn((n + 63) / 64), b64(64);
-
-    crthip_state first;
-    HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->seq_guess_n = 0;                                    /* a new video: no warm start for the sync chain */
     rc = crt_run_encoder_prepare(c, p, true);
     if (rc) return rc;
     if (vhs) {
@@ -575,64 +587,145 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
         rc = crt_run_noise(c, p, n, c->d_analog, c->d_inp, d_state, false);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_seq_rn, gn, b64, 0, c->stream, n, d_state, c->whole_field);
+        hipLaunchKernelGGL(k_seq_rn, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_state, c->whole_field,
+                           (unsigned) first_index, (unsigned) rn0);
         /* encode every field (noise fused), ccf presets */
         rc = crt_run_encoder(c, p, n, d_images, istride, c->d_inp, d_state, true, 1, false);
         if (rc) return rc;
     }
-    /* first guess: nobody's sync state moves */
-    {
+    HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+/* phase 2: the sync chain.  Field k starts from field k-1's final (hsync, vsync), field 0 from (hsync_in, vsync_in);
+ * solved as a fixed point over ALL fields in parallel (see the comment at the top).  Called again with another
+ * incoming pair (a video cut over several shards: the predecessor's final state became known) it restarts from the
+ * finals of the previous call, so only the fields whose state really depends on the incoming pair are recomputed
+ * in more than one pass. */
+int crthip_seq_sync(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state, int hsync_in, int vsync_in,
+                    int *hsync_out, int *vsync_out, int *passes_out)
+{
+    int rc = seq_check(c, p, n);
+    if (rc) return rc;
+    if (!d_state || n > c->cap_fields) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    SeqScratch sc;
+    rc = seq_scratch(c, n, p->outh, &sc);
+    if (rc) return rc;
+    const dim3 gn((n + 63) / 64), b64(64);
+    if (c->seq_guess_n != n) {
+        /* first guess: nobody's sync state moves */
         int2 *h = (int2 *) malloc(sizeof(int2) * (size_t) n);
         if (!h) return CRTHIP_E_NOMEM;
-        for (int k = 0; k < n; k++) h[k] = make_int2(first.hsync, first.vsync);
-        hipError_t e = hipMemcpyAsync(guess, h, sizeof(int2) * (size_t) n, hipMemcpyHostToDevice, c->stream);
+        for (int k = 0; k < n; k++) h[k] = make_int2(hsync_in, vsync_in);
+        hipError_t e = hipMemcpyAsync(sc.guess, h, sizeof(int2) * (size_t) n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         free(h);
         HIPCHK(c, e);
+        c->seq_guess_n = n;
     }
     int passes = 0;
     for (;;) {
         passes++;
-        HIPCHK(c, hipMemsetAsync(changed, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_seq_load, gn, b64, 0, c->stream, n, d_state, guess, make_int2(first.hsync, first.vsync));
+        HIPCHK(c, hipMemsetAsync(sc.changed, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_seq_load, gn, b64, 0, c->stream, n, d_state, sc.guess, make_int2(hsync_in, vsync_in));
         rc = crt_run_encoder_state(c, p, n, d_state);                 /* ccf preset, crt_ntsc.c:325-329 */
         if (rc) return rc;
         rc = crt_run_sync(c, p, n, c->d_inp, d_state, c->d_lines, 0);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_seq_compare, gn, b64, 0, c->stream, n, d_state, guess, changed);
+        hipLaunchKernelGGL(k_seq_compare, gn, b64, 0, c->stream, n, d_state, sc.guess, sc.changed);
         int flag = 0;
-        HIPCHK(c, hipMemcpyAsync(&flag, changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&flag, sc.changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (!flag || passes > n + 1) break;
     }
     if (passes_out) *passes_out = passes;
-    /* rn after each field, decode, weave */
-    if (!vhs) crt_run_advance_rn(c, n, d_state);
+    if (hsync_out || vsync_out) {
+        int hv[2];
+        HIPCHK(c, hipMemcpyAsync(hv, &d_state[n - 1].hsync, sizeof(hv), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (hsync_out) *hsync_out = hv[0];
+        if (vsync_out) *vsync_out = hv[1];
+    }
+    return CRTHIP_OK;
+}
+
+/* phase 3: rn after each field, all fields decoded in parallel (without blend: phase 4 folds the fields) */
+int crthip_seq_decode(crthip_ctx *c, const crthip_params *p, int n, void *d_out, size_t ostride, crthip_state *d_state)
+{
+    int rc = seq_check(c, p, n);
+    if (rc) return rc;
+    if (!d_out || !d_state || n > c->cap_fields) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->system != CRTHIP_SYSTEM_NTSCVHS) crt_run_advance_rn(c, n, d_state);
+    crthip_params pb = *p;
+    pb.blend = 0;
+    rc = crt_run_decode(c, &pb, n, c->d_inp, c->d_lines, d_out, ostride);
+    if (rc) return rc;
+    HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+/* phase 4: image k = the single output buffer as it stands after field k.  d_out_init = the buffer before the shard's
+ * first field (NULL = zeros).  Without blend: rows a field does not write come from the latest earlier field that
+ * wrote them, or from d_out_init; patch_only != 0 revisits only the latter (the images were woven before with a
+ * placeholder init: a later shard of a video whose predecessor's last picture arrives late).  With blend: the
+ * recurrence over the fields, one pass per field in order (patch_only is not available). */
+int crthip_seq_weave(crthip_ctx *c, const crthip_params *p, int n, void *d_out, size_t ostride, const void *d_out_init,
+                     int patch_only)
+{
+    int rc = seq_check(c, p, n);
+    if (rc) return rc;
+    if (!d_out || n > c->cap_fields || (p->blend && patch_only)) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    SeqScratch sc;
+    rc = seq_scratch(c, n, p->outh, &sc);
+    if (rc) return rc;
+    const int outh = p->outh;
+    const size_t pitch = (size_t) p->outw * p->out_bpp;
     if (p->blend) {
-        /* decode without blend, then fold the fields into each other one after the other (see k_seq_blend_step) */
-        crthip_params pb = *p;
-        pb.blend = 0;
-        rc = crt_run_decode(c, &pb, n, c->d_inp, c->d_lines, d_out, ostride);
-        if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(latest, 0xff, sizeof(int) * (size_t) n * outh, c->stream));       /* -1 everywhere */
-        hipLaunchKernelGGL(k_seq_rowsrc, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, latest);
+        HIPCHK(c, hipMemsetAsync(sc.latest, 0xff, sizeof(int) * (size_t) n * outh, c->stream));       /* -1 everywhere */
+        hipLaunchKernelGGL(k_seq_rowsrc, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, sc.latest);
         const int fmt = p->out_format;
         const unsigned alpha = p->out_bpp == 3 ? 0u : ((fmt == CRTHIP_FMT_ARGB || fmt == CRTHIP_FMT_ABGR) ? 0x000000ffu : 0xff000000u);
         for (int k = 0; k < n; k++)
             hipLaunchKernelGGL(k_seq_blend_step, dim3((unsigned) outh), dim3(256), 0, c->stream, k, outh, pitch,
-                               (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, latest, alpha);
+                               (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, sc.latest, alpha);
         HIPCHK(c, hipGetLastError());
         return CRTHIP_OK;
     }
-    rc = crt_run_decode(c, p, n, c->d_inp, c->d_lines, d_out, ostride);
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(owner, 0, (size_t) n * outh, c->stream));
-    hipLaunchKernelGGL(k_seq_rows, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, owner);
-    hipLaunchKernelGGL(k_seq_latest, dim3((outh + 63) / 64), b64, 0, c->stream, n, outh, owner, latest);
+    if (!patch_only) {
+        HIPCHK(c, hipMemsetAsync(sc.owner, 0, (size_t) n * outh, c->stream));
+        hipLaunchKernelGGL(k_seq_rows, dim3((n * c->sd.lines + 255) / 256), dim3(256), 0, c->stream, n, c->sd.lines, outh, c->d_lines, sc.owner);
+        hipLaunchKernelGGL(k_seq_latest, dim3((outh + 63) / 64), dim3(64), 0, c->stream, n, outh, sc.owner, sc.latest);
+    }
     hipLaunchKernelGGL(k_seq_weave, dim3((unsigned) n * (unsigned) outh), dim3(256), 0, c->stream, n, outh, pitch,
-                       (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, latest);
+                       (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, sc.latest, patch_only);
     HIPCHK(c, hipGetLastError());
     return CRTHIP_OK;
+}
+
+int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                    void *d_out, size_t ostride, const void *d_out_init, crthip_state *d_state, int *passes_out)
+{
+    int rc = check_params(c, p, n);
+    if (rc) return rc;
+    if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
+    if (p->out_bpp == 0) {
+        rc = seq_check(c, p, n);
+        return rc == CRTHIP_E_ARG && c->err[0] == 's' ? CRTHIP_OK : rc;     /* like crt_demodulate: nothing happens */
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    crthip_state first;
+    HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = crthip_seq_encode(c, p, n, 0, first.rn, d_images, istride, d_state);
+    if (rc) return rc;
+    rc = crthip_seq_sync(c, p, n, d_state, first.hsync, first.vsync, nullptr, nullptr, passes_out);
+    if (rc) return rc;
+    rc = crthip_seq_decode(c, p, n, d_out, ostride, d_state);
+    if (rc) return rc;
+    return crthip_seq_weave(c, p, n, d_out, ostride, d_out_init, 0);
 }
 
 int crthip_set_shape(crthip_ctx *c, int shape)

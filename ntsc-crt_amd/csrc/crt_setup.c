@@ -527,8 +527,11 @@ crthip_params_finalize(crthip_params *p)
         p->col_step_lo = lo;
     }
     p->bloom_max_e = (128 + (p->noise / 2)) * d.av_len;         /* crt_core.c:400 */
-    if (p->bloom && p->bloom_max_e <= 0) {
-        return CRTHIP_E_ARG;                                    /* the reference would divide by zero (:522) */
+    if (p->bloom && (p->bloom_max_e <= 0 || p->noise < 0)) {
+        /* max_e <= 0: the reference divides by zero (:522).  noise < 0 shrinks max_e, the beam-energy term then drives
+         * line_w past AV_LEN + 16 and scanL (:521) below zero: the reference reads in front of its line buffer
+         * (undefined there), the row decoder would leave its LDS window -- refused */
+        return CRTHIP_E_ARG;
     }
     p->finalized = CRTHIP_PARAMS_MAGIC;
     return CRTHIP_OK;

@@ -34,7 +34,18 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(L, n), n
-    assert L.crthip_abi_version() == 2
+    assert L.crthip_abi_version() == 3
+
+
+def test_node_library_exports_its_header(lib):
+    """include/crt_hip_node.h -> libcrthip_node.so (links RCCL; no compute calls here)"""
+    path = os.path.join(ROOT, "ntsc-crt_amd", "lib", "libcrthip_node.so")
+    names = [n for n in _declared_functions(os.path.join(ROOT, "include", "crt_hip_node.h")) if n.startswith("crthip_node_")]
+    assert len(names) >= 10
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
+    for n in names:
+        assert n in exported, n
 
 
 def test_struct_sizes_match_header(lib):

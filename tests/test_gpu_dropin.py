@@ -108,16 +108,17 @@ def test_nes_dropin(name, outsz):
         R.compare_state(a, b, "%s step %d" % (name, step))
 
 
+@pytest.mark.parametrize("sysname", ["vhs", "vhsbloom"])
 @pytest.mark.parametrize("aberration", [0, 1])
-def test_vhs_dropin_shares_the_libc_rand_stream(aberration):
+def test_vhs_dropin_shares_the_libc_rand_stream(aberration, sysname):
     """video_convert.c semantics: the program seeds rand(), crt_modulate draws the aberration height
     from it, crt_demodulate consumes ~500k values per field.  The HIP library borrows the generator
     from libc, advances it on the GPU and puts it back: after every call the NEXT rand() of the
     process must be what it would have been with the reference."""
     import ctypes as C
     libc = C.CDLL(None)
-    hip = R.RefLib("vhs", dropin=True)
-    chk = _checker("vhs")
+    hip = R.RefLib(sysname, dropin=True)
+    chk = _checker(sysname)
     img = R.synth_image(832, 624, 4, 9)
     a, b = hip.new_crt(832, 624, R.FMT_BGRA), chk.new_crt(832, 624, R.FMT_BGRA)
     for c in (a, b):
@@ -300,6 +301,66 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, CRTHIP_LAZY_MIRROR="1"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_lazy_mirror_memset_of_a_stale_host_copy():
+    """in lazy mode crt_modulate does not refresh crt.analog on the host, which after crt_init is all
+    zeros -- a caller's memset(crt.analog, 0, ...) (crt_main.c:430) then restores the very bytes the stale copy held.  The
+    layer stamps a marker into the stale copy so the memset is still seen; the smaller picture modulated afterwards must
+    not keep samples of the larger one.  Also: sparse edits of analog[] while the device copy is newer are patched in."""
+    import sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+import crtref as R
+hip, chk = R.RefLib("ntsc", dropin=True), (R.RefLib("ntsc") if R.have_ref("ntsc") else R.Oracle("ntsc"))
+big = R.synth_image(640, 480, 4, 5)
+small = R.synth_image(200, 100, 4, 6)
+small = np.concatenate([small, np.zeros_like(small[-1:])])
+a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+for step in range(6):
+    for c in (a, b):
+        if step == 0:
+            c.settings(big, format=R.FMT_BGRA, w=640, h=480, as_color=1, raw=0)
+        if step == 2:
+            c.analog[:] = 0                   # the host copy of `a` was zeros (+ marker) all along
+            c.settings(small, format=R.FMT_BGRA, w=200, h=100, as_color=1, raw=1, xoffset=40, yoffset=30)
+        if step == 4:
+            c.analog[50000:50040] = 90        # sparse edit on top of the current field
+            c.analog[120003] = -30
+        if step != 4:
+            c.modulate()
+        c.demodulate(15)
+    assert np.array_equal(a.out, b.out), "step %%d" %% step
+    for f in ("hsync", "vsync", "rn"):
+        assert a.get(f) == b.get(f), (step, f)
+print("ok")
+""" % os.path.join(R.ROOT, "tests")
+    for mode in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, CRTHIP_LAZY_MIRROR=mode))
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_nesrgb_dropin_unknown_format_first():
+    """crt_nesrgb.c:63-66 writes the sync skeleton before its pixel-format check.  A first call with an
+    unknown format must not leave the set without a skeleton for the valid calls that follow."""
+    hip = R.RefLib("nesrgb", dropin=True)
+    chk = _checker("nesrgb")
+    img = R.synth_image(256, 240, 4, 9)
+    img = np.concatenate([img, img[-1:]])
+    a, b = hip.new_crt(640, 480, R.FMT_BGRA), chk.new_crt(640, 480, R.FMT_BGRA)
+    for c in (a, b):
+        c.settings(img, format=77, w=256, h=240, dot_crawl_offset=1)
+        c.modulate()                              # unknown format: returns early
+        c.sset("format", R.FMT_BGRA)
+    for step in range(3):
+        for c in (a, b):
+            c.modulate()
+            c.demodulate(10)
+        np.testing.assert_array_equal(a.out, b.out, err_msg="step %d" % step)
+        for f in ("hsync", "vsync", "rn"):
+            assert a.get(f) == b.get(f), (step, f)
 
 
 @pytest.mark.parametrize("flags", ["-or", "-of", "-opf", "-opm"])

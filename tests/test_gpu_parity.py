@@ -431,6 +431,43 @@ def test_nes_parity(crtlib, case, fused):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["nes", "nesrgb"])
+def test_nes_context_reused_with_another_yoffset(crtlib, name):
+    """with NES timing the burst sits on the active lines only (crt_nes.c:173-178), so the cached clean
+    skeleton of the fused path depends on yoffset as well as on the burst table.  One context, same hue, several yoffsets."""
+    import torch
+    n, outw, outh = 2, 640, 480
+    orc = R.Oracle(name)
+    g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, name, device=0)
+    ocrts = [orc.new_crt(outw, outh, R.FMT_BGRA) for _ in range(n)]
+    for step, yoff in enumerate([0, 3, -2, 3]):
+        if name == "nes":
+            ppu = np.stack([R.synth_ppu(256, 240, 5 * step + k) for k in range(n)])
+            full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
+            full[:, :240] = torch.from_numpy(ppu.astype(np.int16)).to("cuda:0")
+            s = crtlib.Settings(full[:, :240], hue=20, dot_crawl_offset=[1, 2], yoffset=yoff)
+            pads = [np.concatenate([ppu[k], ppu[k][-1:]], axis=0) for k in range(n)]
+            skw = dict(w=256, h=240, hue=20, yoffset=yoff)
+        else:
+            imgs = np.stack([R.synth_image(256, 240, 4, 40 + 5 * step + k) for k in range(n)])
+            s = crtlib.Settings(_padded(imgs), format=R.FMT_BGRA, hue=20, dot_crawl_offset=[1, 2], yoffset=yoff)
+            pads = [np.concatenate([imgs[k], imgs[k][-1:]], axis=0) for k in range(n)]
+            skw = dict(format=R.FMT_BGRA, w=256, h=240, hue=20, yoffset=yoff)
+        g.fieldpass(s, 12)
+        g.synchronize()
+        gout = g.out.cpu().numpy()
+        for k, c in enumerate(ocrts):
+            c.settings(pads[k], dot_crawl_offset=[1, 2][k], **skw)
+            c.analog[:] = 0                      # batch semantics: every field starts from a crt_init-clean analog[]
+            c.sset("field_initialized", 0)
+            c.modulate()
+            c.demodulate(12)
+            np.testing.assert_array_equal(gout[k].reshape(-1), c.out, err_msg="%s yoffset %d field %d" % (name, yoff, k))
+            for f in ("hsync", "vsync", "rn"):
+                assert g.get(f)[k] == c.get(f), "%s yoffset %d %s" % (name, yoff, f)
+    g.close()
+
+
 @pytest.mark.parametrize("aberration", [0, 9, 17])
 def test_vhs_encoder_parity(crtlib, aberration):
     """crt_ntscvhs.c: VHS band limits, aberration band without sync pulses, hsync/ccf reset.  Only the
@@ -463,10 +500,11 @@ def test_vhs_encoder_parity(crtlib, aberration):
     g.close()
 
 
+@pytest.mark.parametrize("sysname", ["vhs", "vhsbloom"])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("noise", [0, 12, 40])
-def test_vhs_fieldpass_parity(crtlib, fused, noise):
-    """BASELINE configs[3]: CRT_SYSTEM_NTSCVHS, 832x624.  The decoder's noise is the C library's rand()
+def test_vhs_fieldpass_parity(crtlib, fused, noise, sysname):
+    """BASELINE configs[3]: CRT_SYSTEM_NTSCVHS, 832x624 (and its CRT_DO_BLOOM build).  The decoder's noise is the C library's rand()
     stream (crt_core.c:344-351): field k's generator starts at srand(seed_k) and carries over from
     step to step, so the oracle processes each field's whole sequence under its own libc stream.
     (The aberration band draws from the same stream in crt_modulate; that interplay is covered by the
@@ -476,7 +514,7 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
     n, w, h, steps = 3, 832, 624, 3
     seeds = [1, 77, 20260924]
     imgs = np.stack([R.synth_image(w, h, 4, 60 + k, "random" if k != 1 else "bars") for k in range(n)])
-    orc = R.Oracle("vhs")
+    orc = R.Oracle(sysname)
     want = []
     for k in range(n):
         c = orc.new_crt(w, h, R.FMT_BGRA)
@@ -493,7 +531,7 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
             per.append((c.inp.copy(), c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn"), c.ccf.copy()))
             c.sset("field", c.sget("field") ^ 1)
         want.append(per)
-    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "vhs", device=0)
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, sysname, device=0)
     g.scanlines = 1
     g.srand(seeds)
     fields = [k & 1 for k in range(n)]
@@ -508,7 +546,7 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise):
         gout = g.out.cpu().numpy()
         for k in range(n):
             inp, out, hs, vs, rn, ccf = want[k][step]
-            what = "vhs fused=%s noise %d step %d field %d" % (fused, noise, step, k)
+            what = "%s fused=%s noise %d step %d field %d" % (sysname, fused, noise, step, k)
             if not fused:
                 np.testing.assert_array_equal(g.inp[k, :orc.input_size].cpu().numpy(), inp, err_msg=what + " inp")
             assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), what

@@ -1,58 +1,318 @@
 // HBM bandwidth ceilings for the access kinds the field-pass kernels use (MI355X): write-only streams (the decoder's
-// picture), read-only streams (the encoder's image), and both at once.  hipcc --offload-arch=gfx950 -O3 -o ubench_hbm.bin
+// picture), read-only streams (the encoder's image), and both at once -- swept over launch geometry, because the
+// round-2 version of this file (grid-stride loops, 8192 blocks) measured a 5.9 TB/s copy where
+// /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s.
+//   hipcc --offload-arch=gfx950 -O3 -o ubench_hbm.bin tools/ubench_hbm.hip
+//   ./ubench_hbm.bin            sweep, prints the best geometry per access kind
+//   ./ubench_hbm.bin calib      one launch of every calibration pattern (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE:
+//                               the byte count of every kernel is in its name, tools/calib_pmc.py divides)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
-__global__ void k_fill(v4i *p, size_t n16, int nt)
+
+// MODE 0: grid-stride, 1: one contiguous chunk per block (U pieces per thread in flight)
+template <int NT, int U>
+__global__ void k_fill(v4i *p, size_t n16, int chunked)
 {
-    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
     v4i v = { 1, 2, 3, 4 };
-    for (; i < n16; i += stride) { if (nt) __builtin_nontemporal_store(v, p + i); else p[i] = v; }
+    if (chunked) {
+        size_t base = (size_t) blockIdx.x * blockDim.x * U + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t i = base + (size_t) u * blockDim.x;
+            if (i < n16) { if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v; }
+        }
+    } else {
+        size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
+        for (; i < n16; i += stride) { if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v; }
+    }
 }
-__global__ void k_read(const v4i *p, size_t n16, int *out)
+template <int NT, int U>
+__global__ void k_read(const v4i *p, size_t n16, int *out, int chunked)
 {
-    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
     int acc = 0;
-    for (; i < n16; i += stride) { v4i v = __builtin_nontemporal_load(p + i); acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (chunked) {
+        size_t base = (size_t) blockIdx.x * blockDim.x * U + threadIdx.x;
+        v4i v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t i = base + (size_t) u * blockDim.x;
+            if (i >= n16) i = n16 - 1;
+            v[u] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    } else {
+        size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
+        for (; i < n16; i += stride) { v4i v = NT ? __builtin_nontemporal_load(p + i) : p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    }
     if (acc == 0x12345678) *out = acc;
 }
-__global__ void k_copy(const v4i *s, v4i *d, size_t n16)
+template <int NT, int U>
+__global__ void k_copy(const v4i *s, v4i *d, size_t n16, int chunked)
 {
-    size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+    if (chunked) {
+        size_t base = (size_t) blockIdx.x * blockDim.x * U + threadIdx.x;
+        v4i v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t i = base + (size_t) u * blockDim.x;
+            if (i >= n16) i = n16 - 1;
+            v[u] = NT ? __builtin_nontemporal_load(s + i) : s[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t i = base + (size_t) u * blockDim.x;
+            if (i < n16) { if (NT) __builtin_nontemporal_store(v[u], d + i); else d[i] = v[u]; }
+        }
+    } else {
+        size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
+        for (; i < n16; i += stride) {
+            v4i v = NT ? __builtin_nontemporal_load(s + i) : s[i];
+            if (NT) __builtin_nontemporal_store(v, d + i); else d[i] = v;
+        }
+    }
 }
-// picture-like writes: 128-byte pieces, each block walks `rows` rows of `pitch` bytes, 4 row copies per piece (row duplication)
-__global__ void k_rows(v4i *p, size_t pitch16, int rows_per_block, int dups)
+// picture-like writes (the decoder's store pattern): a 64-lane wave owns 64 picture LINES; per tile of PIECES*16 bytes
+// it stores, for each of its lines, `dups` duplicated rows -- PIECES lanes x 16 B per row piece, 64/PIECES lines per
+// instruction.  pitch16 = row pitch in 16-byte units.
+template <int PIECES>
+__global__ void __launch_bounds__(64) k_rows(v4i *p, size_t pitch16, int lines_per_pic, int dups, int rows_per_pic, int n_pics)
 {
-    const int piece = threadIdx.x & 7, r = threadIdx.x >> 3;       // 8 lanes x 16 B = 128 B of one row, 32 rows per block pass
+    const int lane = threadIdx.x, piece = lane % PIECES, lr = lane / PIECES;
+    const size_t wave = blockIdx.x;
     v4i v = { 1, 2, 3, 4 };
-    for (size_t x = 0; x + 8 <= pitch16; x += 8)
-        for (int rr = r; rr < rows_per_block; rr += blockDim.x / 8)
-            for (int d = 0; d < dups; d++)
-                __builtin_nontemporal_store(v, p + ((size_t) blockIdx.x * rows_per_block * dups + (size_t) rr * dups + d) * pitch16 + x + piece);
+    for (size_t x = 0; x + PIECES <= pitch16; x += PIECES) {
+#pragma unroll 2
+        for (int i = 0; i < PIECES; i++) {
+            const size_t line = wave * 64 + (size_t) i * (64 / PIECES) + lr;
+            const size_t pic = line / lines_per_pic, l = line % lines_per_pic;
+            if (pic < (size_t) n_pics) {
+                v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + x + piece;
+                for (int d = 0; d < dups; d++) __builtin_nontemporal_store(v, row + (size_t) d * pitch16);
+            }
+        }
+    }
 }
-int main()
+// calibration patterns for the TCC counters (known byte counts): 64-byte row pieces at a stride, scattered 16-byte windows
+__global__ void k_read_pieces64(const v4i *p, size_t n_pieces, size_t stride16, int *out)
+{
+    // 4 lanes x 16 B = one 64-byte piece; consecutive pieces `stride16` apart (a different 128-byte line each)
+    size_t t = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    size_t piece = t >> 2;
+    int acc = 0;
+    if (piece < n_pieces) { v4i v = p[piece * stride16 + (t & 3)]; acc = v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678) *out = acc;
+}
+__global__ void k_read_scatter16(const v4i *p, size_t n, size_t stride16, int *out)
+{
+    size_t t = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    int acc = 0;
+    if (t < n) { v4i v = p[t * stride16]; acc = v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678) *out = acc;
+}
+__global__ void k_write_pieces64(v4i *p, size_t n_pieces, size_t stride16)
+{
+    size_t t = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    size_t piece = t >> 2;
+    v4i v = { 1, 2, 3, 4 };
+    if (piece < n_pieces) p[piece * stride16 + (t & 3)] = v;
+}
+// 64-byte pieces at an odd byte offset (the encoder's 753-byte sample rows: two partial sectors per piece)
+__global__ void k_write_pieces64_unaligned(char *p, size_t n_pieces, size_t stride_bytes, int off)
+{
+    size_t t = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    size_t piece = t >> 2;
+    struct __attribute__((packed)) u16 { v4i v; };
+    v4i v = { 1, 2, 3, 4 };
+    if (piece < n_pieces) ((u16 *) (p + piece * stride_bytes + off + (t & 3) * 16))->v = v;
+}
+
+
+// ---- variants of the decoder's store pattern (what makes picture-row writes slower than a plain fill?) ----
+// VAR 0: baseline (as k_rows<8>)   1: plain stores   2: dups in the outer loop (all pieces of row copy 0, then copy 1, ...)
+// 3: XCD-aware wave -> line-group map (consecutive groups on one XCD)   4: 1 KB of ONE row per instruction (needs a 256-px tile)
+// 5: 256-thread blocks = 4 neighbouring line groups per CU slot
+template <int VAR>
+__global__ void k_rows_var(v4i *p, size_t pitch16, int lines_per_pic, int dups, int rows_per_pic, int n_pics, int n_waves)
+{
+    const int lane = threadIdx.x & 63;
+    size_t wave = (size_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (VAR == 3) { const size_t per = n_waves / 8; const size_t b = blockIdx.x; wave = (b % 8) * per + b / 8; if (b >= per * 8) wave = b; }
+    v4i v = { 1, 2, 3, 4 };
+    if (VAR == 4) {
+        for (size_t x = 0; x + 64 <= pitch16; x += 64)
+            for (int i = 0; i < 64; i++) {
+                const size_t line = wave * 64 + i, pic = line / lines_per_pic, l = line % lines_per_pic;
+                if (pic < (size_t) n_pics) {
+                    v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + x + lane;
+                    for (int d = 0; d < dups; d++) __builtin_nontemporal_store(v, row + (size_t) d * pitch16);
+                }
+            }
+        return;
+    }
+    const int piece = lane % 8, lr = lane / 8;
+    for (size_t x = 0; x + 8 <= pitch16; x += 8) {
+        if (VAR == 2) {
+            for (int d = 0; d < dups; d++)
+                for (int i = 0; i < 8; i++) {
+                    const size_t line = wave * 64 + (size_t) i * 8 + lr, pic = line / lines_per_pic, l = line % lines_per_pic;
+                    if (pic < (size_t) n_pics)
+                        __builtin_nontemporal_store(v, p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic + d) * pitch16 + x + piece);
+                }
+        } else {
+#pragma unroll 2
+            for (int i = 0; i < 8; i++) {
+                const size_t line = wave * 64 + (size_t) i * 8 + lr, pic = line / lines_per_pic, l = line % lines_per_pic;
+                if (pic < (size_t) n_pics) {
+                    v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + x + piece;
+                    for (int d = 0; d < dups; d++) { if (VAR == 1) row[(size_t) d * pitch16] = v; else __builtin_nontemporal_store(v, row + (size_t) d * pitch16); }
+                }
+            }
+        }
+    }
+}
+// the encoder's read pattern at 1080p: a wave owns 64 image rows `row_step` rows apart, reads 128-byte pieces (8 lanes x 16 B) of
+// each, DEPTH tiles in flight
+template <int DEPTH, int NT>
+__global__ void __launch_bounds__(64) k_rows_read(const v4i *p, size_t pitch16, int rows_per_pic, int lines_per_pic, int n_pics, int *out)
+{
+    const int lane = threadIdx.x, piece = lane % 8, lr = lane / 8;
+    const size_t wave = blockIdx.x;
+    const v4i *rowp[8];
+    for (int i = 0; i < 8; i++) {
+        size_t line = wave * 64 + (size_t) i * 8 + lr, pic = line / lines_per_pic, l = line % lines_per_pic;
+        if (pic >= (size_t) n_pics) { pic = 0; l = 0; }
+        rowp[i] = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + piece;
+    }
+    int acc = 0;
+    v4i buf[DEPTH][8];
+    const size_t tiles = pitch16 / 8;
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) buf[d][i] = NT ? __builtin_nontemporal_load(rowp[i] + d * 8) : rowp[i][d * 8];
+    for (size_t t = 0; t < tiles; t += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { acc += buf[d][i].x ^ buf[d][i].y ^ buf[d][i].z ^ buf[d][i].w; }
+            const size_t tn = t + d + DEPTH;
+            if (tn < tiles) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) buf[d][i] = NT ? __builtin_nontemporal_load(rowp[i] + tn * 8) : rowp[i][tn * 8];
+            }
+            // stand-in for the per-tile arithmetic of k_active (keeps the loads from being issued back to back)
+            for (int k = 0; k < 200; k++) acc = acc * 1664525 + 1013904223;
+        }
+    }
+    if (acc == 0x12345678) *out = acc;
+}
+
+static hipEvent_t e0, e1;
+template <class F> static double best_ms(F launch, int iters = 5)
+{
+    launch(); hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int it = 0; it < iters; it++) {
+        hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char **argv)
 {
     const size_t bytes = 12ull << 30, n16 = bytes / 16;
     v4i *a, *b; int *o;
-    hipMalloc(&a, bytes); hipMalloc(&b, bytes); hipMalloc(&o, 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto run = [&](const char *name, double gb, auto launch) {
-        launch(); hipDeviceSynchronize();
-        float best = 1e9f;
-        for (int it = 0; it < 5; it++) { hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
-        printf("%-44s %8.1f GB/s  (%.3f ms for %.1f GB)\n", name, gb / (best * 1e-3), best, gb);
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&o, 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(a, 1, bytes); hipMemset(b, 2, bytes);
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 1 && !strcmp(argv[1], "calib")) {
+        // one launch each, byte counts printed; kernel names are unique so the PMC csv can be joined by name
+        const size_t n1 = 1ull << 30;   // 1 GiB worth of useful bytes per pattern
+        hipLaunchKernelGGL((k_read<1, 4>), dim3(n1 / 16 / 1024), dim3(256), 0, 0, a, n1 / 16, o, 1);
+        hipLaunchKernelGGL((k_read<0, 4>), dim3(n1 / 16 / 1024), dim3(256), 0, 0, a, n1 / 16, o, 1);
+        hipLaunchKernelGGL((k_fill<1, 4>), dim3(n1 / 16 / 1024), dim3(256), 0, 0, b, n1 / 16, 1);
+        hipLaunchKernelGGL((k_fill<0, 4>), dim3(n1 / 16 / 1024), dim3(256), 0, 0, b, n1 / 16, 1);
+        // 64-byte pieces, one per 256 bytes (stride 16 x 16 B): useful bytes n1, 4 GiB span
+        hipLaunchKernelGGL(k_read_pieces64, dim3(n1 / 64 * 4 / 256), dim3(256), 0, 0, a, n1 / 64, (size_t) 16, o);
+        hipLaunchKernelGGL(k_write_pieces64, dim3(n1 / 64 * 4 / 256), dim3(256), 0, 0, b, n1 / 64, (size_t) 16);
+        hipLaunchKernelGGL(k_write_pieces64_unaligned, dim3(n1 / 64 * 4 / 256), dim3(256), 0, 0, (char *) b, n1 / 64, (size_t) 256, 28);
+        // scattered 16-byte windows, one per 256 bytes: useful bytes n1 / 4
+        hipLaunchKernelGGL(k_read_scatter16, dim3(n1 / 64 / 256), dim3(256), 0, 0, a, n1 / 64, (size_t) 16, o);
+        hipDeviceSynchronize();
+        printf("calib: k_read<1,4> %zu B nt 16B/lane | k_read<0,4> %zu B plain | k_fill<1,4> %zu B nt | k_fill<0,4> %zu B plain | "
+               "k_read_pieces64 %zu B | k_write_pieces64 %zu B | k_write_pieces64_unaligned %zu B | k_read_scatter16 %zu B\n",
+               n1, n1, n1, n1, n1, n1, n1, n1 / 4);
+        return 0;
+    }
+    printf("# tools/ubench_hbm.hip on MI355X, %.1f GB per test, best of 5; GB/s = useful bytes / time (copy: read + written)\n", bytes / 1e9);
+    struct Best { double gbps = 0; char what[96] = ""; } bf, br, bc;
+    auto note = [&](Best &bst, const char *kind, const char *geom, double gb, double ms) {
+        const double g = gb / (ms * 1e-3);
+        printf("%-6s %-44s %8.1f GB/s (%.3f ms)\n", kind, geom, g, ms);
+        if (g > bst.gbps) { bst.gbps = g; snprintf(bst.what, sizeof(bst.what), "%s", geom); }
     };
-    const int grid = 256 * 32;
-    run("fill, plain 16-byte stores", bytes / 1e9, [&] { hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, 0, a, n16, 0); });
-    run("fill, nontemporal 16-byte stores", bytes / 1e9, [&] { hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, 0, a, n16, 1); });
-    run("read, nontemporal 16-byte loads", bytes / 1e9, [&] { hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, n16, o); });
-    run("copy (read + write bytes counted)", 2.0 * bytes / 1e9, [&] { hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, a, b, n16); });
-    // 1080p pictures: pitch 7680 B, 240 lines x 4 duplicated rows: one block = 60 lines
+    char geom[96];
+    const int blocks[] = { 256, 512, 1024 };
+    for (int bi = 0; bi < 3; bi++) {
+        const int bs = blocks[bi];
+        for (int mult = 2; mult <= 64; mult *= 2) {          // grid-stride: 256 CUs x mult blocks
+            const int grid = 256 * mult;
+            snprintf(geom, sizeof(geom), "grid-stride nt  block %4d grid %6d", bs, grid);
+            note(bf, "fill", geom, bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_fill<1, 1>), dim3(grid), dim3(bs), 0, 0, a, n16, 0); }));
+            note(br, "read", geom, bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_read<1, 1>), dim3(grid), dim3(bs), 0, 0, a, n16, o, 0); }));
+            note(bc, "copy", geom, 2.0 * bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_copy<1, 1>), dim3(grid), dim3(bs), 0, 0, a, b, n16, 0); }));
+        }
+#define CHUNKED(U) do { \
+            const unsigned grid = (unsigned) ((n16 + (size_t) bs * U - 1) / ((size_t) bs * U)); \
+            snprintf(geom, sizeof(geom), "chunked nt      block %4d x%d (%u blocks)", bs, U, grid); \
+            note(bf, "fill", geom, bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_fill<1, U>), dim3(grid), dim3(bs), 0, 0, a, n16, 1); })); \
+            note(br, "read", geom, bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_read<1, U>), dim3(grid), dim3(bs), 0, 0, a, n16, o, 1); })); \
+            note(bc, "copy", geom, 2.0 * bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_copy<1, U>), dim3(grid), dim3(bs), 0, 0, a, b, n16, 1); })); \
+            snprintf(geom, sizeof(geom), "chunked plain   block %4d x%d (%u blocks)", bs, U, grid); \
+            note(bf, "fill", geom, bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_fill<0, U>), dim3(grid), dim3(bs), 0, 0, a, n16, 1); })); \
+            note(br, "read", geom, bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_read<0, U>), dim3(grid), dim3(bs), 0, 0, a, n16, o, 1); })); \
+            note(bc, "copy", geom, 2.0 * bytes / 1e9, best_ms([&] { hipLaunchKernelGGL((k_copy<0, U>), dim3(grid), dim3(bs), 0, 0, a, b, n16, 1); })); \
+        } while (0)
+        CHUNKED(1); CHUNKED(2); CHUNKED(4); CHUNKED(8);
+    }
+    printf("BEST fill %8.1f GB/s  [%s]\nBEST read %8.1f GB/s  [%s]\nBEST copy %8.1f GB/s  [%s]\n", bf.gbps, bf.what, br.gbps, br.what, bc.gbps, bc.what);
+    // the decoder's store pattern at 1080p: pitch 7680 B, 240 lines per picture, each written to 3 or 4 rows of 1080
     const size_t pitch16 = 7680 / 16;
     const int pics = (int) (bytes / (7680ull * 1080));
-    run("picture rows: 128-byte pieces x 4 duplicated rows", pics * 7680.0 * 960 / 1e9,
-        [&] { hipLaunchKernelGGL(k_rows, dim3(pics * 4), dim3(256), 0, 0, a, pitch16, 60, 4); });
+    const int waves = (pics * 240 + 63) / 64;
+    for (int dups = 1; dups <= 4; dups++) {
+        const double gb = (double) pics * 240 * dups * 7680.0 / 1e9;
+        snprintf(geom, sizeof(geom), "picture rows, 128-byte pieces x %d rows", dups);
+        printf("%-6s %-44s %8.1f GB/s\n", "rows", geom, gb / (best_ms([&] { hipLaunchKernelGGL((k_rows<8>), dim3(waves), dim3(64), 0, 0, a, pitch16, 240, dups, 1080, pics); }) * 1e-3));
+        snprintf(geom, sizeof(geom), "picture rows, 256-byte pieces x %d rows", dups);
+        printf("%-6s %-44s %8.1f GB/s\n", "rows", geom, gb / (best_ms([&] { hipLaunchKernelGGL((k_rows<16>), dim3(waves), dim3(64), 0, 0, a, pitch16, 240, dups, 1080, pics); }) * 1e-3));
+        snprintf(geom, sizeof(geom), "picture rows, 64-byte pieces x %d rows", dups);
+        printf("%-6s %-44s %8.1f GB/s\n", "rows", geom, gb / (best_ms([&] { hipLaunchKernelGGL((k_rows<4>), dim3(waves), dim3(64), 0, 0, a, pitch16, 240, dups, 1080, pics); }) * 1e-3));
+    }
+    {
+        const int dups = 4;
+        const double gb = (double) pics * 240 * dups * 7680.0 / 1e9;
+#define VARIANT(V, name, blk) do { const int wpb = (blk) / 64; \
+            printf("%-6s %-44s %8.1f GB/s\n", "rowsv", name, gb / (best_ms([&] { hipLaunchKernelGGL((k_rows_var<V>), dim3((waves + wpb - 1) / wpb), dim3(blk), 0, 0, a, pitch16, 240, dups, 1080, pics, waves); }) * 1e-3)); } while (0)
+        VARIANT(0, "baseline nt, 128 B x 4 rows", 64);
+        VARIANT(1, "plain stores", 64);
+        VARIANT(2, "row copies in the outer loop", 64);
+        VARIANT(3, "XCD-aware line-group map", 64);
+        VARIANT(4, "1 KB of one row per instruction", 64);
+        VARIANT(5, "256-thread blocks", 256);
+        // dense pictures (no skipped rows: 960-row pictures)
+        printf("%-6s %-44s %8.1f GB/s\n", "rowsv", "baseline, dense 960-row pictures", gb / (best_ms([&] { hipLaunchKernelGGL((k_rows_var<0>), dim3(waves), dim3(64), 0, 0, a, pitch16, 240, dups, 960, pics, waves); }) * 1e-3));
+        // reads: 236 of 1080 rows per picture
+        const int rwaves = (pics * 236 + 63) / 64;
+        const double rgb = (double) pics * 236 * 7680.0 / 1e9;
+#define RVAR(D, NT_) printf("%-6s read rows 128-byte pieces depth %d %s            %8.1f GB/s\n", "rowsr", D, NT_ ? "nt   " : "plain", \
+            rgb / (best_ms([&] { hipLaunchKernelGGL((k_rows_read<D, NT_>), dim3(rwaves), dim3(64), 0, 0, a, pitch16, 1080, 236, pics, o); }) * 1e-3))
+        RVAR(1, 1); RVAR(2, 1); RVAR(3, 1); RVAR(1, 0); RVAR(2, 0);
+    }
     return 0;
 }
