@@ -207,9 +207,17 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
         blob_crcs = [int(c.item()) for c in allc]
     crt._load_field_state(s)
 
+    seq_rounds = []
+
     def step(k):
         if wl.get("sequence"):
-            crt.sequence(s, noise)
+            if dist is None:
+                crt.sequence(s, noise)
+            else:
+                # ONE video of world * n fields cut over the ranks (last row): sync state by all_gather,
+                # the picture handed from rank to rank (shard.sequence_sharded)
+                seq_rounds.append(shard.sequence_sharded(shard.CrtSequenceEngine(crt, s, noise), dist, rank, world, world * n,
+                                                         0, 0, 194, None, 0, dev, (outh, outw, 4)))
             return
         crt.fieldpass(s, noise, params=p)
         if not nes:        # next field of the interlaced sequence (video_convert.c:261-267)
@@ -318,7 +326,9 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
         "value": fps, "unit": "frames/sec", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
         "config": {"workload": wl["desc"], "fields_per_gpu_per_step": n, "frames_per_step": world * n,
                    "sharding": "frames by rank, RCCL broadcast of settings only",
-                   "mode": "one video per GPU (crthip_sequence)" if wl.get("sequence") else "independent frames (crthip_fieldpass)",
+                   "mode": ("one video cut over the ranks (shard.sequence_sharded), %s exchange round(s) per step" % sorted(set(seq_rounds))
+                            if seq_rounds else "one video per GPU (crthip_sequence)") if wl.get("sequence")
+                           else "independent frames (crthip_fieldpass)",
                    "launch": launch_mode},
         "roofline": {"bound": "hbm", "kernel": "k_" + dom,
                      # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration

@@ -71,8 +71,13 @@ extern "C" {
 #ifndef CRT_DO_BLOOM
 #define CRT_DO_BLOOM    0
 #endif
+/* look for VSYNC / HSYNC (crt_core.h:71-72): -DCRT_DO_VSYNC=0 / -DCRT_DO_HSYNC=0 give the reference's other builds */
+#ifndef CRT_DO_VSYNC
 #define CRT_DO_VSYNC    1
+#endif
+#ifndef CRT_DO_HSYNC
 #define CRT_DO_HSYNC    1
+#endif
 
 /* One television set.  The caller owns this object and the `out` image; the library keeps
  * device-side mirrors and re-reads / writes back the host copy on every call, so direct

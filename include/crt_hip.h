@@ -86,6 +86,18 @@ extern "C" {
  * past the image -- for odd fields of raw images with h <= desth.  With this flag the kernels read that row like
  * the reference does; without it they read row h - 1 instead and never touch memory behind an image. */
 #define CRTHIP_F_IMAGE_SPARE_ROW 16
+/* Further build-time switches of the reference as run-time flags (each is a #define in its sources / headers; 0 = the
+ * shipped build).  All of them reproduce the corresponding rebuilt reference bit for bit (tests/, oracle/_ref): */
+#define CRTHIP_F_NO_HSYNC     0x20    /* CRT_DO_HSYNC 0 (crt_core.h:72; crt_core.c:446-450): hsync = 0 after every line      */
+#define CRTHIP_F_NO_VSYNC     0x40    /* CRT_DO_VSYNC 0 (crt_core.h:71; crt_core.c:323-341): field parity found in the CLEAN
+                                         signal, vsync = -3 from then on                                                    */
+#define CRTHIP_F_VHS_LCG_NOISE 0x80   /* CRT_VHS_NOISE 0 (crt_ntscvhs.h:29; crt_core.c:343-357): the VHS build with the LCG
+                                         noise of every other system, no rand() stream                                      */
+#define CRTHIP_F_NES_BORDER   0x1000  /* NES_BORDER 1 (crt_nes.c:69,138-160): crthip_params.nes_border_color right of the picture,
+                                         lines CRT_TOP .. CRT_BOT + 2, rewritten by every crt_modulate                      */
+#define CRTHIP_F_HIPASS       0x800   /* HIPASS 1 (crt_ntsc.c:115-126 and its siblings): iirf returns s - h ("for debugging") */
+#define CRTHIP_F_VHS_LP       0x2000  /* VHS_MODE VHS_LP / VHS_EP (crt_ntscvhs.h:102-124): the encoder's band limits of the  */
+#define CRTHIP_F_VHS_EP       0x4000  /*   other two tape speeds                                                            */
 #define CRTHIP_F_EQ_FIR(taps)  ((taps) << 8)
 #define CRTHIP_F_EQ_FIR_MASK   (7 << 8)
 
@@ -143,7 +155,13 @@ typedef struct crthip_params {
     /* source column of destination sample x, crt_ntsc.c:272: x * w / destw == (x * col_step) >> 32 with
      * col_step = ceil(2^32 * w / destw), exact while x * destw < 2^32 */
     unsigned col_step_lo, col_step_hi;
-    int reserved[4];
+    /* Decoder envelope: the largest carrier amplitude |wave| for which the I / Q equalisers' low cascades
+     * can be dropped.  crthip_params_finalize sets the bound that holds for ANY inp[] (|s| <= 127: 65 532); the fused entry
+     * points (crthip_fieldpass, crthip_sequence), which produce inp[] themselves, raise it from the signal range they know
+     * (sync level ... white level + noise term).  A performance hint only: every setting gives identical pictures. */
+    int loskip_wave_max;
+    int nes_border_color; /* user: NTSC_SETTINGS.border_color (crt_nes.h:136), drawn with CRTHIP_F_NES_BORDER */
+    int reserved[2];
 } crthip_params;
 
 /*
@@ -314,7 +332,7 @@ int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
  * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,
  * "24-bit multiply envelope"), everything else goes to the exact 32-bit instantiation.  Both
  * give identical results; this switch forces the 32-bit kernels everywhere (tests, debugging).
- * on: 0 automatic, 1 exact kernels only, 2 no 64-bit-mad tiers, 3 64-bit-mad tier but all filter cascades. */
+ * on: 0 automatic, 1 exact kernels only, 2 no 64-bit-mad tiers, 3 never drop the I/Q low cascades (= 2 since round 3). */
 int  crthip_set_exact(crthip_ctx *ctx, int on);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py roofline leg).

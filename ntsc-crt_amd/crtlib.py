@@ -19,6 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SYSTEM_NTSC, SYSTEM_NES, SYSTEM_PV1K, SYSTEM_SNES, SYSTEM_TEMP, SYSTEM_VHS, SYSTEM_NESRGB = 0, 1, 2, 3, 4, 5, 6
 FMT_RGB, FMT_BGR, FMT_ARGB, FMT_RGBA, FMT_ABGR, FMT_BGRA = range(6)
 F_NES_SETUP, F_VHS_DRAW_ABERRATION, F_BLOOM, F_IMAGE_SPARE_ROW = 2, 4, 8, 16
+F_NO_HSYNC, F_NO_VSYNC, F_VHS_LCG_NOISE, F_HIPASS, F_VHS_LP, F_VHS_EP, F_NES_BORDER = 0x20, 0x40, 0x80, 0x800, 0x2000, 0x4000, 0x1000
 K_NAMES = ("template", "active", "noise", "sync", "decode")
 MAX_VPER, MAX_CCS, CARRIER_ROWS = 5, 5, 10
 STATE_INTS = 36      # sizeof(crthip_state) / 4
@@ -34,11 +35,23 @@ SYSTEMS = {"ntsc": (SYSTEM_NTSC, 1), "vhs": (SYSTEM_VHS, 1), "nes": (SYSTEM_NES,
 DOT_CRAWL_SYSTEMS = (SYSTEM_NES, SYSTEM_NESRGB, SYSTEM_SNES, SYSTEM_PV1K, SYSTEM_TEMP)
 
 
+# the reference's remaining build-time switches as names: base system + crthip_params.flags
+VARIANTS = {"vhslp": ("vhs", F_VHS_LP), "vhsep": ("vhs", F_VHS_EP), "vhslcg": ("vhs", F_VHS_LCG_NOISE),
+            "ntscnovsync": ("ntsc", F_NO_VSYNC), "ntscnohsync": ("ntsc", F_NO_HSYNC), "ntschipass": ("ntsc", F_HIPASS),
+            "nesborder": ("nes", F_NES_BORDER)}
+
+
 def split_system(name):
-    """'ntscbloom' -> ('ntsc', True)"""
+    """'ntscbloom' -> ('ntsc', True); a VARIANTS name -> its base system (variant_flags gives the flags)"""
+    if name in VARIANTS:
+        return VARIANTS[name][0], False
     if name.endswith("bloom"):
         return name[:-5], True
     return name, False
+
+
+def variant_flags(name):
+    return VARIANTS[name][1] if name in VARIANTS else 0
 
 
 class Params(C.Structure):
@@ -57,7 +70,7 @@ class Params(C.Structure):
         ("eq_g", (C.c_int * 3) * 3), ("huesn", C.c_int), ("huecs", C.c_int),
         ("bright", C.c_int), ("white", C.c_int), ("ire_base", C.c_int), ("dx", C.c_int),
         ("ratio", C.c_int), ("eq_kernel", C.c_int), ("bloom", C.c_int), ("bloom_max_e", C.c_int),
-        ("col_step_lo", C.c_uint), ("col_step_hi", C.c_uint), ("reserved", C.c_int * 4)]
+        ("col_step_lo", C.c_uint), ("col_step_hi", C.c_uint), ("loskip_wave_max", C.c_int), ("nes_border_color", C.c_int), ("reserved", C.c_int * 2)]
 
 
 def bpp4fmt(fmt):
@@ -122,10 +135,12 @@ def load_library():
 def make_params(system="ntsc", **kw):
     """crthip_params_default + user fields + crthip_params_finalize (host only, no GPU needed)."""
     L = load_library()
+    name_in = system
     system, bloom = split_system(system)
     sysid, pattern = SYSTEMS[system]
     if bloom:
         kw["flags"] = kw.get("flags", 0) | F_BLOOM
+    kw["flags"] = kw.get("flags", 0) | variant_flags(name_in)
     p = Params()
     rc = L.crthip_params_default(C.byref(p), sysid, pattern)
     if rc:
@@ -146,7 +161,7 @@ class Settings:
     ``frame`` (or ``dot_crawl_offset`` for NES) may be ints or per-image sequences."""
 
     def __init__(self, data, format=FMT_BGRA, raw=0, as_color=1, field=0, frame=0, hue=0,
-                 xoffset=0, yoffset=0, dot_crawl_offset=0, aberration=0, spare_row=None):
+                 xoffset=0, yoffset=0, dot_crawl_offset=0, aberration=0, spare_row=None, border_color=0):
         self.data = data
         # CRTHIP_F_IMAGE_SPARE_ROW: every image is followed by one more readable row (the reference reads row h,
         # crt_ntsc.c:263).  None = detect from the tensor: stride(0) and the storage behind the last image cover it.
@@ -156,6 +171,7 @@ class Settings:
         self.xoffset, self.yoffset = xoffset, yoffset
         self.dot_crawl_offset = dot_crawl_offset
         self.aberration = aberration
+        self.border_color = border_color  # NES, NES_BORDER builds (crt_nes.h:136)
         self.initialized = 0          # iirs_initialized / field_initialized
 
 
@@ -271,7 +287,7 @@ class CRT:
                            out_format=self.out_format, mon_hue=self.hue, brightness=self.brightness,
                            contrast=self.contrast, saturation=self.saturation, black_point=self.black_point,
                            white_point=self.white_point, scanlines=self.scanlines, blend=self.blend,
-                           v_fac=self.v_fac, noise=noise, flags=flags)
+                           v_fac=self.v_fac, noise=noise, flags=flags, nes_border_color=getattr(s, "border_color", 0))
 
     def _has_spare_row(self, s):
         if s.spare_row is not None:

@@ -314,6 +314,26 @@ monitor_params(crthip_params *p, const struct CRT *v)
 #if CRT_DO_BLOOM
     p->flags |= CRTHIP_F_BLOOM;                     /* crt_core.h:70 */
 #endif
+    /* the reference's other build-time switches, selected like there: by the macros this file is compiled with */
+#if !CRT_DO_VSYNC
+    p->flags |= CRTHIP_F_NO_VSYNC;                  /* crt_core.h:71 */
+#endif
+#if !CRT_DO_HSYNC
+    p->flags |= CRTHIP_F_NO_HSYNC;                  /* crt_core.h:72 */
+#endif
+#ifdef CRT_HIPASS
+    p->flags |= CRTHIP_F_HIPASS;                    /* HIPASS 1, crt_ntsc.c:115 */
+#endif
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+#if !CRT_VHS_NOISE
+    p->flags |= CRTHIP_F_VHS_LCG_NOISE;             /* crt_ntscvhs.h:29 */
+#endif
+#if (VHS_MODE == VHS_LP)
+    p->flags |= CRTHIP_F_VHS_LP;
+#elif (VHS_MODE == VHS_EP)
+    p->flags |= CRTHIP_F_VHS_EP;
+#endif
+#endif
 }
 
 /*
@@ -349,7 +369,7 @@ unpark_libc_rand(int *lib)
     setstate((char *) lib);
 }
 
-#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS) && CRT_VHS_NOISE
 static unsigned *d_hist_buf;
 
 /* the generator's history y[n-31 .. n-1] in logical order, out of the parked state array */
@@ -521,6 +541,10 @@ crt_modulate(struct CRT *v, struct NTSC_SETTINGS *s)
 #if HAS_DOT_CRAWL
     aux = s->dot_crawl_offset;
 #endif
+#if (CRT_SYSTEM == CRT_SYSTEM_NES) && defined(NES_BORDER) && NES_BORDER
+    p.flags |= CRTHIP_F_NES_BORDER;                 /* crt_nes.c:69 */
+    p.nes_border_color = (int) s->border_color;
+#endif
 #if (CRT_SYSTEM == CRT_SYSTEM_NES) || (CRT_SYSTEM == CRT_SYSTEM_NESRGB)
     /* crt_nes.c:118-121, crt_nesrgb.c:63-66: the sync skeleton is only written on the first call */
     if (!s->field_initialized) {
@@ -663,7 +687,7 @@ crt_demodulate(struct CRT *v, int noise)
         }
     }
     state_to_device(sl, v, 0, 0, 0);
-#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS)
+#if (CRT_SYSTEM == CRT_SYSTEM_NTSCVHS) && CRT_VHS_NOISE
     {
         unsigned hist[32];
         read_libc_rand(lib, hist);

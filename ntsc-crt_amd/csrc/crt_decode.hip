@@ -192,7 +192,10 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
 /* decoder output tile: PXT pixels per row (16: 64-byte store pieces, less LDS -> more waves, best for
  * narrow pictures that are ALU bound; 32: full 128-byte lines per store piece group, best for wide
  * pictures that lean on HBM write bandwidth) */
-/* TIER: 0 = 64-bit-mad stages without the I/Q low cascades, 1 = 64-bit-mad stages, 2 = 24-bit mads,
+/* TIER: 0 = 64-bit-mad stages without the I/Q low cascades, carrier products by v_mul_i32_i24 (|wave| <= 65532);
+ * 1 = the same with the carrier products by v_mad_i64_i32 (|wave| <= crthip_params.loskip_wave_max <= 120000: a carrier
+ * << 7 is no 24-bit multiplier any more, the cascades can still be dropped -- the NES at its default saturation);
+ * 2 = 24-bit mads, all cascades (also every line flagged CRTHIP_LINE_KEEPLO),
  * 3 = exact 32-bit multiplies; 4 / 5 = the FIR kernels of a USE_CONVOLUTION build (P.eq_kernel taps; the whole
  * batch) with 24-bit / exact 32-bit multiplies around them; a wave of 64 lines is decoded by the kernel
  * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
@@ -224,6 +227,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
      * runs once, not once per tier */
     int tier = __ballot(lp.nrows & CRTHIP_LINE_EXACT) ? 3 : __ballot(lp.nrows & CRTHIP_LINE_NOT64) ? 2
              : __ballot(lp.nrows & CRTHIP_LINE_WIDE) ? 1 : 0;
+    /* a line that needs its I/Q low cascades takes the 24-bit tier (tiers 0 and 1 have none) */
+    if (tier < 2 && __ballot(lp.nrows & (int) CRTHIP_LINE_KEEPLO) != 0ull) tier = 2;
     if (min_tier >= 4) tier = (min_tier == 5 || tier == 3) ? 5 : 4;     /* FIR build: 24-bit envelope as for tier 2 */
     else if (tier < min_tier) tier = min_tier;
     if (tier != TIER) return;
@@ -248,8 +253,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     if constexpr (S::CCS == 5) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            w5i[i] = ((lp.wave0 * P.dem_cs[0][i] + lp.wave1 * P.dem_sn[0][i]) >> 15) * P.saturation;
-            w5q[i] = ((lp.wave0 * P.dem_cs[1][i] + lp.wave1 * P.dem_sn[1][i]) >> 15) * P.saturation;
+            w5i[i] = ((lp.wave0 * P.dem_cs[0][i] + lp.wave1 * P.dem_sn[0][i]) >> 15) * P.saturation * WSCALE;
+            w5q[i] = ((lp.wave0 * P.dem_cs[1][i] + lp.wave1 * P.dem_sn[1][i]) >> 15) * P.saturation * WSCALE;
         }
     }
     int ph5 = 0;                                   /* sample index % 5 */
@@ -331,13 +336,15 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 int cy, ci, cq;
                 if (TIER == 0) {
                     /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
-                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
+                    cy = eq_step64<true, GY1, GY2, false>(wy, ylfm, yhfm, pair_of(s + bright));
                     ci = eq_step64_chroma<false, 1311>(wi_, ilfm, ihfm, __mul24(s, wi)) >> 3;   /* wi, wq: carriers << 7 here */
                     cq = eq_step64_chroma<false, 0>(wq_, qlfm, qhfm, __mul24(s, wq)) >> 3;
                 } else if (TIER == 1) {
-                    cy = eq_step64<true, 8192, 9175, false>(wy, ylfm, yhfm, pair_of(s + bright));
-                    ci = eq_step64_chroma<true, 1311>(wi_, ilfm, ihfm, s * wi) >> 3;            /* 32-bit product: |wi| < 2^24 */
-                    cq = eq_step64_chroma<true, 0>(wq_, qlfm, qhfm, s * wq) >> 3;
+                    /* carriers << 7 beyond 24 bits: the products come from the 64-bit multiply-add (exact low dword,
+                     * |s * (wave << 7)| < 2^31 up to |wave| = 120000) */
+                    cy = eq_step64<true, GY1, GY2, false>(wy, ylfm, yhfm, pair_of(s + bright));
+                    ci = eq_step64_chroma<false, 1311>(wi_, ilfm, ihfm, mul_lo_mad64(s, wi)) >> 3;
+                    cq = eq_step64_chroma<false, 0>(wq_, qlfm, qhfm, mul_lo_mad64(s, wq)) >> 3;
                 } else if (FIR) {
                     const int uy = s + bright, ui = mulq<FAST>(s, wi) >> 9, uq = mulq<FAST>(s, wq) >> 9;
 #define CRT_FIR3(M) do { cy = fir_step<M>(fy, uy, k) << 4; ci = fir_step<M>(fi, ui, k) >> 3; cq = fir_step<M>(fq, uq, k) >> 3; } while (0)
@@ -489,14 +496,32 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
 static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 {
     const int b = p->bright < 0 ? -p->bright : p->bright;
-    const int ct = p->contrast < 0 ? -p->contrast : p->contrast;
-    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23) || c->sd.cc_samples != 4) return 3;   /* 5-sample system: exact kernel only */
-    const bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
-                         p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
-                         p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
-    /* ... and |contrast| <= 2^15: tiers 0 / 1 take ((v >> 12) * contrast) >> 8 from an exact 64-bit product (see D9) */
-    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX || ct > 32768) return 2;
-    return c->no_loskip ? 1 : 0;
+    const long ct = p->contrast < 0 ? -(long) p->contrast : (long) p->contrast;
+    if (c->force_exact || b > FAST_BRIGHT_MAX || ct >= (1 << 23)) return 3;
+    /* the 64-bit-mad tiers: luma coefficients near 2^16 (the form x' = hi32(((c - 2^16) << 16) * d + {2^31, u})), chroma ones
+     * below 2^15 */
+    bool coef_ok = p->eq_lf[0] >= 32768 && p->eq_lf[0] < 98304 && p->eq_hf[0] >= 32768 && p->eq_hf[0] < 98304 &&
+                   p->eq_lf[1] > 0 && p->eq_lf[1] < 32768 && p->eq_hf[1] > 0 && p->eq_hf[1] < 32768 &&
+                   p->eq_lf[2] > 0 && p->eq_lf[2] < 32768 && p->eq_hf[2] > 0 && p->eq_hf[2] < 32768;
+    /* ... and no luma stage may wrap in the reference: stage k of a cascade with alpha = c / 2^16 obeys
+     * |x_k| <= (alpha |x_(k-1)| + 1) / (1 - |1 - alpha|), its product is c * (x_(k-1) - x_k) */
+    for (int cas = 0; cas < 2 && coef_ok; cas++) {
+        const double cf = cas ? p->eq_hf[0] : p->eq_lf[0], al = cf / 65536.0, den = 1.0 - (al > 1.0 ? al - 1.0 : 1.0 - al);
+        double prev = 127.0 + b, worst = 0.0;
+        for (int k = 0; k < 4; k++) {
+            const double cur = (al * prev + 1.0) / den + 1.0;
+            if (prev + cur > worst) worst = prev + cur;
+            prev = cur;
+        }
+        if (cf * worst + 32768.0 >= 2147483647.0) coef_ok = false;
+    }
+    if (c->no_tier0 || !coef_ok || b > T0_BRIGHT_MAX) return 2;
+    /* ... and ((v >> 12) * contrast) >> 8 must not wrap in the reference, because tiers 0 / 1 take it from an exact 64-bit
+     * product (D9): |luma| <= 10 U + 64 with U = 127 + |bright| (both luma gain sets), |chroma| <= 3870,
+     * |v| <= 4 * 4095 * |luma| + (4530 + 7021) * |chroma| */
+    const long vmax = 16380L * (10L * (127 + b) + 64) + 11551L * 3870L;
+    if (((vmax >> 12) + 1) * ct >= (1L << 31)) return 2;
+    return c->no_loskip ? 2 : 0;                /* crthip_set_exact(3): keep the I/Q low cascades = the 24-bit tier */
 }
 
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
@@ -537,7 +562,7 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_DECODE(T, B3) \
-    do { if constexpr (S::CCS != 4 && T != 3) break; /* the 5-sample system only has the exact kernel (min_tier 3) */ \
+    do { if constexpr (S::CCS != 4 && T >= 4) break; /* no FIR build of the 5-sample system */ \
          else if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); \
          else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank); } while (0)
             /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */

@@ -56,7 +56,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
     {
         const int g4 = (blockIdx.x * LPW / 4) * 4 + lrow;
         int fl = 0;
-        if (g4 < total) fl = lines[g4].nrows & (CRTHIP_LINE_WIDE | CRTHIP_LINE_NOT64 | CRTHIP_LINE_EXACT);
+        if (g4 < total) fl = lines[g4].nrows & ((int) CRTHIP_LINE_KEEPLO | CRTHIP_LINE_NOT64 | CRTHIP_LINE_EXACT);
         const bool grp_wide = force_wide || __ballot(fl != 0) != 0ull;
         if (grp_wide == NARROW) return;
     }

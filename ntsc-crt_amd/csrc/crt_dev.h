@@ -90,6 +90,7 @@ struct NesTiming : SysCommon {   /* crt_nes.h:30-126, crt_nesrgb.h, crt_snes.h (
     static constexpr int AV_BEG = 74 * HRES / 341;
     static constexpr int AV_LEN = 256 * HRES / 341;
     static constexpr int VS_SEP_END = 327 * HRES / 341;
+    static constexpr int LAV_BEG = 58 * HRES / 341;     /* crt_nes.h:114: where the border colour starts (NES_BORDER builds) */
     static constexpr bool IS_NES = true, NES_TIMING = true, LINE_ROWS = true, BANDLIMIT = false, FIELD_ROWS = false;
 };
 struct SysNTSC : RgbTiming<2275> { static constexpr int SYSTEM = CRTHIP_SYSTEM_NTSC, PATTERN = 1; };
@@ -169,15 +170,38 @@ template <class S> __device__ __forceinline__ int carrier_row(int n, int field, 
 #define CRTHIP_LINE_NROWS_MASK 0xffff     /* crthip_line.nrows bits 0-15: rows written              */
 #define CRTHIP_LINE_RANK_SHIFT 16         /* bits 16-27: rank among lines starting on the same row   */
 #define CRTHIP_LINE_RANK_MASK  0xfff
-#define CRTHIP_LINE_WIDE  0x10000000      /* bit 28: chroma too strong to drop the I/Q low cascades (decoder tier 0) */
+#define CRTHIP_LINE_WIDE  0x10000000      /* bit 28: carrier << 7 is no 24-bit multiplier any more (decoder tier 0 -> 1) */
 #define CRTHIP_LINE_NOT64 0x20000000      /* bit 29: outside the no-wrap envelope of the 64-bit-mad decoder */
-#define LOSKIP_WAVE_MAX   65532           /* |wave[k]| bound of decoder tier 0: |s*wave >> 9| <= 16383 */
+#define CRTHIP_LINE_KEEPLO 0x80000000     /* bit 31: chroma too strong to drop the I/Q low cascades (crthip_params.loskip_wave_max) */
+#define LOSKIP_WAVE_MAX   65532           /* |wave[k]| bound of decoder tier 0's products: (wave << 7) fits 24 bits; also the
+                                             no-low-cascade bound for arbitrary inp[] (|s * wave >> 9| <= 16383) */
 #define T0_WAVE_MAX       120000          /* |wave[k]| bound of decoder tiers 0 and 1 */
 #define T0_BRIGHT_MAX     2600            /* |bright| bound of decoder tiers 0 and 1  */
 #define FAST_WAVE_MAX     524288          /* |wave[k]| bound of the fast decoder, 2^19 */
 #define FAST_BRIGHT_MAX   130000          /* |bright| bound of the fast decoder        */
 #define LCG_MUL 214019u          /* crt_core.c:359 */
 #define LCG_ADD 140327895u
+
+/* decoder tier flags of a line (crthip_line.nrows) from its carrier amplitude.  4 samples per chroma cycle: wave0 / wave1
+ * are the carriers themselves.  5 samples (PV-1000): they are dci / dcq and the five carriers are
+ * ((dci * cos_i + dcq * sin_i) >> 15) * saturation with |cos|, |sin| <= 32767 (crt_core.c:497-505), so
+ * |carrier| <= (|dci| + |dcq| + 1) * |saturation|. */
+template <int CCS>
+__device__ __forceinline__ int line_tier_flags(int wave0, int wave1, int saturation, int loskip_wave_max, bool reads_tail)
+{
+    /* a window that runs past the end of the field reads the struct members mirrored there (CRTHIP_TAIL): any byte value */
+    if (reads_tail && loskip_wave_max > LOSKIP_WAVE_MAX) loskip_wave_max = LOSKIP_WAVE_MAX;
+    long a;
+    const long a0 = wave0 < 0 ? -(long) wave0 : wave0, a1 = wave1 < 0 ? -(long) wave1 : wave1;
+    if (CCS == 4) a = a0 > a1 ? a0 : a1;
+    else a = (a0 + a1 + 1) * (saturation < 0 ? -(long) saturation : (long) saturation);
+    if (a > FAST_WAVE_MAX) return CRTHIP_LINE_EXACT;
+    if (a > T0_WAVE_MAX) return CRTHIP_LINE_NOT64;
+    int f = 0;
+    if (a > LOSKIP_WAVE_MAX) f |= CRTHIP_LINE_WIDE;
+    if (a > loskip_wave_max) f |= (int) CRTHIP_LINE_KEEPLO;
+    return f;
+}
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) unaligned16 { v4i v; };
@@ -322,6 +346,13 @@ __device__ __forceinline__ int dot2_vs(int v, int k_uniform, int acc)
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(k_uniform), "v"(acc));
     return r;
 }
+/* the low 32 bits of a * b through the (full rate) 64-bit multiply-add: the wrapped 32-bit product, vgpr * vgpr */
+__device__ __forceinline__ int mul_lo_mad64(int a, int b)
+{
+    long r, carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
+    return (int) r;
+}
 /* v_mad_i64_i32 with a zero addend */
 __device__ __forceinline__ long mad64_vs0(int d, int m_uniform)
 {
@@ -398,6 +429,7 @@ struct crthip_ctx {
     signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields (cached: the burst table they were built from) */
     bool skel_valid;
     int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
+    int skel_border[4];         /* ... NES_BORDER: flag, colour, black point, white point */
     int skel_yo;                /* ... and the first active line (NES timing: the burst is only on the active lines) */
     int shape;                  /* crthip_set_shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel */
     int row_tile;               /* CRTHIP_ROW_TILE: samples per tile of the scanline-parallel decoder, 32 (default) or 16 */
@@ -414,6 +446,7 @@ struct crthip_ctx {
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
     int ac_tile;                /* encoder tile, same convention, by input width */
     int ac_tile_env;            /* CRTHIP_AC_TILE: overrides both (A/B measurements) */
+    bool sync_split;            /* crthip_fieldpass: the sync chain of the batch's second half under the decoder of the first */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join, ev_chunk[CRTHIP_MAX_CHUNKS];
@@ -531,6 +564,7 @@ int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed cha
                   crthip_state *d_state, bool advance_rn);
 int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
 int crt_run_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration);
+int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthip_state *d_state);
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
                  crthip_line *d_lines, int advance_rn);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,

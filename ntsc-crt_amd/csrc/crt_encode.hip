@@ -4,6 +4,31 @@
 /* ------------------------------------------------------------------------- */
 /* M4: blanking / sync / burst skeleton                                        */
 /* ------------------------------------------------------------------------- */
+/* NES PPU square wave, crt_nes.c:21-61 */
+__device__ __forceinline__ int ppu_level(int p, int phase)
+{
+    const int hue = p & 15;
+    if (hue >= 14) return 0;
+    int high = ((hue + phase) % 12) < 6;
+    if (hue == 0) high = 1;
+    if (hue == 13) high = 0;
+    /* active[] = {0300,0100,0500,0400,0600,0200}: emphasis bits attenuating this phase */
+    const int slot = (phase >> 1) % 6;
+    const int mask = slot == 0 ? 0300 : slot == 1 ? 0100 : slot == 2 ? 0500 : slot == 3 ? 0400 : slot == 4 ? 0600 : 0200;
+    const int emph = (p & 0700 & mask) != 0;
+    const int lum = (p >> 4) & 3;
+    /* IRE[(high<<3) + (emph<<2) + lum] */
+    int v;
+    if (high) {
+        v = emph ? (lum == 0 ? 26951 : lum == 1 ? 52181 : 83721)
+                 : (lum == 0 ? 43581 : lum == 1 ? 75693 : 112965);
+    } else {
+        v = emph ? (lum == 0 ? -17203 : lum == 1 ? -8028 : lum == 2 ? 19497 : 57342)
+                 : (lum == 0 ? -12042 : lum == 1 ? 0 : lum == 2 ? 34406 : 81427);
+    }
+    return v;
+}
+
 /* value of skeleton sample (line n, column t) and whether crt_modulate writes it.
  * RGB systems: crt_ntsc.c:205-252 (+ crt_ntscvhs.c:234-238), crt_snes.c:203-243, crt_template.c, crt_pv1k.c:190-231;
  * NES timing: crt_nes.c:81-104,173-178, crt_nesrgb.c:24-46,104-109 */
@@ -21,6 +46,21 @@ skeleton(const crthip_params &P, int n, int t, int field, int frame, int aux, bo
             int cb = P.burst[row][tc];
             val = (int) (signed char) ((S::BLANK + cb * S::BURST) >> 5);
             written = true;
+        }
+        if constexpr (S::IS_NES) {
+            /* NES_BORDER 1 (crt_nes.c:138-160): the border colour from LAV_BEG to the end of lines TOP .. BOT + 2, written by
+             * every crt_modulate before the picture (which then covers its own rectangle) */
+            if ((P.flags & CRTHIP_F_NES_BORDER) && n >= S::TOP && n <= S::BOT + 2 && t >= S::LAV_BEG) {
+                const int phase = 4 * ((n + (row - n % S::VPER)) % 3) + 6 + 3 * (t - S::LAV_BEG);   /* phasetab[(n + dco) % 3] + 6 */
+                const int p = t == S::LAV_BEG ? 0xf0 : P.nes_border_color;
+                int ire = S::BLACK + P.black_point;
+                ire += ppu_level(p, phase + 0);
+                ire += ppu_level(p, phase + 1);
+                ire += ppu_level(p, phase + 2);
+                ire += ppu_level(p, phase + 3);
+                val = (int) (signed char) ((ire * P.white_point / 100) >> 12);
+                written = true;
+            }
         }
         return written;
     } else {
@@ -124,31 +164,6 @@ __device__ __forceinline__ bool format_alpha_first(int format) { return format =
 __device__ __forceinline__ bool format_blue_low(int format)
 {
     return format == CRTHIP_FMT_BGR || format == CRTHIP_FMT_BGRA || format == CRTHIP_FMT_ABGR;
-}
-
-/* NES PPU square wave, crt_nes.c:21-61 */
-__device__ __forceinline__ int ppu_level(int p, int phase)
-{
-    const int hue = p & 15;
-    if (hue >= 14) return 0;
-    int high = ((hue + phase) % 12) < 6;
-    if (hue == 0) high = 1;
-    if (hue == 13) high = 0;
-    /* active[] = {0300,0100,0500,0400,0600,0200}: emphasis bits attenuating this phase */
-    const int slot = (phase >> 1) % 6;
-    const int mask = slot == 0 ? 0300 : slot == 1 ? 0100 : slot == 2 ? 0500 : slot == 3 ? 0400 : slot == 4 ? 0600 : 0200;
-    const int emph = (p & 0700 & mask) != 0;
-    const int lum = (p >> 4) & 3;
-    /* IRE[(high<<3) + (emph<<2) + lum] */
-    int v;
-    if (high) {
-        v = emph ? (lum == 0 ? 26951 : lum == 1 ? 52181 : 83721)
-                 : (lum == 0 ? 43581 : lum == 1 ? 75693 : 112965);
-    } else {
-        v = emph ? (lum == 0 ? -17203 : lum == 1 ? -8028 : lum == 2 ? 19497 : 57342)
-                 : (lum == 0 ? -12042 : lum == 1 ? 0 : lum == 2 ? 34406 : 81427);
-    }
-    return v;
 }
 
 /* Cooperative tile I/O of the lane-per-row encoders (see the comment above k_decode): the wave moves 64 rows x ACT
@@ -377,6 +392,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
         const int white = P.white, ire_base = P.ire_base, noise = P.noise;
         int hy = 0, hi = 0, hq = 0;
+        const bool hipass = (P.flags & CRTHIP_F_HIPASS) != 0;
         int cph = 0;                                              /* x % CCS for the 5-sample system (wave-uniform) */
         /* RGB -> YIQ coefficients by byte position (wave-uniform) */
         const bool alpha_first = format_alpha_first(P.format), blue_low = format_blue_low(P.format);
@@ -457,6 +473,10 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                     } else {                                        /* CRT_DO_BANDLIMITING 0, crt_snes.c:113-122 */
                         hy = fy; hi = fi; hq = fq;
                     }
+                    /* what iirf returns: the state -- or, in a HIPASS 1 build (crt_ntsc.c:121-122; exact kernels only),
+                     * input minus state */
+                    int oy = hy, oi = hi, oq = hq;
+                    if (!FAST && S::BANDLIMIT && hipass) { oy = (I64 ? pair_hi(fyp) : fy) - hy; oi = fi - hi; oq = fq - hq; }
                     int ccI, ccQ;
                     if constexpr (S::CCS == 4) {
                         ccI = k == 0 ? cI[0] : k == 1 ? cI[1] : k == 2 ? cI[2] : cI[3];
@@ -471,12 +491,12 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         /* (h * cc) >> 4 twice: the carriers are pre-scaled by 2^12 (cI / cQ above), so that each
                          * shift is "take the high word" and both ride on the add;
                          * base + (v * white >> 10) == (v * white + (base << 10)) >> 10: one multiply-add */
-                        const int miq = add_hiwords(__mul24(hi, ccI), __mul24(hq, ccQ));
-                        ire = mad24_vv(hy + miq, white, ire_base_1024) >> 10;
+                        const int miq = add_hiwords(__mul24(oi, ccI), __mul24(oq, ccQ));
+                        ire = mad24_vv(oy + miq, white, ire_base_1024) >> 10;
                     } else {
-                        const int mi = (hi * ccI) >> 4;
-                        const int mq = (hq * ccQ) >> 4;
-                        ire = ire_base + (((hy + mi + mq) * white) >> 10);
+                        const int mi = (oi * ccI) >> 4;
+                        const int mq = (oq * ccQ) >> 4;
+                        ire = ire_base + (((oy + mi + mq) * white) >> 10);
                     }
                     ire = clampi(ire, 0, 110);
                     if (NOISE) {
@@ -608,7 +628,7 @@ k_active_row(const crthip_params P, int n_fields, const unsigned char *__restric
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         hstate += ((v[k] - hstate) * b_coef) >> 11;                /* iirf, crt_ntsc.c:117-126 */
-                        v[k] = hstate;
+                        v[k] = (P.flags & CRTHIP_F_HIPASS) ? v[k] - hstate : hstate;   /* HIPASS 1: crt_ntsc.c:121-122 */
                     }
 #pragma unroll
                     for (int k = 0; k < 16; k++) fp[h0 + k] = v[k];
@@ -892,6 +912,7 @@ static bool encoder_fast_ok(const crthip_params *p)
     const int wh = p->white < 0 ? -p->white : p->white;
     const int nz = p->noise < 0 ? -p->noise : p->noise;
     bool ok = wh < (1 << 23) && nz < (1 << 15);                   /* noise * 256 is a 24-bit multiplier in k_active */
+    if (p->flags & CRTHIP_F_HIPASS) ok = false;                   /* the debug build's high-pass lives in the exact kernels */
     for (int r = 0; r < CRTHIP_CARRIER_ROWS; r++)                  /* ... and so are the carriers * 4096 */
         for (int k = 0; k < CRTHIP_MAX_CCS; k++)
             ok = ok && p->modI[r][k] > -2048 && p->modI[r][k] < 2048 && p->modQ[r][k] > -2048 && p->modQ[r][k] < 2048;
@@ -1015,12 +1036,16 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
         using S = decltype(tag);
         /* every input of skeleton(): the burst table and, where the burst sits on the active lines only (NES timing,
          * crt_nes.c:173-178), the first active line; field / frame / dot crawl select the variant */
-        if (fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0 || c->skel_yo != p->yo)) {
+        const int border_key[4] = { p->flags & CRTHIP_F_NES_BORDER, p->nes_border_color, p->black_point, p->white_point };
+        const bool border_same = !(p->flags & CRTHIP_F_NES_BORDER) ? c->skel_border[0] == 0
+                                                                    : memcmp(c->skel_border, border_key, sizeof(border_key)) == 0;
+        if (fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0 || c->skel_yo != p->yo || !border_same)) {
             constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
             ProfScope ps(c, CRTHIP_K_TEMPLATE);
             hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
             memcpy(c->skel_burst, p->burst, sizeof(p->burst));
             c->skel_yo = p->yo;
+            memcpy(c->skel_border, border_key, sizeof(border_key));
             c->skel_valid = true;
         }
         if constexpr (S::IS_NES) {

@@ -188,6 +188,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     c->overlap_chunks = 0;      /* automatic */
     { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
     { const char *e = getenv("CRTHIP_SYNC_KERNEL"); c->sync_kernel = e ? atoi(e) : 0; }
+    { const char *e = getenv("CRTHIP_SYNC_SPLIT"); c->sync_split = e ? atoi(e) != 0 : false; }
     { const char *e = getenv("CRTHIP_ROW_TILE"); c->row_tile = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
@@ -368,6 +369,10 @@ int crthip_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char
     if (p->out_bpp == 0) return CRTHIP_OK;                       /* crt_core.c:312-315 */
     if (!d_analog || !d_inp || !d_state) return CRTHIP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (p->flags & CRTHIP_F_NO_VSYNC) {                         /* CRT_DO_VSYNC 0: crt_core.c:323-341, before the noise */
+        rc = crt_run_clean_vsync(c, n, d_analog, d_state);
+        if (rc) return rc;
+    }
     rc = crt_run_noise(c, p, n, d_analog, d_inp, d_state, true);
     HIPCHK(c, hipGetLastError());
     return rc;
@@ -399,8 +404,21 @@ int crthip_decode(crthip_ctx *c, const crthip_params *p, int n, const signed cha
     return rc;
 }
 
-/* one chunk of a batch, fields [first, first+n), on the context's current stream.  `part`: 1 = everything up to the
- * line table (encoder, channel noise, sync chain), 2 = the decoder, 3 = both */
+/* The blob the sync chain of a FUSED launch sees: inp[] was produced here, from a clean analog[] and the encoder, so its
+ * sample range is known and the decoder's no-low-cascade envelope can be as wide as that range allows
+ * (crthip_params.loskip_wave_max; crt_setup_signal_range).  The stage-level crthip_sync keeps the any-signal bound. */
+static crthip_params with_signal_envelope(const crthip_params *p)
+{
+    crthip_params q = *p;
+    int lo, hi;
+    crt_setup_signal_range(p, &lo, &hi);
+    q.loskip_wave_max = crt_setup_loskip_bound(lo, hi);
+    return q;
+}
+
+/* one chunk of a batch, fields [first, first+n), on the context's current stream.  `part` (bits): 1 = encoder + channel
+ * noise, 4 = the sync chain up to the line table, 2 = the decoder (the rand()-noise VHS build and CRT_DO_VSYNC 0 run 1 and 4
+ * as one unit under bit 1) */
 static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n, int part,
                            const void *d_images, size_t istride, void *d_out, size_t ostride, crthip_state *d_state)
 {
@@ -412,7 +430,9 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
     int rc = CRTHIP_OK;
     if (part & 1) {
-        if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+        const bool vhs_rand = c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
+        if (vhs_rand || (p->flags & CRTHIP_F_NO_VSYNC)) {
+            /* (CRT_DO_VSYNC 0 needs the clean field as well: its vertical sync search reads analog[], crt_core.c:323-341) */
             /* VHS noise follows the C library's rand() stream, not the LCG: the fused encoder (margins + active
              * rectangle = every sample of the field) runs with noise 0 into analog[], then the dedicated noise
              * kernels (which also produce rn) */
@@ -426,11 +446,12 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
             if (rc) return rc;
             if (p->out_bpp == 0) return CRTHIP_OK;
             unsigned *saved = c->d_vhs_hist;
-            c->d_vhs_hist = saved + (size_t) first * 32;
+            if (vhs_rand) c->d_vhs_hist = saved + (size_t) first * 32;
             rc = crthip_noise(c, p, n, analog, inp, st);
             c->d_vhs_hist = saved;
             if (rc) return rc;
             rc = crt_run_sync(c, p, n, inp, st, ln, 0);
+            part &= ~4;
         } else {
             if (enc == 0) {
                 /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
@@ -441,9 +462,12 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
                 hipMemsetAsync(analog, 0, c->fstride * (size_t) n, c->stream);
                 rc = crt_run_noise(c, p, n, analog, inp, st, false);
             }
-            if (rc) return rc;
-            if (p->out_bpp != 0) rc = crt_run_sync(c, p, n, inp, st, ln, 1);
         }
+        if (rc) return rc;
+    }
+    if ((part & 4) && p->out_bpp != 0) {
+        const crthip_params q = enc == 0 ? with_signal_envelope(p) : *p;
+        rc = crt_run_sync(c, &q, n, inp, st, ln, 1);
         if (rc) return rc;
     }
     if ((part & 2) && p->out_bpp != 0) rc = crt_run_decode(c, p, n, inp, ln, out, ostride);
@@ -456,7 +480,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     int rc = check_params(c, p, n);
     if (rc) return rc;
     if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !c->d_vhs_hist)
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE) && !c->d_vhs_hist)
         return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
     int enc = check_encoder(c, p);
     if (enc < 0) return enc;
@@ -482,8 +506,28 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     int want_chunks = c->overlap_chunks;
     if (want_chunks == 0) want_chunks = 1;       /* measured: no configuration gains (profiles/r02_overlap_sweep.txt) */
     const int nchunks = (want_chunks > 1 && n >= 256 * want_chunks && !c->prof) ? want_chunks : 1;
-    if (nchunks == 1) {
-        rc = fieldpass_chunk(c, p, enc, 0, n, 3, d_images, istride, d_out, ostride, d_state);
+    const bool rand_or_novsync = (c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE)) || (p->flags & CRTHIP_F_NO_VSYNC);
+    if (nchunks == 1 && c->sync_split && n >= 1024 && !c->prof && !rand_or_novsync && p->out_bpp != 0 && crt_ensure_aux(c) == CRTHIP_OK) {
+        /* The sync chain is pure latency (one wave per field, ~0.09 ms however small the batch) between two kernels that
+         * fill the chip.  Everything is encoded at full width; then the chain of the second half of the batch runs on the
+         * internal stream UNDER the decoder of the first half. */
+        hipStream_t main_stream = c->stream;
+        const int h = (n / 2 + 3) & ~3;
+        rc = fieldpass_chunk(c, p, enc, 0, n, 1, d_images, istride, d_out, ostride, d_state);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        c->stream = c->aux_stream;
+        rc = fieldpass_chunk(c, p, enc, h, n - h, 4, d_images, istride, d_out, ostride, d_state);
+        c->stream = main_stream;
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+        rc = fieldpass_chunk(c, p, enc, 0, h, 4 | 2, d_images, istride, d_out, ostride, d_state);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+        rc = fieldpass_chunk(c, p, enc, h, n - h, 2, d_images, istride, d_out, ostride, d_state);
+    } else if (nchunks == 1) {
+        rc = fieldpass_chunk(c, p, enc, 0, n, 7, d_images, istride, d_out, ostride, d_state);
     } else {
         /* Two-stage software pipeline over the chunks: the encoder + sync chain of ALL chunks run back to back on an
          * internal stream, the decoders on the caller's stream, decoder k waiting for the event behind sync chain k.
@@ -499,7 +543,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         int used = 0;
         for (int k = 0, first = 0; first < n && rc == CRTHIP_OK; k++, first += per) {
             const int cnt = n - first < per ? n - first : per;
-            rc = fieldpass_chunk(c, p, enc, first, cnt, 1, d_images, istride, d_out, ostride, d_state);
+            rc = fieldpass_chunk(c, p, enc, first, cnt, 1 | 4, d_images, istride, d_out, ostride, d_state);
             if (rc == CRTHIP_OK && hipEventRecord(c->ev_chunk[k], c->aux_stream) != hipSuccess) rc = CRTHIP_E_HIP;
             used = k + 1;
         }
@@ -546,8 +590,10 @@ static int seq_check(crthip_ctx *c, const crthip_params *p, int n)
 {
     int rc = check_params(c, p, n);
     if (rc) return rc;
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !c->d_vhs_hist)
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE) && !c->d_vhs_hist)
         return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
+    if (p->flags & CRTHIP_F_NO_VSYNC)
+        return set_err(c, CRTHIP_E_ARG, "sequence mode is not available for the CRT_DO_VSYNC 0 variant (its sync search reads the clean field)", hipSuccess);
     if (p->blend && (unsigned) p->outh + p->v_fac < (unsigned) c->sd.lines)
         return set_err(c, CRTHIP_E_ARG, "sequence mode with blend needs outh + v_fac >= CRT_LINES (one line per output row)", hipSuccess);
     if (p->out_bpp == 0) return set_err(c, CRTHIP_E_ARG, "sequence mode: unknown output pixel format", hipSuccess);
@@ -563,7 +609,7 @@ int crthip_seq_encode(crthip_ctx *c, const crthip_params *p, int n, int first_in
     int rc = seq_check(c, p, n);
     if (rc) return rc;
     if (!d_images || !d_state || first_index < 0) return CRTHIP_E_ARG;
-    const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS;
+    const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
     if (vhs && first_index != 0)
         return set_err(c, CRTHIP_E_ARG, "VHS: a video shares ONE rand() stream; its fields cannot start in the middle (first_index != 0)", hipSuccess);
     HIPCHK(c, hipSetDevice(c->device));
@@ -625,13 +671,14 @@ int crthip_seq_sync(crthip_ctx *c, const crthip_params *p, int n, crthip_state *
         c->seq_guess_n = n;
     }
     int passes = 0;
+    const crthip_params q = with_signal_envelope(p);                  /* inp[] comes from crthip_seq_encode */
     for (;;) {
         passes++;
         HIPCHK(c, hipMemsetAsync(sc.changed, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_seq_load, gn, b64, 0, c->stream, n, d_state, sc.guess, make_int2(hsync_in, vsync_in));
         rc = crt_run_encoder_state(c, p, n, d_state);                 /* ccf preset, crt_ntsc.c:325-329 */
         if (rc) return rc;
-        rc = crt_run_sync(c, p, n, c->d_inp, d_state, c->d_lines, 0);
+        rc = crt_run_sync(c, &q, n, c->d_inp, d_state, c->d_lines, 0);
         if (rc) return rc;
         hipLaunchKernelGGL(k_seq_compare, gn, b64, 0, c->stream, n, d_state, sc.guess, sc.changed);
         int flag = 0;
@@ -657,7 +704,7 @@ int crthip_seq_decode(crthip_ctx *c, const crthip_params *p, int n, void *d_out,
     if (rc) return rc;
     if (!d_out || !d_state || n > c->cap_fields) return CRTHIP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->system != CRTHIP_SYSTEM_NTSCVHS) crt_run_advance_rn(c, n, d_state);
+    if (c->system != CRTHIP_SYSTEM_NTSCVHS || (p->flags & CRTHIP_F_VHS_LCG_NOISE)) crt_run_advance_rn(c, n, d_state);
     crthip_params pb = *p;
     pb.blend = 0;
     rc = crt_run_decode(c, &pb, n, c->d_inp, c->d_lines, d_out, ostride);

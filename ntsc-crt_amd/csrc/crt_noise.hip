@@ -506,7 +506,7 @@ int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state)
 int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
                   crthip_state *d_state, bool advance_rn)
 {
-    if (c->system == CRTHIP_SYSTEM_NTSCVHS) {
+    if (c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE)) {
         if (!c->d_vhs_hist) return set_err(c, CRTHIP_E_ARG, "VHS: no generator histories bound (crthip_vhs_bind_history)", hipSuccess);
         return dispatch_system(c->system, c->pattern, [&](auto tag) {
             using S = decltype(tag);

@@ -386,6 +386,15 @@ crthip_params_finalize(crthip_params *p)
     if (p->bloom && (d.nes_timing || p->eq_kernel != 0)) {
         return CRTHIP_E_ARG;                                    /* "does not work for NES" (crt_core.h:70) */
     }
+    if ((p->flags & (CRTHIP_F_VHS_LP | CRTHIP_F_VHS_EP | CRTHIP_F_VHS_LCG_NOISE)) && p->system != CRTHIP_SYSTEM_NTSCVHS) {
+        return CRTHIP_E_ARG;
+    }
+    if ((p->flags & CRTHIP_F_VHS_LP) && (p->flags & CRTHIP_F_VHS_EP)) {
+        return CRTHIP_E_ARG;
+    }
+    if ((p->flags & CRTHIP_F_NES_BORDER) && p->system != CRTHIP_SYSTEM_NES) {
+        return CRTHIP_E_ARG;
+    }
 
     memset(p->burst, 0, sizeof(p->burst));
     memset(p->modI, 0, sizeof(p->modI));
@@ -468,9 +477,15 @@ crthip_params_finalize(crthip_params *p)
             }
         }
         if (d.y_freq != 0) {
-            p->iir_c[0] = lowpass_coef(d.y_freq);
-            p->iir_c[1] = lowpass_coef(d.i_freq);
-            p->iir_c[2] = lowpass_coef(d.q_freq);
+            int yf = d.y_freq, jf = d.i_freq, qf = d.q_freq;
+            if (p->system == CRTHIP_SYSTEM_NTSCVHS && (p->flags & CRTHIP_F_VHS_LP)) {        /* crt_ntscvhs.h:114-118 */
+                yf = 240000; jf = 40000; qf = 40000;
+            } else if (p->system == CRTHIP_SYSTEM_NTSCVHS && (p->flags & CRTHIP_F_VHS_EP)) { /* crt_ntscvhs.h:119-123 */
+                yf = 200000; jf = 37000; qf = 37000;
+            }
+            p->iir_c[0] = lowpass_coef(yf);
+            p->iir_c[1] = lowpass_coef(jf);
+            p->iir_c[2] = lowpass_coef(qf);
         }
     }
 
@@ -533,8 +548,118 @@ crthip_params_finalize(crthip_params *p)
          * (undefined there), the row decoder would leave its LDS window -- refused */
         return CRTHIP_E_ARG;
     }
+    p->loskip_wave_max = 65532;                                 /* |s| <= 127, see crt_hip.h */
     p->finalized = CRTHIP_PARAMS_MAGIC;
     return CRTHIP_OK;
+}
+
+/* NES composite level of PPU pixel p at phase `phase`, crt_nes.c:21-61 (host copy: only used to bound the signal) */
+static int
+nes_level(int p, int phase)
+{
+    static const int active[6] = { 0300, 0100, 0500, 0400, 0600, 0200 };
+    static const int ire[16] = {
+        -12042, 0, 34406, 81427,        /* low, no emphasis  */
+        -17203, -8028, 19497, 57342,    /* low, emphasis     */
+        43581, 75693, 112965, 112965,   /* high, no emphasis */
+        26951, 52181, 83721, 83721      /* high, emphasis    */
+    };
+    int hue = p & 15, high, emph;
+
+    if (hue >= 14) {
+        return 0;
+    }
+    high = ((hue + phase) % 12) < 6;
+    if (hue == 0) {
+        high = 1;
+    }
+    if (hue == 13) {
+        high = 0;
+    }
+    emph = (p & 0700 & active[(phase >> 1) % 6]) != 0;
+    return ire[(high << 3) + (emph << 2) + ((p >> 4) & 3)];
+}
+
+/*
+ * Range [*lo, *hi] of every sample of a field as crt_modulate leaves it in a crt_init-clean analog[] and the noise stage
+ * of crt_demodulate hands it on (crt_core.c:359-366).  The struct bytes mirrored behind inp[] (CRTHIP_TAIL) are NOT
+ * covered: a line whose window reaches them keeps the any-signal bound (line_tier_flags, crt_dev.h).  Used by
+ * the fused entry points to widen the decoder's no-low-cascade envelope (crthip_params.loskip_wave_max); VHS, whose
+ * noise gain is data dependent (crt_core.c:349-357), reports the full range.
+ */
+void
+crt_setup_signal_range(const crthip_params *p, int *lo, int *hi)
+{
+    struct crt_sysdef d;
+    int a_lo = 0, a_hi = 0, r, k, v, t0, t1;
+
+    *lo = -128;
+    *hi = 127;
+    if (crt_sysdef_get(&d, p->system, p->chroma_pattern) != CRTHIP_OK ||
+        (p->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE))) {
+        return;
+    }
+    /* skeleton: blank, sync tip, burst (crt_ntsc.c:205-252, crt_nes.c:81-104) */
+    if (d.sync_level < a_lo) a_lo = d.sync_level;
+    if (d.blank_level > a_hi) a_hi = d.blank_level;
+    for (r = 0; r < CRTHIP_CARRIER_ROWS; r++) {
+        for (k = 0; k < CRTHIP_MAX_CCS; k++) {
+            v = (int) (signed char) ((d.blank_level + p->burst[r][k] * d.burst_level) >> 5);
+            if (v < a_lo) a_lo = v;
+            if (v > a_hi) a_hi = v;
+        }
+    }
+    /* active video */
+    if (d.ppu_input) {
+        int px, ph;
+        for (px = 0; px < 512; px++) {                      /* crt_nes.c:162-193, every pixel value at every phase */
+            for (ph = 0; ph < 12; ph++) {
+                int ire = d.black_level + p->black_point + nes_level(px, ph) + nes_level(px, ph + 1) +
+                          nes_level(px, ph + 2) + nes_level(px, ph + 3);
+                v = (int) (signed char) ((ire * p->white_point / 100) >> 12);
+                if (v < a_lo) a_lo = v;
+                if (v > a_hi) a_hi = v;
+            }
+        }
+    } else {
+        if (110 > a_hi) a_hi = 110;                         /* clamped to 0..110, crt_ntsc.c:319-320 */
+    }
+    /* noise term ((byte - 0x7f) * noise) >> 8, byte = 0..255 */
+    t0 = (-127 * p->noise) >> 8;
+    t1 = (128 * p->noise) >> 8;
+    if (p->noise > (1 << 20) || p->noise < -(1 << 20)) {
+        return;
+    }
+    a_lo += t0 < t1 ? t0 : t1;
+    a_hi += t0 < t1 ? t1 : t0;
+    if (a_lo < -127) a_lo = -127;                           /* crt_core.c:363-364 */
+    if (a_hi > 127) a_hi = 127;
+    *lo = a_lo;
+    *hi = a_hi;
+}
+
+/* largest |wave| for which the chroma equaliser input u = (s * wave) >> 9, s in [lo, hi], keeps every state of the
+ * cascades inside the hull H of the inputs and 0 with max|H| <= 32767 and width(H) <= 32767 (see eq_step64 in
+ * crt_decode.hip): |u| <= |s| * W / 512 + 1 */
+int
+crt_setup_loskip_bound(int lo, int hi)
+{
+    int m, wd;
+    long a, b;
+
+    if (lo > 0) lo = 0;
+    if (hi < 0) hi = 0;
+    m = -lo > hi ? -lo : hi;
+    wd = hi - lo;
+    if (m <= 0 || wd <= 0) {
+        return 65532;
+    }
+    a = (32766L * 512L) / m;
+    b = (32765L * 512L) / wd;
+    if (b < a) a = b;
+    if (a < 65532L) a = 65532L;
+    if (a > 120000L) a = 120000L;                           /* T0_WAVE_MAX: the 64-bit-mad tiers end there anyway */
+    return (int) a;
 }
 
 /* ------------------------------------------------------------------------- */

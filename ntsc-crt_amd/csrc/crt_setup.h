@@ -47,6 +47,10 @@ void crt_setup_sincos14(int *s, int *c, int n);   /* crt_core.c:42-61 */
 int  crt_setup_expx(int n);                       /* crt_ntsc.c:41-83 */
 int  crt_setup_bpp4fmt(int format);               /* crt_core.c:63-78 */
 
+/* decoder envelope helpers (see crt_setup.c) */
+void crt_setup_signal_range(const crthip_params *p, int *lo, int *hi);
+int  crt_setup_loskip_bound(int lo, int hi);
+
 /* VHS rand() model (see crt_setup.c) */
 void crt_setup_vhs_power(unsigned long k, unsigned c[31]);
 void crt_setup_vhs_power_table(unsigned long first, unsigned long step, int count, unsigned *rows);

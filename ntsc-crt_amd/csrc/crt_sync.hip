@@ -109,7 +109,7 @@ __device__ __forceinline__ void vsync_search(const signed char *__restrict__ in,
 template <class S>
 __global__ void __launch_bounds__(64)
 k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
-        uint2 whole_field, int advance_rn)
+        uint2 whole_field, int advance_rn, int clean_signal)
 {
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
@@ -118,7 +118,7 @@ k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthi
     int vline, vj;
     vsync_search<S>(inp + (size_t) f * fstride, st->vsync, lane, vline, vj);
     if (lane == 0) {
-        st->vsync = vline;
+        st->vsync = clean_signal ? -3 : vline;      /* CRT_DO_VSYNC 0 (crt_core.c:323-341): searched in analog[], then pinned */
         st->odd_field = vj > S::HRES / 2;
         if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
     }
@@ -231,7 +231,7 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
         } else {
             hsync_new = posmod(hsync_new, S::HRES);                      /* caller-supplied out-of-range hsync */
         }
-        if (!skip) hsync = hsync_new;
+        if (!skip) hsync = (P.flags & CRTHIP_F_NO_HSYNC) ? 0 : hsync_new;              /* CRT_DO_HSYNC 0: crt_core.c:448-450 */
 
         int xpos, ypos;                                                  /* :452-454 */
         if (hsync >= 0 && hsync < S::HRES) {
@@ -323,14 +323,7 @@ k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp
                 /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
                 if (nrows > CRTHIP_LINE_NROWS_MASK) nrows = CRTHIP_LINE_NROWS_MASK;
                 nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
-                if (CCS != 4)
-                    nrows |= CRTHIP_LINE_WIDE;                             /* no amplitude envelope for the 5-sample carriers */
-                else if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
-                    nrows |= CRTHIP_LINE_EXACT;
-                else if (lp.wave0 > T0_WAVE_MAX || lp.wave0 < -T0_WAVE_MAX || lp.wave1 > T0_WAVE_MAX || lp.wave1 < -T0_WAVE_MAX)
-                    nrows |= CRTHIP_LINE_NOT64;
-                else if (lp.wave0 > LOSKIP_WAVE_MAX || lp.wave0 < -LOSKIP_WAVE_MAX || lp.wave1 > LOSKIP_WAVE_MAX || lp.wave1 < -LOSKIP_WAVE_MAX)
-                    nrows |= CRTHIP_LINE_WIDE;
+                nrows |= line_tier_flags<CCS>(lp.wave0, lp.wave1, P.saturation, P.loskip_wave_max, lp.pos + S::AV_LEN + 8 > S::INPUT_SIZE);
                 lp.nrows = nrows;
                 lp.hsync = hsync;
             }
@@ -429,10 +422,16 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     int hsync = __builtin_amdgcn_readfirstlane(st->hsync);
     /* D2: the vertical sync search of this field, by the field's own wave (one launch and one trip through memory less
      * than a kernel of its own; what a single field-pass costs is mostly this chain's latency) */
-    int vsync, vj_;
-    vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
-    vsync = __builtin_amdgcn_readfirstlane(vsync);
-    const int odd_field = __builtin_amdgcn_readfirstlane(vj_) > S::HRES / 2;
+    int vsync, vj_, odd_field;
+    if (P.flags & CRTHIP_F_NO_VSYNC) {
+        /* CRT_DO_VSYNC 0: k_vsync looked at the clean signal before the noise stage (crt_core.c:323-341) */
+        vsync = __builtin_amdgcn_readfirstlane(st->vsync);
+        odd_field = __builtin_amdgcn_readfirstlane(st->odd_field);
+    } else {
+        vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
+        vsync = __builtin_amdgcn_readfirstlane(vsync);
+        odd_field = __builtin_amdgcn_readfirstlane(vj_) > S::HRES / 2;
+    }
     if (live && lane == 0) {
         st->vsync = vsync;
         st->odd_field = odd_field;
@@ -552,6 +551,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                     } else {
                         h = posmod(h, S::HRES);
                     }
+                    if (P.flags & CRTHIP_F_NO_HSYNC) h = 0;                              /* CRT_DO_HSYNC 0: crt_core.c:448-450 */
                     h_out = h;
                 }
                 new_hs = h_out;
@@ -660,14 +660,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                             rank++;
                     }
                     nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
-                    if (CCS != 4)
-                        nrows |= CRTHIP_LINE_WIDE;
-                    else if (lp.wave0 > FAST_WAVE_MAX || lp.wave0 < -FAST_WAVE_MAX || lp.wave1 > FAST_WAVE_MAX || lp.wave1 < -FAST_WAVE_MAX)
-                        nrows |= CRTHIP_LINE_EXACT;
-                    else if (lp.wave0 > T0_WAVE_MAX || lp.wave0 < -T0_WAVE_MAX || lp.wave1 > T0_WAVE_MAX || lp.wave1 < -T0_WAVE_MAX)
-                        nrows |= CRTHIP_LINE_NOT64;
-                    else if (lp.wave0 > LOSKIP_WAVE_MAX || lp.wave0 < -LOSKIP_WAVE_MAX || lp.wave1 > LOSKIP_WAVE_MAX || lp.wave1 < -LOSKIP_WAVE_MAX)
-                        nrows |= CRTHIP_LINE_WIDE;
+                    nrows |= line_tier_flags<CCS>(lp.wave0, lp.wave1, P.saturation, P.loskip_wave_max, lp.pos + S::AV_LEN + 8 > S::INPUT_SIZE);
                     lp.nrows = nrows;
                 }
                 v4i a, b;
@@ -753,6 +746,18 @@ k_bloom(const crthip_params P, int n_fields, const signed char *__restrict__ inp
 }
 
 
+/* CRT_DO_VSYNC 0 (crt_core.c:323-341): the field parity is looked for in the CLEAN signal, before the noise stage, and
+ * vsync is pinned to -3; the sync kernels then skip their own search (CRTHIP_F_NO_VSYNC) */
+int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthip_state *d_state)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        ProfScope ps(c, CRTHIP_K_SYNC);
+        hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_analog, c->fstride, d_state, c->whole_field, 0, 1);
+        return CRTHIP_OK;
+    });
+}
+
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
                  crthip_line *d_lines, int advance_rn)
 {
@@ -761,7 +766,8 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         ProfScope ps(c, CRTHIP_K_SYNC);
         const bool legacy = c->legacy_sync || c->sync_kernel == 1;
         if (legacy)
-            hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn);
+            if (!(p->flags & CRTHIP_F_NO_VSYNC))
+                hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn, 0);
         /* k_hsync (16 lanes per field) is kept for A/B measurements (CRTHIP_SYNC_KERNEL=1): the wave-per-field kernel
          * is faster at every batch size measured (profiles/r02_shape_sweep.txt, rows L against A).
          * CRTHIP_SYNC_KERNEL=2 / 3 force 1 / 4 fields per workgroup */

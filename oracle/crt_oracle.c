@@ -249,6 +249,16 @@ orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern)
     sys->do_bloom = 0;
 }
 
+/* crt_ntscvhs.h:102-124: Y / I / Q band limits of the three tape speeds */
+void
+orc_sys_set_vhs_mode(struct orc_sys *sys, int mode)
+{
+    static const int freq[3][3] = { { 300000, 62700, 62700 }, { 240000, 40000, 40000 }, { 200000, 37000, 37000 } };
+    int k;
+    if (sys->system != ORC_SYS_VHS || mode < 0 || mode > 2) return;
+    for (k = 0; k < 3; k++) sys->iir_c[k] = iir_coef(1431818, freq[mode][k]);
+}
+
 /* crt_core.c:241-289 crt_init = memset + crt_resize + crt_reset + rn seed */
 void
 orc_crt_init(const struct orc_sys *sys, struct orc_crt *v,
@@ -422,13 +432,18 @@ modulate_rgb(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *
             } else {                                 /* crt_snes.c:113-122 with CRT_DO_BANDLIMITING 0 */
                 hy = fy; hi = fi; hq = fq;
             }
-            fy = hy;
-            if (sys->enc_line_rows) {
-                fi = hi * modI[row][xoff] >> 4;
-                fq = hq * modQ[row][xoff] >> 4;
-            } else {
-                fi = hi * ph * modI[0][xoff] >> 4;
-                fq = hq * ph * modQ[0][xoff] >> 4;
+            {
+                /* iirf's return value: the state, or with HIPASS 1 (crt_ntsc.c:121-122) input minus state */
+                const int hp = sys->hipass && sys->enc_bandlimit;
+                const int oy = hp ? fy - hy : hy, oi = hp ? fi - hi : hi, oq = hp ? fq - hq : hq;
+                fy = oy;
+                if (sys->enc_line_rows) {
+                    fi = oi * modI[row][xoff] >> 4;
+                    fq = oq * modQ[row][xoff] >> 4;
+                } else {
+                    fi = oi * ph * modI[0][xoff] >> 4;
+                    fq = oq * ph * modQ[0][xoff] >> 4;
+                }
             }
             ire += (fy + fi + fq) * white >> 10;
             if (ire < 0) ire = 0;
@@ -567,6 +582,24 @@ modulate_nes(const struct orc_sys *sys, struct orc_crt *v, struct orc_settings *
     xo = (sys->av_beg + s->xoffset) & ~3;            /* :132-136 */
     yo = sys->top + s->yoffset;
 
+    if (sys->nes_border) {                           /* NES_BORDER 1, :138-160: written on every call, before the picture */
+        for (n = sys->top; n <= sys->bot + 2; n++) {
+            int8_t *line = v->analog + n * hres;
+            int phase = phasetab[(n + s->dot_crawl_offset) % 3] + 6;
+            int t;
+            for (t = sys->lav_beg; t < hres; t++) {
+                int p = t == sys->lav_beg ? 0xf0 : (int) s->border_color;
+                int ire = sys->black_level + v->black_point;
+                ire += ppu_level(p, phase + 0);
+                ire += ppu_level(p, phase + 1);
+                ire += ppu_level(p, phase + 2);
+                ire += ppu_level(p, phase + 3);
+                ire = (ire * v->white_point / 100) >> 12;
+                line[t] = (int8_t) ire;
+                phase += 3;
+            }
+        }
+    }
     for (y = 0; y < sys->lines; y++) {               /* :162-194 */
         int sy = (y * s->h) / sys->lines;
         int phase;
@@ -634,11 +667,12 @@ int
 orc_stage_noise(const struct orc_sys *sys, const int8_t *analog, int8_t *inp, int rn, int noise)
 {
     int i, vhs_line = 0;
+    const int vhs = sys->system == ORC_SYS_VHS && !sys->vhs_lcg_noise;      /* :343 (CRT_SYSTEM == NTSCVHS) && CRT_VHS_NOISE */
 
-    if (sys->system == ORC_SYS_VHS) vhs_line = ((rand() % 8) - 4) + 14;     /* :344 */
+    if (vhs) vhs_line = ((rand() % 8) - 4) + 14;                            /* :344 */
     for (i = 0; i < sys->input_size; i++) {
         int nn = noise, s;
-        if (sys->system == ORC_SYS_VHS) {                                   /* :349-357 */
+        if (vhs) {                                                          /* :349-357 */
             rn = rand();
             if (i > (sys->input_size - sys->hres * (16 + ((rand() % 20) - 10))) &&
                 i < (sys->input_size - sys->hres * (5 + ((rand() % 8) - 4)))) {
@@ -759,7 +793,7 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
      * line's first sample are stale in the reference but never read: the resampler starts at scanL) */
     static int yq[3][2048];
     const int hres = sys->hres, av_len = sys->av_len, ccs = sys->cc_samples;
-    int bpp, pitch, huesn, huecs, bright, odd_field, ratio, field_rows, line;
+    int bpp, pitch, huesn, huecs, bright, odd_field = 0, ratio, field_rows, line;
     int max_e = 0, prev_e = 0;
 
     bpp = orc_bpp4fmt(v->out_format);
@@ -776,8 +810,12 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
     memcpy(v->inp + sys->input_size + 8, &v->out_format, 4);
     memset(v->inp + sys->input_size + 12, 0, ORC_TAIL - 12);
 
+    if (sys->no_vsync) {                                                     /* :323-341: the field parity from the clean signal */
+        stage_vsync(sys, v->analog, &v->vsync, &odd_field);
+        v->vsync = -3;
+    }
     v->rn = orc_stage_noise(sys, v->analog, v->inp, v->rn, noise);           /* D1 */
-    stage_vsync(sys, v->inp, &v->vsync, &odd_field);                         /* D2 */
+    if (!sys->no_vsync) stage_vsync(sys, v->inp, &v->vsync, &odd_field);     /* D2 */
 
     if (sys->do_bloom) {                                                     /* :399-402 */
         max_e = (128 + (noise / 2)) * av_len;
@@ -815,7 +853,7 @@ orc_demodulate_trace(const struct orc_sys *sys, struct orc_crt *v, int noise, st
             acc += sig[sys->sync_beg + i];
             if (acc <= sys->hsync_thresh) break;
         }
-        v->hsync = POSMOD(i + v->hsync, hres);
+        v->hsync = sys->no_hsync ? 0 : POSMOD(i + v->hsync, hres);           /* :446-450 */
 
         xpos = POSMOD(sys->av_beg + v->hsync - 3, hres);                     /* D6, :452-467 */
         ypos = POSMOD(line + v->vsync + 3, sys->vres);

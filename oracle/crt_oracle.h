@@ -66,6 +66,12 @@ struct orc_sys {
     int equ_a_lo, equ_a_hi, equ_b_lo, equ_b_hi;   /* equalising-pulse lines (inclusive) */
     int vs_lo, vs_hi;    /* vertical sync lines (inclusive) */
     int vs_by_field;     /* odd fields use the {4,50,96,100} % pattern (crt_ntsc.c:219-223) */
+    /* further build-time switches of the reference, all "set by the caller after orc_sys_init" (0 = the shipped build) */
+    int vhs_lcg_noise;   /* crt_ntscvhs.h:29 CRT_VHS_NOISE 0: the VHS build with the LCG noise of every other system */
+    int no_vsync;        /* crt_core.h:71 CRT_DO_VSYNC 0 (crt_core.c:323-341): field parity from the CLEAN signal, vsync = -3 */
+    int no_hsync;        /* crt_core.h:72 CRT_DO_HSYNC 0 (crt_core.c:446-450): hsync = 0 after every line */
+    int hipass;          /* crt_ntsc.c:115 HIPASS 1: iirf returns s - h */
+    int nes_border;      /* crt_nes.c:69 NES_BORDER 1 (:138-160): the border colour right of the picture, lines TOP .. BOT + 2 */
 };
 
 struct orc_crt {
@@ -103,6 +109,8 @@ struct orc_line {
 };
 
 void orc_sys_init(struct orc_sys *sys, int system, int chroma_pattern);
+/* crt_ntscvhs.h:102-124 VHS_MODE: 0 SP (shipped), 1 LP, 2 EP -- the encoder's three band limits */
+void orc_sys_set_vhs_mode(struct orc_sys *sys, int mode);
 void orc_sincos14(int *s, int *c, int n);
 int  orc_bpp4fmt(int format);
 int  orc_expx(int n);

@@ -44,7 +44,19 @@ SYSTEMS = {
     "vhsbloom": (SYS_VHS, 1, "libref_vhsbloom.so"),
     "pv1kbloom": (SYS_PV1K, 1, "libref_pv1kbloom.so"),
     "snesbloom": (SYS_SNES, 1, "libref_snesbloom.so"),
+    # VERDICT round 2, missing #3: the remaining build-time switches (oracle/Makefile: PATCHLIB)
+    "vhslp": (SYS_VHS, 1, "libref_vhslp.so"),             # VHS_MODE VHS_LP, crt_ntscvhs.h:102-124
+    "vhsep": (SYS_VHS, 1, "libref_vhsep.so"),             # VHS_MODE VHS_EP
+    "vhslcg": (SYS_VHS, 1, "libref_vhslcg.so"),           # CRT_VHS_NOISE 0, crt_ntscvhs.h:29
+    "ntscnovsync": (SYS_NTSC, 1, "libref_ntscnovsync.so"),   # CRT_DO_VSYNC 0, crt_core.h:71
+    "ntscnohsync": (SYS_NTSC, 1, "libref_ntscnohsync.so"),   # CRT_DO_HSYNC 0, crt_core.h:72
+    "ntschipass": (SYS_NTSC, 1, "libref_ntschipass.so"),     # HIPASS 1, crt_ntsc.c:115
+    "nesborder": (SYS_NES, 2, "libref_nesborder.so"),        # NES_BORDER 1, crt_nes.c:69
 }
+# oracle switches of those builds (struct orc_sys members "set by the caller after orc_sys_init")
+VARIANTS = {"vhslp": dict(vhs_mode=1), "vhsep": dict(vhs_mode=2), "vhslcg": dict(vhs_lcg_noise=1),
+            "ntscnovsync": dict(no_vsync=1), "ntscnohsync": dict(no_hsync=1), "ntschipass": dict(hipass=1),
+            "nesborder": dict(nes_border=1)}
 EQ_KERNEL = {"ntscfir7": 7, "ntscfir6": 6, "ntscfir5": 5, "ntscfir4": 4}      # everything else: 0 (IIR)
 DOT_CRAWL_SYSTEMS = (SYS_NES, SYS_NESRGB, SYS_SNES, SYS_PV1K, SYS_TEMP)       # NTSC_SETTINGS has dot_crawl_offset
 PROGRESSIVE_SYSTEMS = (SYS_NES, SYS_NESRGB)                                   # no field / frame members
@@ -80,7 +92,14 @@ DROPIN = {"ntsc": ("libntsccrt_hip_ntsc.so", ["-DCRT_SYSTEM=0"]),
           "ntscbloom": ("libntsccrt_hip_ntsc_bloom.so", ["-DCRT_SYSTEM=0", "-DCRT_DO_BLOOM=1"]),
           "vhsbloom": ("libntsccrt_hip_vhs_bloom.so", ["-DCRT_SYSTEM=5", "-DCRT_DO_BLOOM=1"]),
           "snesbloom": ("libntsccrt_hip_snes_bloom.so", ["-DCRT_SYSTEM=3", "-DCRT_DO_BLOOM=1"]),
-          "pv1kbloom": ("libntsccrt_hip_pv1k_bloom.so", ["-DCRT_SYSTEM=2", "-DCRT_DO_BLOOM=1"])}
+          "pv1kbloom": ("libntsccrt_hip_pv1k_bloom.so", ["-DCRT_SYSTEM=2", "-DCRT_DO_BLOOM=1"]),
+          "vhslp": ("libntsccrt_hip_vhs_lp.so", ["-DCRT_SYSTEM=5", "-DVHS_MODE=1"]),
+          "vhsep": ("libntsccrt_hip_vhs_ep.so", ["-DCRT_SYSTEM=5", "-DVHS_MODE=2"]),
+          "vhslcg": ("libntsccrt_hip_vhs_lcg.so", ["-DCRT_SYSTEM=5", "-DCRT_VHS_NOISE=0"]),
+          "ntscnovsync": ("libntsccrt_hip_ntsc_novsync.so", ["-DCRT_SYSTEM=0", "-DCRT_DO_VSYNC=0"]),
+          "ntscnohsync": ("libntsccrt_hip_ntsc_nohsync.so", ["-DCRT_SYSTEM=0", "-DCRT_DO_HSYNC=0"]),
+          "ntschipass": ("libntsccrt_hip_ntsc_hipass.so", ["-DCRT_SYSTEM=0", "-DCRT_HIPASS=1"]),
+          "nesborder": ("libntsccrt_hip_nes_border.so", ["-DCRT_SYSTEM=1", "-DNES_BORDER=1"])}
 
 
 def build_dropin_probe(name):
@@ -313,7 +332,8 @@ class OrcSys(C.Structure):
         ("cc_samples", C.c_int), ("cb_len", C.c_int), ("enc_bandlimit", C.c_int), ("enc_field_rows", C.c_int),
         ("enc_line_rows", C.c_int), ("vert_step", C.c_int), ("burst_off", C.c_int), ("q_off", C.c_int),
         ("equ_a_lo", C.c_int), ("equ_a_hi", C.c_int), ("equ_b_lo", C.c_int), ("equ_b_hi", C.c_int),
-        ("vs_lo", C.c_int), ("vs_hi", C.c_int), ("vs_by_field", C.c_int)]
+        ("vs_lo", C.c_int), ("vs_hi", C.c_int), ("vs_by_field", C.c_int),
+        ("vhs_lcg_noise", C.c_int), ("no_vsync", C.c_int), ("no_hsync", C.c_int), ("hipass", C.c_int), ("nes_border", C.c_int)]
 
 
 class OrcCrt(C.Structure):
@@ -358,6 +378,11 @@ class Oracle:
         L.orc_sys_init(C.byref(self.sys), self.system, self.pattern)
         self.sys.eq_kernel = EQ_KERNEL.get(name, 0)
         self.sys.do_bloom = int(is_bloom(name))
+        for k, val in VARIANTS.get(name, {}).items():
+            if k == "vhs_mode":
+                L.orc_sys_set_vhs_mode(C.byref(self.sys), val)
+            else:
+                setattr(self.sys, k, val)
         for n in ("hres", "vres", "input_size", "top", "bot", "av_beg", "av_len"):
             setattr(self, n, getattr(self.sys, n))
         self.vper = self.sys.cc_vper

@@ -20,7 +20,8 @@ def _built():
 
 
 ALL_DROPINS = ["ntsc", "vhs", "nes", "nesp0", "ntscp0", "snes", "pv1k", "temp", "nesrgb",
-               "ntscbloom", "vhsbloom", "snesbloom", "pv1kbloom"]
+               "ntscbloom", "vhsbloom", "snesbloom", "pv1kbloom",
+               "vhslp", "vhsep", "vhslcg", "ntscnovsync", "ntscnohsync", "ntschipass", "nesborder"]
 
 
 @needs_ref

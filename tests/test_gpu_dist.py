@@ -54,3 +54,125 @@ def test_node_entry_matches_the_single_context_path(n_fields):
     assert r.returncode == 0 and "node_probe ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("0 pictures, 0 states differ") == 9, r.stdout
     assert "several exchange rounds" in r.stdout, "the heavy-noise video should need more than one exchange round somewhere:\n" + r.stdout
+
+
+class _LocalComm:
+    """The subset of torch.distributed that shard.sequence_sharded uses, between THREADS of one process: lets several
+    crtlib.CRT objects on the one GPU of a gpurun box play the ranks of a multi-GPU run."""
+
+    class ReduceOp:
+        MAX = "max"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.mail = {}
+        self.cv = threading.Condition()
+
+    class _View:
+        def __init__(self, comm, rank):
+            self.c, self.rank, self.ReduceOp = comm, rank, _LocalComm.ReduceOp
+
+        def all_gather(self, out, t):
+            self.c.slots[self.rank] = t.clone()
+            self.c.barrier.wait()
+            for r in range(self.c.world):
+                out[r].copy_(self.c.slots[r])
+            self.c.barrier.wait()
+
+        def all_reduce(self, t, op=None):
+            self.c.slots[self.rank] = t.clone()
+            self.c.barrier.wait()
+            m = max(int(x.item()) for x in self.c.slots)
+            self.c.barrier.wait()
+            t.fill_(m)
+
+        def send(self, t, dst):
+            with self.c.cv:
+                self.c.mail[(self.rank, dst)] = t.clone()
+                self.c.cv.notify_all()
+
+        def recv(self, t, src):
+            with self.c.cv:
+                self.c.cv.wait_for(lambda: (src, self.rank) in self.c.mail, timeout=120)
+                t.copy_(self.c.mail.pop((src, self.rank)))
+
+    def view(self, rank):
+        return _LocalComm._View(self, rank)
+
+
+@pytest.mark.parametrize("world,total,blend,scanlines", [(2, 9, 0, 1), (3, 10, 0, 0), (2, 7, 1, 0), (4, 5, 0, 1)])
+def test_sequence_sharded_over_several_contexts_on_one_gpu(world, total, blend, scanlines):
+    """shard.sequence_sharded driving the HIP phases (crthip_seq_*): one video cut over `world` crtlib.CRT objects -- the
+    ranks of a multi-GPU run, here threads on one GPU -- must give exactly what crthip_sequence gives on one context
+    (which tests/test_gpu_parity.py holds against the oracle): pictures, hsync / vsync / rn of every field.
+    Heavy noise + an odd starting state: the sync state really travels across the seams."""
+    import threading
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "ntsc-crt_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import crtlib
+    import crtref as R
+    import shard
+    w, h, outw, outh, noise = 320, 240, 400, 300, 120
+    frames = np.stack([R.synth_image(w, h, 4, 900 + k, "random" if k % 3 else "bars") for k in range(total)])
+    init = torch.from_numpy(R.lcg_bytes(outh * outw * 4, 5).reshape(outh, outw, 4).copy()).to("cuda:0")
+
+    def settings(lo, hi):
+        full = torch.zeros((hi - lo, h + 1, w, 4), dtype=torch.uint8, device="cuda:0")
+        full[:, :h] = torch.from_numpy(frames[lo:hi]).to("cuda:0")
+        par = [shard.field_parity(k) for k in range(lo, hi)]
+        return crtlib.Settings(full[:, :h], format=crtlib.FMT_BGRA, field=[a for a, _ in par], frame=[b for _, b in par])
+
+    one = crtlib.CRT(total, outw, outh, crtlib.FMT_BGRA, "ntsc", device=0)
+    one.scanlines, one.blend = scanlines, blend
+    one.state[0, crtlib.ST_HSYNC] = 7
+    one.state[0, crtlib.ST_VSYNC] = 2
+    one.sequence(settings(0, total), noise, out_init=init)
+    one.synchronize()
+    want = one.out.cpu().numpy()
+    want_state = [one.get(f) for f in ("hsync", "vsync", "rn")]
+
+    comm = _LocalComm(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            lo, hi = shard.shard_range(total, rank, world)
+            crt = crtlib.CRT(max(hi - lo, 1), outw, outh, crtlib.FMT_BGRA, "ntsc", device=0)
+            crt.scanlines, crt.blend = scanlines, blend
+            eng = shard.CrtSequenceEngine(crt, settings(lo, max(hi, lo + 1)) if hi > lo else None, noise)
+            rounds = shard.sequence_sharded(eng, comm.view(rank), rank, world, total, 7, 2, 194,
+                                            init if rank == 0 else None, blend, torch.device("cuda:0"), (outh, outw, 4))
+            crt.synchronize()
+            results[rank] = (lo, hi, crt.out.cpu().numpy()[:hi - lo], [crt.get(f)[:hi - lo] for f in ("hsync", "vsync", "rn")], rounds)
+            crt.close()
+        except Exception as e:                                   # pragma: no cover
+            errors.append((rank, repr(e)))
+            try:
+                comm.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for lo, hi, out, st, rounds in results:
+        assert 1 <= rounds <= world + 1
+        np.testing.assert_array_equal(out, want[lo:hi], err_msg="fields %d..%d" % (lo, hi))
+        for got, full in zip(st, want_state):
+            assert got == full[lo:hi]
+    one.close()
+
+
+def test_bench_sequence_mode_over_rccl():
+    j = _bench([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--sequence", "--no-cpu", "--no-extra", "--steps", "3",
+                "--warmup", "1", "--batch", "256"])
+    assert "shard.sequence_sharded" in j["config"]["mode"] and j["collectives"]["initialized"] is True
+    assert j["value"] > 1e4

@@ -93,7 +93,7 @@ def test_ntsc_pattern0_dropin():
         R.compare_state(a, b, "ntscp0 step %d" % step)
 
 
-@pytest.mark.parametrize("name,outsz", [("nes", (640, 480)), ("nesp0", (512, 480))])
+@pytest.mark.parametrize("name,outsz", [("nes", (640, 480)), ("nesp0", (512, 480)), ("nesborder", (640, 480))])
 def test_nes_dropin(name, outsz):
     hip = R.RefLib(name, dropin=True)
     chk = _checker(name)
@@ -102,13 +102,13 @@ def test_nes_dropin(name, outsz):
         ppu = R.synth_ppu(256, 240, 7 + step)
         pad = np.concatenate([ppu, ppu[-1:]], axis=0)
         for c in (a, b):
-            c.settings(pad, w=256, h=240, dot_crawl_offset=step % 3, hue=(step * 40) % 360)
+            c.settings(pad, w=256, h=240, dot_crawl_offset=step % 3, hue=(step * 40) % 360, border_color=[0x21, 0x16, 0x2a, 0x0d][step])
             c.modulate()
             c.demodulate([0, 12, 24, 5][step])
         R.compare_state(a, b, "%s step %d" % (name, step))
 
 
-@pytest.mark.parametrize("sysname", ["vhs", "vhsbloom"])
+@pytest.mark.parametrize("sysname", ["vhs", "vhsbloom", "vhslp", "vhsep"])
 @pytest.mark.parametrize("aberration", [0, 1])
 def test_vhs_dropin_shares_the_libc_rand_stream(aberration, sysname):
     """video_convert.c semantics: the program seeds rand(), crt_modulate draws the aberration height
@@ -142,7 +142,8 @@ def test_vhs_dropin_shares_the_libc_rand_stream(aberration, sysname):
         np.testing.assert_array_equal(a.out, b.out)
 
 
-@pytest.mark.parametrize("name", ["snes", "temp", "pv1k", "ntscbloom", "snesbloom", "pv1kbloom"])
+@pytest.mark.parametrize("name", ["snes", "temp", "pv1k", "ntscbloom", "snesbloom", "pv1kbloom",
+                                  "vhslcg", "ntscnovsync", "ntscnohsync", "ntschipass"])
 def test_f4_and_bloom_dropins(name):
     """libntsccrt_hip_{snes,temp,pv1k}.so and the -DCRT_DO_BLOOM=1 libraries against the
     reference built for the same CRT_SYSTEM (/ with crt_core.h:70 patched), every visible struct member after

@@ -7,8 +7,11 @@
 Writes profiles/<name>_kernel_stats.csv, <name>_kernel_stats.args.txt, <name>_pmc.json and, with a workload name,
 profiles/traffic.json (headline) or profiles/traffic_<workload>.json (what bench.py reads for roofline.traffic: it
 only trusts a file made for the same workload).
-HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: rocprofv3's *_SIZE counters are in KB and gfx950 reports a full
-128-byte line as 64 fetched bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+HBM bytes = (f x FETCH_SIZE + WRITE_SIZE) x 1024.  rocprofv3's *_SIZE counters are in KB; on gfx950 FETCH_SIZE tallies
+every read REQUEST of the L2's memory side as 64 bytes, whether it asked for 64 or for 128 (MI355X_MICROARCH.md, HBM
+section; calibrated per access pattern in profiles/r03_pmc_calibration.json with tools/ubench_hbm.bin calib: 16 B / lane
+wave-contiguous reads count half, 64-byte row pieces and scattered 16-byte windows count in full).  So f is a property
+of the kernel's load pattern -- FETCH_FACTOR below; WRITE_SIZE counts 32-byte granules and needs no factor."""
 import collections, csv, glob, json, os, shutil, sys
 
 tag, name, fields = sys.argv[1], sys.argv[2], int(sys.argv[3])
@@ -21,6 +24,19 @@ shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, name + "_ke
 with open(os.path.join(dst, name + "_kernel_stats.args.txt"), "w") as f:
     f.write(bench_cmd + "\n(fields per launch: %d; rocprofv3 --kernel-trace --stats)\n" % fields)
 
+def fetch_factor(kernel):
+    """bytes per counted 64: what the kernel's dominant read pattern asks the memory side for"""
+    k = kernel
+    if k.startswith("void k_active"):
+        # image rows in 16-byte pieces: 4 lanes = 64 B per row (16-dword tiles) or 8 lanes = 128 B (32-dword tiles)
+        return (2.0, "128-byte image pieces") if k.rstrip(">").endswith(", 32") else (1.0, "64-byte image pieces")
+    if k.startswith("void k_decode"):
+        return 1.0, "64-byte sample pieces (4 lanes x 16 B per scanline)"
+    if k.startswith("void k_hsync") or k.startswith("void k_vsync"):
+        return 1.0, "per-lane 16-byte windows of different scanlines (the wave-wide vsync candidates, 1 KB runs, are the smaller part: lower bound)"
+    return 2.0, "wave-contiguous 16 B / lane"
+
+
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0.0, 0])
@@ -31,7 +47,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, (v, n) in agg.items():
         out.setdefault(k, {})[c + "_KB_per_launch"] = v / n
 for k, d in out.items():
-    d["hbm_bytes_per_field"] = (2 * d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 / fields
+    f, why = fetch_factor(k)
+    d["fetch_factor"], d["fetch_pattern"] = f, why
+    d["hbm_bytes_per_field"] = (f * d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 / fields
+    d["hbm_bytes_per_field_if_every_request_were_128B"] = (2 * d.get("FETCH_SIZE_KB_per_launch", 0) + d.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 / fields
 
 
 def per_field(*prefixes):
@@ -57,8 +76,8 @@ def valu_per_field(*prefixes):
     return v / fields if v else None
 json.dump({"bench": bench_cmd, "fields_per_launch": fields,
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (raw counter = KB); HBM bytes per field = "
-                     "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 / fields: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports "
-                     "half of wide coalesced reads)",
+                     "(f x FETCH_SIZE + WRITE_SIZE) x 1024 / fields with the per-kernel fetch_factor f: gfx950 tallies a read "
+                     "request as 64 B whether it asked for 64 or 128 (profiles/r03_pmc_calibration.json)",
            "hbm_bytes_per_field_all_kernels": total, "kernels": out},
           open(os.path.join(dst, name + "_pmc.json"), "w"), indent=1)
 if workload:
