@@ -468,9 +468,13 @@ def main():
                  desc="the headline workload at batch 64 (small-batch path: scanline-parallel kernel shape)"),
             dict(name="640x480_batch1", system="ntsc", w=640, h=480, outw=640, outh=480, batch=1, noise=24, scanlines=1,
                  desc="the headline workload, ONE field per launch sequence (latency)"),
+            dict(name="640x480_batch256", system="ntsc", w=640, h=480, outw=640, outh=480, batch=256, noise=24, scanlines=1,
+                 desc="the headline workload at batch 256 (between the two kernel shapes)"),
+            dict(name="pv1k_batch4096", system="pv1k", w=640, h=480, outw=640, outh=480, batch=4096, noise=24, scanlines=1,
+                 desc="CRT_SYSTEM_PV1K (5 samples per chroma cycle, 1920-sample lines) 640x480 -> 640x480 BGRA, interlaced, noise 24"),
         ]
         for e in EX:
-            small = e["batch"] <= 64
+            small = e["batch"] <= 256
             r = run_workload(torch, crtlib, shard, None, dev, 0, 1, local, e, 30 if small else max(5, args.steps // 2), 3,
                              min(args.cpu_seconds, 4.0), not args.no_cpu and not small,
                              traffic_file=os.path.join(ROOT, "profiles", "traffic_%s.json" % e["name"]))

@@ -329,8 +329,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
                 int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
                 if constexpr (S::CCS == 5) {
-                    wi = ph5 == 0 ? w5i[0] : ph5 == 1 ? w5i[1] : ph5 == 2 ? w5i[2] : ph5 == 3 ? w5i[3] : w5i[4];
-                    wq = ph5 == 0 ? w5q[0] : ph5 == 1 ? w5q[1] : ph5 == 2 ? w5q[2] : ph5 == 3 ? w5q[3] : w5q[4];
+                    wi = w5i[ph5];                           /* ph5 is wave-uniform: a relative register move */
+                    wq = w5q[ph5];
                     ph5 = ph5 == 4 ? 0 : ph5 + 1;
                 }
                 int cy, ci, cq;

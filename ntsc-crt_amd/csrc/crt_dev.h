@@ -446,7 +446,6 @@ struct crthip_ctx {
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
     int ac_tile;                /* encoder tile, same convention, by input width */
     int ac_tile_env;            /* CRTHIP_AC_TILE: overrides both (A/B measurements) */
-    bool sync_split;            /* crthip_fieldpass: the sync chain of the batch's second half under the decoder of the first */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join, ev_chunk[CRTHIP_MAX_CHUNKS];

@@ -188,7 +188,6 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     c->overlap_chunks = 0;      /* automatic */
     { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
     { const char *e = getenv("CRTHIP_SYNC_KERNEL"); c->sync_kernel = e ? atoi(e) : 0; }
-    { const char *e = getenv("CRTHIP_SYNC_SPLIT"); c->sync_split = e ? atoi(e) != 0 : false; }
     { const char *e = getenv("CRTHIP_ROW_TILE"); c->row_tile = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
@@ -504,29 +503,11 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
      * them side by side is slower than one after the other (2 chunks -3 %, 8 chunks -19 %); at 640x480 every kernel is
      * vector bound and chunks only add latency.  So automatic means: one chunk. */
     int want_chunks = c->overlap_chunks;
-    if (want_chunks == 0) want_chunks = 1;       /* measured: no configuration gains (profiles/r02_overlap_sweep.txt) */
+    if (want_chunks == 0) want_chunks = 1;       /* measured: no configuration gains (profiles/r02_overlap_sweep.txt); round 3 also
+                                                    tried only the sync chain of the second half of the batch under the decoder
+                                                    of the first: 3-4 % slower at 640x480 and 1080p alike (profiles/r03_1080p_experiments.txt) */
     const int nchunks = (want_chunks > 1 && n >= 256 * want_chunks && !c->prof) ? want_chunks : 1;
-    const bool rand_or_novsync = (c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE)) || (p->flags & CRTHIP_F_NO_VSYNC);
-    if (nchunks == 1 && c->sync_split && n >= 1024 && !c->prof && !rand_or_novsync && p->out_bpp != 0 && crt_ensure_aux(c) == CRTHIP_OK) {
-        /* The sync chain is pure latency (one wave per field, ~0.09 ms however small the batch) between two kernels that
-         * fill the chip.  Everything is encoded at full width; then the chain of the second half of the batch runs on the
-         * internal stream UNDER the decoder of the first half. */
-        hipStream_t main_stream = c->stream;
-        const int h = (n / 2 + 3) & ~3;
-        rc = fieldpass_chunk(c, p, enc, 0, n, 1, d_images, istride, d_out, ostride, d_state);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-        c->stream = c->aux_stream;
-        rc = fieldpass_chunk(c, p, enc, h, n - h, 4, d_images, istride, d_out, ostride, d_state);
-        c->stream = main_stream;
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
-        rc = fieldpass_chunk(c, p, enc, 0, h, 4 | 2, d_images, istride, d_out, ostride, d_state);
-        if (rc) return rc;
-        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-        rc = fieldpass_chunk(c, p, enc, h, n - h, 2, d_images, istride, d_out, ostride, d_state);
-    } else if (nchunks == 1) {
+    if (nchunks == 1) {
         rc = fieldpass_chunk(c, p, enc, 0, n, 7, d_images, istride, d_out, ostride, d_state);
     } else {
         /* Two-stage software pipeline over the chunks: the encoder + sync chain of ALL chunks run back to back on an
