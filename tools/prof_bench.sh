@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 out=gpurun_out/prof_$tag
 mkdir -p $out
-args="--steps 5 --warmup 2 --no-cpu --no-extra $*"
+args="--steps 20 --warmup 3 --no-cpu --no-extra $*"
 echo "python bench.py $args" > $out/args.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py $args > $out/trace.log 2>&1
 tail -1 $out/trace.log | cut -c1-300
