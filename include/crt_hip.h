@@ -282,7 +282,16 @@ int  crthip_sequence(crthip_ctx *ctx, const crthip_params *p, int n,
  *   weave  : image k = the output buffer after field k, given d_out_init = the buffer before the shard's first field
  *            (NULL = zeros).  patch_only != 0 (blend == 0 only): the images were woven before with a placeholder init;
  *            only the rows no field of the shard wrote are taken from d_out_init now.
+ *
+ * VHS build: a video's fields share ONE rand() stream, so a shard cannot start in the middle of it -- unless the stream was
+ * walked ahead for the whole video first: crthip_vhs_chain does that for n consecutive fields on ONE context (entry 0 of its
+ * bound history array = the generator before field 0; on return entry k = the generator at the start of field k, and with
+ * draw_aberration state[k].aux = the aberration height crt_modulate draws, crt_ntscvhs.c:205-207).  A context whose bound
+ * histories (and aux) were filled from that array is told so with crthip_seq_vhs_prechained(ctx, 1); its crthip_seq_encode
+ * then accepts any first_index and does not walk the stream again.  (include/crt_hip_node.h does all of this.)
  */
+int  crthip_vhs_chain(crthip_ctx *ctx, int n, crthip_state *d_state, int draw_aberration);
+int  crthip_seq_vhs_prechained(crthip_ctx *ctx, int on);
 int  crthip_seq_encode(crthip_ctx *ctx, const crthip_params *p, int n, int first_index, int rn0,
                        const void *d_images, size_t image_stride, crthip_state *d_state);
 int  crthip_seq_sync(crthip_ctx *ctx, const crthip_params *p, int n, crthip_state *d_state, int hsync_in, int vsync_in,

@@ -17,7 +17,9 @@
  *   the output      rows a field does not write keep what the previous fields left there (crt_core.c:431, 608, 662):
  *   picture         shard s's last picture is handed to shard s + 1 -- RCCL send/recv over xGMI between devices, a
  *                   device-to-device copy between shards that share a device -- and only the rows nobody in s + 1
- *                   wrote are taken from it (blend != 0: the blend recurrence itself runs down this chain).
+ *                   wrote are taken from it (blend != 0: the blend recurrence itself runs down this chain);
+ *   VHS: rand()     one stream per video: walked ahead on shard 0's device, the per-field states scattered (see
+ *                   crthip_node_sequence).
  *
  * A shard = one crthip_ctx with its own stream.  Several shards may share a device (`devices[]` may repeat an index):
  * that is how the whole protocol is exercised on a box with ONE GPU.  The RCCL communicator spans the DISTINCT devices.
@@ -45,6 +47,9 @@ int  crthip_node_rccl_ranks(const crthip_node *node);                 /* distinc
 crthip_ctx *crthip_node_ctx(crthip_node *node, int shard);            /* the shard's context (knobs: crthip_set_*) */
 const char *crthip_node_error_string(const crthip_node *node);
 int  crthip_node_synchronize(crthip_node *node);                      /* every shard's stream */
+/* VHS: the shard's per-field generator histories (crthip_vhs_bind_history of the shard's context; count x 32 words on the
+ * shard's device) */
+int  crthip_node_vhs_bind_history(crthip_node *node, int shard, unsigned *d_hist);
 
 /* contiguous block of shard `shard` in a batch / video of n_total fields: blocks of ceil(n_total / shards) */
 void crthip_node_shard_range(const crthip_node *node, int n_total, int shard, int *first, int *count);
@@ -65,7 +70,12 @@ int  crthip_node_fieldpass(crthip_node *node, const crthip_params *p, int n_tota
  * d_state[0][0].hsync / .vsync / .rn = the set's state before field 0; every d_state[s][k].field / .frame / .aux = the
  * encoder inputs of that field.  d_out_init: the output buffer before field 0, on shard 0's device (NULL = zeros).
  * *rounds (optional) = exchange rounds of the sync fixed point over the shards.  Synchronous.
- * Not available for the VHS build: its fields share one libc rand() stream (use crthip_sequence on one device). */
+ * VHS build (the system extra/video_convert.c is built for): the fields share ONE libc rand() stream.  Every shard's history
+ * array is bound with crthip_node_vhs_bind_history; entry 0 of shard 0's array = the generator before field 0.  Shard 0's
+ * device walks the stream for the whole video first (crthip_vhs_chain, ~0.15 ms per field, picture independent), the
+ * per-field generator states -- and, with CRTHIP_F_VHS_DRAW_ABERRATION, the aberration heights -- are scattered to the
+ * shards, after which they work in parallel like the other systems.  On return every shard's entry k = the generator after
+ * its field k. */
 int  crthip_node_sequence(crthip_node *node, const crthip_params *p, int n_total,
                           const void *const *d_images, size_t image_stride,
                           void *const *d_out, size_t out_stride, const void *d_out_init,

@@ -122,6 +122,8 @@ def load_library():
     L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_set_shape.argtypes = [vp, ci]
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
+    L.crthip_vhs_chain.argtypes = [vp, ci, vp, ci]
+    L.crthip_seq_vhs_prechained.argtypes = [vp, ci]
     L.crthip_seq_encode.argtypes = [vp, PP, ci, ci, ci, vp, sz, vp]
     L.crthip_seq_sync.argtypes = [vp, PP, ci, vp, ci, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.crthip_seq_decode.argtypes = [vp, PP, ci, vp, sz, vp]

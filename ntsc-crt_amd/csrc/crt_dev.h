@@ -438,6 +438,7 @@ struct crthip_ctx {
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
+    bool vhs_prechained;        /* crthip_seq_vhs_prechained: the bound histories already sit at the start of every field */
     int seq_guess_n;            /* crthip_seq_sync: the guess array holds the finals of a previous call for this many fields (warm restart) */
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
     int vhs_chunks;

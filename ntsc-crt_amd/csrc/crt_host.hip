@@ -591,7 +591,7 @@ int crthip_seq_encode(crthip_ctx *c, const crthip_params *p, int n, int first_in
     if (rc) return rc;
     if (!d_images || !d_state || first_index < 0) return CRTHIP_E_ARG;
     const bool vhs = c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
-    if (vhs && first_index != 0)
+    if (vhs && first_index != 0 && !c->vhs_prechained)
         return set_err(c, CRTHIP_E_ARG, "VHS: a video shares ONE rand() stream; its fields cannot start in the middle (first_index != 0)", hipSuccess);
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->cap_fields) {
@@ -605,8 +605,10 @@ int crthip_seq_encode(crthip_ctx *c, const crthip_params *p, int n, int first_in
         /* the fields share one rand() stream: run the chain ahead (k_vhs_chain: hist[k] = generator at the start
          * of field k, aberration heights drawn in-stream if asked), after which every field is independent;
          * then clean encode -> rand() noise (which also leaves rn), as in crthip_fieldpass */
-        rc = crt_run_vhs_chain(c, n, d_state, (p->flags & CRTHIP_F_VHS_DRAW_ABERRATION) != 0);
-        if (rc) return rc;
+        if (!c->vhs_prechained) {
+            rc = crt_run_vhs_chain(c, n, d_state, (p->flags & CRTHIP_F_VHS_DRAW_ABERRATION) != 0);
+            if (rc) return rc;
+        }
         crthip_params clean = *p;
         clean.noise = 0;
         rc = crt_run_encoder(c, &clean, n, d_images, istride, c->d_analog, d_state, true, 1, false);
@@ -730,6 +732,23 @@ int crthip_seq_weave(crthip_ctx *c, const crthip_params *p, int n, void *d_out, 
     hipLaunchKernelGGL(k_seq_weave, dim3((unsigned) n * (unsigned) outh), dim3(256), 0, c->stream, n, outh, pitch,
                        (unsigned char *) d_out, ostride, (const unsigned char *) d_out_init, sc.latest, patch_only);
     HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration)
+{
+    if (!c || n <= 0 || !d_state || c->system != CRTHIP_SYSTEM_NTSCVHS) return CRTHIP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = crt_run_vhs_chain(c, n, d_state, draw_aberration);
+    if (rc) return rc;
+    HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_seq_vhs_prechained(crthip_ctx *c, int on)
+{
+    if (!c || c->system != CRTHIP_SYSTEM_NTSCVHS) return CRTHIP_E_ARG;
+    c->vhs_prechained = on != 0;
     return CRTHIP_OK;
 }
 

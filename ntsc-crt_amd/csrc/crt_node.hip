@@ -29,6 +29,7 @@ struct crthip_node {
     std::vector<ncclComm_t> comm;       /* per rank */
     std::vector<hipStream_t> rstream;   /* per rank: the stream RCCL calls are enqueued on (= first shard's of that device) */
     std::vector<void *> d_blob;         /* per rank: device buffer of sizeof(crthip_params) */
+    std::vector<unsigned *> vhs_hist;   /* per shard: the bound generator histories (VHS) */
     char err[320];
 };
 
@@ -52,6 +53,7 @@ int crthip_node_create(crthip_node **out, int n_shards, const int *devices, int 
     crthip_node *nd = new (std::nothrow) crthip_node();
     if (!nd) return CRTHIP_E_NOMEM;
     nd->n_shards = n_shards; nd->system = system; nd->pattern = chroma_pattern; nd->n_ranks = 0; nd->err[0] = 0;
+    nd->vhs_hist.assign(n_shards, nullptr);
     nd->device.resize(n_shards); nd->ctx.assign(n_shards, nullptr); nd->stream.assign(n_shards, nullptr); nd->shard_rank.resize(n_shards);
     for (int s = 0; s < n_shards; s++) {
         const int d = devices ? devices[s] : s % ndev;
@@ -112,6 +114,14 @@ int crthip_node_synchronize(crthip_node *nd)
         NODE_HIP(nd, hipStreamSynchronize(nd->stream[s]));
     }
     return CRTHIP_OK;
+}
+
+int crthip_node_vhs_bind_history(crthip_node *nd, int s, unsigned *d_hist)
+{
+    if (!nd || s < 0 || s >= nd->n_shards) return CRTHIP_E_ARG;
+    nd->vhs_hist[s] = d_hist;
+    int rc = crthip_vhs_bind_history(nd->ctx[s], d_hist);
+    return rc == CRTHIP_OK ? rc : node_err(nd, rc, "crthip_vhs_bind_history", crthip_error_string(nd->ctx[s]));
 }
 
 void crthip_node_shard_range(const crthip_node *nd, int n_total, int s, int *first, int *count)
@@ -194,9 +204,8 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
                          void *const *d_out, size_t ostride, const void *d_out_init, crthip_state *const *d_state, int *rounds_out)
 {
     if (!nd || !p || n_total <= 0 || !d_images || !d_out || !d_state) return CRTHIP_E_ARG;
-    if (nd->system == CRTHIP_SYSTEM_NTSCVHS)
-        return node_err(nd, CRTHIP_E_ARG, "crthip_node_sequence", "the VHS build's fields share one rand() stream: use crthip_sequence on one device");
     const int S = nd->n_shards;
+    const bool vhs = nd->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
     std::vector<crthip_params> blob(S);
     int rc = crthip_node_broadcast_params(nd, p, blob.data());
     if (rc) return rc;
@@ -211,6 +220,37 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
     NODE_HIP(nd, hipSetDevice(nd->device[0]));
     NODE_HIP(nd, hipMemcpyAsync(&st0, d_state[0], sizeof(st0), hipMemcpyDeviceToHost, nd->stream[0]));
     NODE_HIP(nd, hipStreamSynchronize(nd->stream[0]));
+
+    if (vhs) {
+        /* one rand() stream per video: shard 0's device walks it for all n_total fields, then every shard gets the generator
+         * states (and drawn aberration heights) of its own fields */
+        for (int s = 0; s < S; s++)
+            if (cnt[s] > 0 && !nd->vhs_hist[s]) return node_err(nd, CRTHIP_E_ARG, "crthip_node_sequence", "VHS: bind every shard's histories (crthip_node_vhs_bind_history)");
+        const bool draw = (p->flags & CRTHIP_F_VHS_DRAW_ABERRATION) != 0;
+        unsigned *hist_all = nullptr;
+        crthip_state *st_all = nullptr;
+        NODE_HIP(nd, hipSetDevice(nd->device[0]));
+        NODE_HIP(nd, hipMalloc((void **) &hist_all, sizeof(unsigned) * 32 * (size_t) n_total));
+        NODE_HIP(nd, hipMalloc((void **) &st_all, sizeof(crthip_state) * (size_t) n_total));
+        NODE_HIP(nd, hipMemsetAsync(st_all, 0, sizeof(crthip_state) * (size_t) n_total, nd->stream[0]));
+        NODE_HIP(nd, hipMemcpyAsync(hist_all, nd->vhs_hist[0], sizeof(unsigned) * 32, hipMemcpyDeviceToDevice, nd->stream[0]));
+        NODE_CRT(nd, 0, crthip_vhs_bind_history(nd->ctx[0], hist_all));
+        rc = crthip_vhs_chain(nd->ctx[0], n_total, st_all, draw);
+        crthip_vhs_bind_history(nd->ctx[0], nd->vhs_hist[0]);
+        if (rc) { hipFree(hist_all); hipFree(st_all); return node_err(nd, rc, "crthip_vhs_chain", crthip_error_string(nd->ctx[0])); }
+        NODE_HIP(nd, hipStreamSynchronize(nd->stream[0]));
+        for (int s = 0; s < S; s++) {
+            if (cnt[s] <= 0) continue;
+            /* (hipMemcpy between devices: peer copy or staged through the host, the runtime's choice) */
+            NODE_HIP(nd, hipMemcpy(nd->vhs_hist[s], hist_all + 32 * (size_t) first[s], sizeof(unsigned) * 32 * (size_t) cnt[s], hipMemcpyDefault));
+            if (draw)
+                NODE_HIP(nd, hipMemcpy2D(&d_state[s][0].aux, sizeof(crthip_state), &st_all[first[s]].aux, sizeof(crthip_state),
+                                         sizeof(int), (size_t) cnt[s], hipMemcpyDefault));
+            NODE_CRT(nd, s, crthip_seq_vhs_prechained(nd->ctx[s], 1));
+        }
+        NODE_HIP(nd, hipSetDevice(nd->device[0]));
+        hipFree(hist_all); hipFree(st_all);
+    }
 
     /* phase 1 + the first sync round: every shard on its own host thread (crthip_seq_sync reads its flag back, i.e.
      * blocks its caller) */
@@ -273,6 +313,7 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
     }
     (void) last_shard;
     rc = crthip_node_synchronize(nd);
+    if (vhs) for (int s = 0; s < S; s++) if (cnt[s] > 0) crthip_seq_vhs_prechained(nd->ctx[s], 0);
     for (int s = 0; s < S; s++) if (init[s]) { hipSetDevice(nd->device[s]); hipFree(init[s]); }
     return rc;
 }

@@ -61,6 +61,8 @@ def sequence_sharded(engine, dist, rank, world, n_total, hsync0, vsync0, rn0, ou
         of its own fields wrote (blend: the recurrence over the fields continues down this chain, rank after rank).
     Returns the number of exchange rounds.  Ranks with an empty block take part in the collectives and pass state on."""
     import torch
+    if getattr(getattr(engine, "crt", None), "base_system", "") == "vhs" and world > 1:
+        raise NotImplementedError("a VHS video shares one rand() stream: cut it over GPUs with crthip_node_sequence (libcrthip_node.so)")
     first, hi = shard_range(n_total, rank, world)
     n = hi - first
     if n > 0:
