@@ -249,12 +249,15 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const int w0 = lp.wave0 * WSCALE, w1 = lp.wave1 * WSCALE, nw0 = -lp.wave0 * WSCALE, nw1 = -lp.wave1 * WSCALE;
     /* 5 samples per chroma cycle (PV-1000, crt_core.c:497-505, 544-549): the line table carries dci / dcq, the carriers
      * of the five sample phases follow from them with the blob's cos / sin tables; the phase of a sample is wave-uniform */
-    int w5i[5] = { 0, 0, 0, 0, 0 }, w5q[5] = { 0, 0, 0, 0, 0 };
+    /* ... so the carrier pair of a sample is ONE LDS read at a scalar offset ([lane][phase]{I, Q}, odd row stride), where
+     * selecting among five per-lane registers costs four v_cndmask per carrier (round 3: 3.35 -> 3.08 ms per 4096 fields) */
+    constexpr int W5_STRIDE = 11;
+    __shared__ int s_w5[S::CCS == 5 ? 64 * W5_STRIDE : 1];
     if constexpr (S::CCS == 5) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            w5i[i] = ((lp.wave0 * P.dem_cs[0][i] + lp.wave1 * P.dem_sn[0][i]) >> 15) * P.saturation * WSCALE;
-            w5q[i] = ((lp.wave0 * P.dem_cs[1][i] + lp.wave1 * P.dem_sn[1][i]) >> 15) * P.saturation * WSCALE;
+            s_w5[lane * W5_STRIDE + 2 * i] = ((lp.wave0 * P.dem_cs[0][i] + lp.wave1 * P.dem_sn[0][i]) >> 15) * P.saturation * WSCALE;
+            s_w5[lane * W5_STRIDE + 2 * i + 1] = ((lp.wave0 * P.dem_cs[1][i] + lp.wave1 * P.dem_sn[1][i]) >> 15) * P.saturation * WSCALE;
         }
     }
     int ph5 = 0;                                   /* sample index % 5 */
@@ -329,8 +332,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 int wi = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? nw0 : nw1;
                 int wq = k == 0 ? nw1 : k == 1 ? w0 : k == 2 ? w1 : nw0;
                 if constexpr (S::CCS == 5) {
-                    wi = w5i[ph5];                           /* ph5 is wave-uniform: a relative register move */
-                    wq = w5q[ph5];
+                    wi = s_w5[lane * W5_STRIDE + 2 * ph5];    /* ph5 is wave-uniform */
+                    wq = s_w5[lane * W5_STRIDE + 2 * ph5 + 1];
                     ph5 = ph5 == 4 ? 0 : ph5 + 1;
                 }
                 int cy, ci, cq;

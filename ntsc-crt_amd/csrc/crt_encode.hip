@@ -389,6 +389,14 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         int cI[S::CCS], cQ[S::CCS];
 #pragma unroll
         for (int k = 0; k < S::CCS; k++) { cI[k] = P.modI[crow][k] * (FAST ? 4096 : 1); cQ[k] = P.modQ[crow][k] * (FAST ? 4096 : 1); }
+        /* 5 samples per chroma cycle (PV-1000): the carrier phase x % 5 is no compile-time constant of the 4-sample unrolling;
+         * the line's five carrier pairs live in LDS, [lane][phase]{I, Q} at an odd row stride */
+        constexpr int CC5_STRIDE = 11;
+        __shared__ int s_cc5[S::CCS == 5 ? 64 * CC5_STRIDE : 1];
+        if constexpr (S::CCS == 5) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) { s_cc5[lane * CC5_STRIDE + 2 * k] = cI[k]; s_cc5[lane * CC5_STRIDE + 2 * k + 1] = cQ[k]; }
+        }
         const int cy_ = P.iir_c[0], ci_ = P.iir_c[1], cq_ = P.iir_c[2];
         const int white = P.white, ire_base = P.ire_base, noise = P.noise;
         int hy = 0, hi = 0, hq = 0;
@@ -482,8 +490,8 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         ccI = k == 0 ? cI[0] : k == 1 ? cI[1] : k == 2 ? cI[2] : cI[3];
                         ccQ = k == 0 ? cQ[0] : k == 1 ? cQ[1] : k == 2 ? cQ[2] : cQ[3];
                     } else {
-                        ccI = cph == 0 ? cI[0] : cph == 1 ? cI[1] : cph == 2 ? cI[2] : cph == 3 ? cI[3] : cI[4];
-                        ccQ = cph == 0 ? cQ[0] : cph == 1 ? cQ[1] : cph == 2 ? cQ[2] : cph == 3 ? cQ[3] : cQ[4];
+                        ccI = s_cc5[lane * CC5_STRIDE + 2 * cph];           /* one LDS read at a scalar offset instead of a */
+                        ccQ = s_cc5[lane * CC5_STRIDE + 2 * cph + 1];       /* five-way register select per carrier          */
                         cph = cph == S::CCS - 1 ? 0 : cph + 1;
                     }
                     int ire;
