@@ -16,7 +16,9 @@ pytestmark = pytest.mark.skipif(shutil.which("cmake") is None or not os.path.exi
 
 @pytest.mark.parametrize("defs,target,lib", [(["-DCRT_SYSTEM=0"], "ntsc", "libntsccrt_hip_ntsc.so"),
                                              (["-DCRT_SYSTEM=5", "-DVIDEO=on"], "ntsc_video", "libntsccrt_hip_vhs.so"),
-                                             (["-DCRT_SYSTEM=2", "-DCRT_DO_BLOOM=1"], "ntsc", "libntsccrt_hip_pv1k_bloom.so")])
+                                             (["-DCRT_SYSTEM=2", "-DCRT_DO_BLOOM=1"], "ntsc", "libntsccrt_hip_pv1k_bloom.so"),
+                                             (["-DCRT_SYSTEM=5", "-DVIDEO=on", "-DCRT_VARIANT=vhs_lp"], "ntsc_video", "libntsccrt_hip_vhs_lp.so"),
+                                             (["-DCRT_SYSTEM=0", "-DCRT_VARIANT=ntsc_nohsync"], "ntsc", "libntsccrt_hip_ntsc_nohsync.so")])
 def test_cmake_targets(tmp_path, defs, target, lib):
     import __graft_entry__ as g
     g.build()
