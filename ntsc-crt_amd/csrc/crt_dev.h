@@ -436,6 +436,8 @@ struct crthip_ctx {
     int sync_kernel;            /* CRTHIP_SYNC_KERNEL: 0 by batch size, 1 k_hsync (4 fields per wave), 2 k_hsync_wave (field per wave) */
     bool legacy_sync;           /* CRTHIP_LEGACY_SYNC=1 in the environment: the 16-lanes-per-field sync kernel (A/B measurements) */
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
+    int *d_bloom;               /* bloom build, lane-per-scanline decoder: line_w histogram, cursors, slot -> line (crt_decode3.hip) */
+    size_t bloom_cap;
     unsigned char *d_seq;       /* crthip_sequence scratch */
     size_t seq_cap;
     bool vhs_prechained;        /* crthip_seq_vhs_prechained: the bound histories already sit at the start of every field */
@@ -569,6 +571,8 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
                  crthip_line *d_lines, int advance_rn);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride);
+int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
+                               const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier);
 int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                         const crthip_line *d_lines, void *d_out, size_t ostride);
 

@@ -267,6 +267,7 @@ void crthip_destroy(crthip_ctx *c)
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
     if (c->d_vhs_next) hipFree(c->d_vhs_next);
     if (c->d_seq) hipFree(c->d_seq);
+    if (c->d_bloom) hipFree(c->d_bloom);
     if (c->d_nes_tab) hipFree(c->d_nes_tab);
     if (c->d_skel) hipFree(c->d_skel);
     if (c->d_jump1) hipFree(c->d_jump1);
@@ -758,10 +759,7 @@ int crthip_sequence(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     int rc = check_params(c, p, n);
     if (rc) return rc;
     if (!d_images || !d_out || !d_state) return CRTHIP_E_ARG;
-    if (p->out_bpp == 0) {
-        rc = seq_check(c, p, n);
-        return rc == CRTHIP_E_ARG && c->err[0] == 's' ? CRTHIP_OK : rc;     /* like crt_demodulate: nothing happens */
-    }
+    if (p->out_bpp == 0) return CRTHIP_OK;                /* unknown output format: like crt_demodulate, nothing happens (crt_core.c:312-315) */
     HIPCHK(c, hipSetDevice(c->device));
     crthip_state first;
     HIPCHK(c, hipMemcpyAsync(&first, d_state, sizeof(first), hipMemcpyDeviceToHost, c->stream));

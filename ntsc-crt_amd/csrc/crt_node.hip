@@ -190,9 +190,9 @@ static int hand_over_picture(crthip_node *nd, int a, const void *src, int b, voi
     }
     const int ra = nd->shard_rank[a], rb = nd->shard_rank[b];
     NODE_NCCL(nd, ncclGroupStart());
-    NODE_HIP(nd, hipSetDevice(nd->device[a]));
+    (void) hipSetDevice(nd->device[a]);
     ncclResult_t e1 = ncclSend(src, bytes, ncclChar, rb, nd->comm[ra], nd->stream[a]);
-    NODE_HIP(nd, hipSetDevice(nd->device[b]));
+    (void) hipSetDevice(nd->device[b]);
     ncclResult_t e2 = ncclRecv(dst, bytes, ncclChar, ra, nd->comm[rb], nd->stream[b]);
     ncclResult_t e3 = ncclGroupEnd();
     if (e1 != ncclSuccess || e2 != ncclSuccess || e3 != ncclSuccess)
@@ -290,31 +290,39 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
     /* the output picture across the seams */
     const size_t pic = (size_t) blob[0].outw * blob[0].outh * blob[0].out_bpp;
     std::vector<void *> init(S, nullptr);
+    auto free_inits = [&]() { for (int s = 0; s < S; s++) if (init[s]) { hipSetDevice(nd->device[s]); hipFree(init[s]); init[s] = nullptr; } };
     auto last_picture = [&](int s) { return (const unsigned char *) d_out[s] + (size_t) (cnt[s] - 1) * ostride; };
+    rc = CRTHIP_OK;
     if (!blob[0].blend) {
         /* every shard weaves with a placeholder (zeros) at once; then, down the chain, only the rows nobody in the shard
          * wrote are patched from the predecessor's last picture */
-        for (int s = 0; s < S; s++)
-            if (cnt[s] > 0) NODE_CRT(nd, s, crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, s == 0 ? d_out_init : nullptr, 0));
+        for (int s = 0; s < S && rc == CRTHIP_OK; s++)
+            if (cnt[s] > 0) {
+                rc = crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, s == 0 ? d_out_init : nullptr, 0);
+                if (rc) node_err(nd, rc, "crthip_seq_weave", crthip_error_string(nd->ctx[s]));
+            }
     }
     int prev = -1;
-    for (int s = 0; s < S; s++) {
+    for (int s = 0; s < S && rc == CRTHIP_OK; s++) {
         if (cnt[s] <= 0) continue;
         if (prev >= 0) {
-            NODE_HIP(nd, hipSetDevice(nd->device[s]));
-            NODE_HIP(nd, hipMalloc(&init[s], pic));
+            if (hipSetDevice(nd->device[s]) != hipSuccess || hipMalloc(&init[s], pic) != hipSuccess) { rc = node_err(nd, CRTHIP_E_NOMEM, "hipMalloc", "picture hand-over buffer"); break; }
             rc = hand_over_picture(nd, prev, last_picture(prev), s, init[s], pic);
-            if (rc) return rc;
-            NODE_CRT(nd, s, crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, init[s], blob[0].blend ? 0 : 1));
+            if (rc == CRTHIP_OK) {
+                rc = crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, init[s], blob[0].blend ? 0 : 1);
+                if (rc) node_err(nd, rc, "crthip_seq_weave", crthip_error_string(nd->ctx[s]));
+            }
         } else if (blob[0].blend) {
-            NODE_CRT(nd, s, crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, d_out_init, 0));
+            rc = crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, d_out_init, 0);
+            if (rc) node_err(nd, rc, "crthip_seq_weave", crthip_error_string(nd->ctx[s]));
         }
         prev = s;
     }
+    if (rc != CRTHIP_OK) { crthip_node_synchronize(nd); free_inits(); return rc; }
     (void) last_shard;
     rc = crthip_node_synchronize(nd);
     if (vhs) for (int s = 0; s < S; s++) if (cnt[s] > 0) crthip_seq_vhs_prechained(nd->ctx[s], 0);
-    for (int s = 0; s < S; s++) if (init[s]) { hipSetDevice(nd->device[s]); hipFree(init[s]); }
+    free_inits();
     return rc;
 }
 

@@ -707,41 +707,102 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
 
 /* CRT_DO_BLOOM (crt_core.c:399-402, 512-526): the beam energy of every decoded line (sum of its AV_LEN samples)
  * drives a leaky integrator prev_e that runs over the lines of a field in order; each line gets its own width,
- * i.e. its own resampler step dx and start scanL.  One workgroup per field: 256 lanes sum the lines in parallel
- * (v_dot4 against 0x01010101), lane 0 then walks the 240-step chain and patches dx / scanl into the line table. */
+ * i.e. its own resampler step dx and start scanL.  One workgroup per field:
+ *   1. the four waves sum the lines, a wave per line at a time: coalesced dword loads, v_dot4 against 0x01010101, a wave
+ *      reduction (the first version gave every lane its own line: 64 cache lines per load instruction, 0.65 ms per 4096
+ *      fields, 2.5x the bytes);
+ *   2. the input term of :518 does not depend on the chain: one lane per line computes it (the division by max_e);
+ *   3. the 240-step chain is now multiply, divide by 128, add: walked by wave 0 on the scalar unit;
+ *   4. one lane per line turns prev_e into line_w, dx (the division by outw) and scanL, and patches the line table. */
 template <class S>
 __global__ void __launch_bounds__(256)
 k_bloom(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
         crthip_line *__restrict__ lines)
 {
-    __shared__ int s_sum[S::LINES];
+    __shared__ int s_sum[S::LINES];            /* the line sum, then its chain term, then prev_e after the line */
     __shared__ int s_nrows[S::LINES];
+    __shared__ int s_pos[S::LINES];
     const int f = blockIdx.x, t = threadIdx.x;
     if (f >= n_fields) return;
     crthip_line *lt = lines + (size_t) f * S::LINES;
     if (t < S::LINES) {
         const crthip_line lp = lt[t];
-        const signed char *sig = inp + (size_t) f * fstride + lp.pos;
-        int sum = 0;
-        if ((lp.nrows & CRTHIP_LINE_NROWS_MASK) != 0) {
-            int i = 0;
-            for (; i + 4 <= S::AV_LEN; i += 4) sum = __builtin_amdgcn_sdot4(load4u(sig + i), 0x01010101, sum, false);
-            for (; i < S::AV_LEN; i++) sum += sig[i];
-        }
-        s_sum[t] = sum;
         s_nrows[t] = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+        s_pos[t] = lp.pos;
     }
     __syncthreads();
-    if (t == 0) {
-        const int max_e = P.bloom_max_e;                                  /* :400 */
-        int prev_e = 16384 / 8;                                           /* :401 */
-        for (int l = 0; l < S::LINES; l++) {
-            if (s_nrows[l] == 0) continue;                                /* :431: skipped lines do not reach :512 */
-            prev_e = (prev_e * 123 / 128) + ((((max_e >> 1) - s_sum[l]) << 10) / max_e);
-            const int line_w = (S::AV_LEN * 112 / 128) + (prev_e >> 9);
-            lt[l].dx = (line_w << 12) / P.outw;
-            lt[l].scanl = ((S::AV_LEN / 2) - (line_w >> 1) + 8) << 12;
+    const int wave = t >> 6, lane = t & 63;
+    /* 16 bytes per lane: one load instruction covers 1024 samples of a line; eight lines per wave and round, straight-line
+     * (lines nobody sees are summed too and dropped) */
+    constexpr int Q = S::AV_LEN / 16, REM = S::AV_LEN - Q * 16;
+    constexpr int UNR = 8;
+    for (int l0 = wave; l0 < S::LINES; l0 += 4 * UNR) {
+        int sum[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int l = l0 + 4 * u < S::LINES ? l0 + 4 * u : l0;
+            const signed char *sig = inp + (size_t) f * fstride + s_pos[l];
+            sum[u] = 0;
+#pragma unroll
+            for (int q0 = 0; q0 < Q; q0 += 64) {
+                if (q0 + lane < Q) {
+                    const v4i v = gload16u((unsigned long long) (sig + 16 * (q0 + lane)));
+                    sum[u] = __builtin_amdgcn_sdot4(v.x, 0x01010101, sum[u], false);
+                    sum[u] = __builtin_amdgcn_sdot4(v.y, 0x01010101, sum[u], false);
+                    sum[u] = __builtin_amdgcn_sdot4(v.z, 0x01010101, sum[u], false);
+                    sum[u] = __builtin_amdgcn_sdot4(v.w, 0x01010101, sum[u], false);
+                }
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int b = 0; b < REM; b++) sum[u] += sig[16 * Q + b];
+            }
         }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+#pragma unroll
+            for (int u = 0; u < UNR; u++) sum[u] += __shfl_xor(sum[u], off);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+            if (lane == 0 && l0 + 4 * u < S::LINES) s_sum[l0 + 4 * u] = sum[u];
+    }
+    __syncthreads();
+    const int max_e = P.bloom_max_e;                                      /* :400 */
+    if (t < S::LINES && s_nrows[t] != 0) s_sum[t] = (((max_e >> 1) - s_sum[t]) << 10) / max_e;
+    __syncthreads();
+    if (t < 64) {
+        /* the chain on the scalar unit: the terms sit in registers (lane = line & 63), v_readlane at a scalar
+         * index instead of two dependent LDS round trips per line */
+        constexpr int NJ = (S::LINES + 63) / 64;
+        int term[NJ], pe[NJ];
+        unsigned long long valid[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int l = j * 64 + t;
+            const bool on = l < S::LINES && s_nrows[l < S::LINES ? l : 0] != 0;
+            term[j] = on ? s_sum[l] : 0;
+            pe[j] = 0;
+            valid[j] = __ballot(on);                                      /* :431: skipped lines do not reach :512 */
+        }
+        int prev_e = 16384 / 8;                                           /* :401 */
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            for (int i = 0; i < 64; i++) {
+                if (!((valid[j] >> i) & 1ull)) continue;
+                prev_e = (prev_e * 123 / 128) + __builtin_amdgcn_readlane(term[j], i);      /* :518 */
+                pe[j] = t == i ? prev_e : pe[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+            if (j * 64 + t < S::LINES) s_sum[j * 64 + t] = pe[j];
+    }
+    __syncthreads();
+    if (t < S::LINES && s_nrows[t] != 0) {
+        const int line_w = (S::AV_LEN * 112 / 128) + (s_sum[t] >> 9);     /* :519 */
+        lt[t].dx = (line_w << 12) / P.outw;                               /* :521 */
+        lt[t].scanl = ((S::AV_LEN / 2) - (line_w >> 1) + 8) << 12;        /* :522 */
     }
 }
 

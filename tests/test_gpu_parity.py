@@ -277,6 +277,55 @@ def test_bloom_build_parity(crtlib, name, case, fused):
     _run_case(crtlib, (name,) + F4_CASES[case], fused=fused, shape=0, steps=3)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("name", ["ntscbloom", "snesbloom", "pv1kbloom"])
+def test_bloom_lane_per_scanline_parity(crtlib, name, case, fused):
+    """the bloom build in the lane-per-scanline decoder (crt_decode3.hip) -- the lines of the batch are
+    counting-sorted by their beam width (crt_core.c:518-522: dx and scanL follow from line_w alone), a wave decodes 64
+    lines of equal geometry.  Forced here (shape 1); 5 fields = 1200 lines over a few dozen widths: full and partial
+    waves, padding slots"""
+    _run_case(crtlib, (name,) + F4_CASES[case], fused=fused, shape=1, steps=2, n=5)
+
+
+@pytest.mark.parametrize("knobs", [dict(saturation=14), dict(saturation=19), dict(saturation=40), dict(brightness=5000, contrast=20),
+                                   dict(saturation=900, contrast=300), dict(brightness=200000, contrast=9000000, white_point=9000000),
+                                   dict(blend=1, v_fac=30), dict(scanlines=1, blend=1)])
+@pytest.mark.parametrize("geom", [(640, 480, R.FMT_BGRA), (64, 48, R.FMT_RGB), (1920, 1080, R.FMT_RGBA), (100, 300, R.FMT_BGR)])
+def test_bloom_lane_per_scanline_tiers_and_geometries(crtlib, knobs, geom):
+    """the bloom kernel's tiers (0: 64-bit mads, 2: 24-bit mads -- also for the lines tier 1 would take --, 3: exact), the
+    wide pixel tile (outw >= 1280), 3-byte formats, blend, and pictures shorter than the raster (several scanlines per
+    output row, one decoder pass per collision rank)"""
+    outw, outh, ofmt = geom
+    case = ("ntscbloom", outw, outh, ofmt, 320, 240, R.FMT_BGRA, 24, dict(as_color=1, hue=33), knobs)
+    _run_case(crtlib, case, fused=True, shape=1, steps=2, n=3)
+
+
+def test_bloom_large_batch_takes_the_lane_per_scanline_decoder(crtlib):
+    """crthip_set_shape(0) with a bloom build: more than ROWS_SHAPE_MAX_FIELDS fields go through the sort + lane-per-scanline
+    decoder, and decode the same pictures as the scanline-parallel shape"""
+    n, outw, outh = 200, 320, 240
+    imgs = np.stack([R.synth_image(96, 80, 4, 5 + k, "random" if k % 3 else "bars") for k in range(n)])
+    outs = []
+    for shape in (0, 2):
+        g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, "ntscbloom", device=0)
+        g.set_shape(shape)
+        s = crtlib.Settings(_padded(imgs), format=R.FMT_BGRA, as_color=1, field=[k & 1 for k in range(n)])
+        g.fieldpass(s, 24)
+        g.synchronize()
+        outs.append(g.out.cpu().numpy().copy())
+        g.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+    # ... and a few of them against the oracle
+    orc, ocrts = _oracle_batch("ntscbloom", 4, outw, outh, R.FMT_BGRA, {})
+    for j, k in enumerate((0, 1, 77, 199)):
+        c = ocrts[j]
+        c.settings(np.concatenate([imgs[k], imgs[k][-1:]], axis=0), format=R.FMT_BGRA, w=96, h=80, field=k & 1, frame=0, as_color=1)
+        c.modulate()
+        c.demodulate(24)
+        np.testing.assert_array_equal(outs[0][k].reshape(-1), c.out, err_msg="field %d" % k)
+
+
 @pytest.mark.parametrize("shape", [1, 2])
 @pytest.mark.parametrize("fused", [False, True])
 def test_nesrgb_parity(crtlib, fused, shape):
@@ -546,6 +595,16 @@ def test_vhs_encoder_parity(crtlib, aberration):
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("noise", [0, 12, 40])
 def test_vhs_fieldpass_parity(crtlib, fused, noise, sysname):
+    _vhs_fieldpass(crtlib, fused, noise, sysname, 0)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_vhs_bloom_lane_per_scanline_parity(crtlib, fused):
+    """the VHS bloom build through the sort + lane-per-scanline decoder (crt_decode3.hip)"""
+    _vhs_fieldpass(crtlib, fused, 12, "vhsbloom", 1)
+
+
+def _vhs_fieldpass(crtlib, fused, noise, sysname, shape):
     """BASELINE configs[3]: CRT_SYSTEM_NTSCVHS, 832x624 (and its CRT_DO_BLOOM build).  The decoder's noise is the C library's rand()
     stream (crt_core.c:344-351): field k's generator starts at srand(seed_k) and carries over from
     step to step, so the oracle processes each field's whole sequence under its own libc stream.
@@ -575,6 +634,7 @@ def test_vhs_fieldpass_parity(crtlib, fused, noise, sysname):
         want.append(per)
     g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, sysname, device=0)
     g.scanlines = 1
+    g.set_shape(shape)
     g.srand(seeds)
     fields = [k & 1 for k in range(n)]
     s = crtlib.Settings(_padded(imgs), format=crtlib.FMT_BGRA, field=list(fields), frame=0)
