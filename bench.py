@@ -472,6 +472,8 @@ def main():
                  desc="the headline workload at batch 256 (between the two kernel shapes)"),
             dict(name="pv1k_batch4096", system="pv1k", w=640, h=480, outw=640, outh=480, batch=4096, noise=24, scanlines=1,
                  desc="CRT_SYSTEM_PV1K (5 samples per chroma cycle, 1920-sample lines) 640x480 -> 640x480 BGRA, interlaced, noise 24"),
+            dict(name="bloom_batch4096", system="ntscbloom", w=640, h=480, outw=640, outh=480, batch=4096, noise=24, scanlines=1,
+                 desc="the headline workload in a CRT_DO_BLOOM build (per-scanline beam width): lines sorted by width, lane-per-scanline decoder"),
         ]
         for e in EX:
             small = e["batch"] <= 256

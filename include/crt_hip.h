@@ -330,8 +330,8 @@ int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
  * throughput shape) when the batch fills the chip, scanline-parallel kernels (a DPP row of 16 or 32 lanes per
  * scanline: one filter stage per lane, samples handed on with row_shr, pixels emitted by the whole wavefront from
  * LDS -- the latency shape) for small batches.  1 / 2 force the throughput / latency shape (tests, tuning).
- * Bloom builds always decode with the latency shape (their resampler is per scanline); the 5-sample system (PV-1000)
- * has the throughput shape with exact 32-bit arithmetic only. */
+ * Bloom builds (a resampler geometry per scanline) take the throughput shape after a counting sort of the batch's scanlines
+ * by beam width, so that the 64 scanlines of a wavefront share one geometry (crt_decode3.hip). */
 int  crthip_set_shape(crthip_ctx *ctx, int shape);
 
 /* Decoder output tile: 16 or 32 pixels per row and flush (0 = choose by output width, default). */

@@ -929,6 +929,14 @@ def test_random_configurations_scanline_parallel_shape(crtlib, seed):
     _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2, shape=2)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_bloom_lane_per_scanline(crtlib, seed):
+    """random configurations of the bloom builds through the beam-width sort + lane-per-scanline decoder"""
+    rng = np.random.default_rng(5000 + seed)
+    case = ("ntscbloom", "snesbloom", "pv1kbloom")[seed % 3], *_random_case(rng)[1:]
+    _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=3, shape=1)
+
+
 @pytest.mark.parametrize("n,w,h,noise", [(4096, 640, 480, 24), (64, 1920, 1080, 0)])
 def test_full_size_batch_properties(crtlib, n, w, h, noise):
     """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24) and configs[2]'s per-GPU

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: tests/test_gpu_parity.py's random configurations (HIP vs oracle, bit-exact) over a seed range,
 also for the VHS / NES / FIR variants.  usage: tools/soak_random.py first_seed count"""
-# seeds alternate systems (NTSC, FIR builds, pattern 0, SNES, template, NES-RGB, PV-1000) and both kernel shapes
+# seeds alternate systems (NTSC, FIR builds, pattern 0, bloom builds, SNES, template, NES-RGB, PV-1000) and both kernel shapes
 import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ntsc-crt_amd"), ROOT):
@@ -21,6 +21,8 @@ for seed in range(first, first + count):
         shape = 1                                     # the FIR decoder exists in the lane-per-scanline shape only
     elif variant == 2:
         case[0] = "ntscp0"
+    elif variant == 3:                                # CRT_DO_BLOOM builds, both shapes (shape 1: lines sorted by beam width)
+        case[0] = ("ntscbloom", "snesbloom", "pv1kbloom")[(seed >> 5) % 3]
     elif variant in (4, 5, 6, 7):                     # SURVEY 8(f) f4 systems
         case[0] = ("snes", "temp", "nesrgb", "pv1k")[variant - 4]
     try:
