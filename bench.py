@@ -12,6 +12,12 @@ batch of synthetic fields.  Headline workload = BASELINE.json configs[1]: 640x48
 CRT_SYSTEM_NTSC, interlaced (field parity alternates per frame), full colour, noise 24, hue 0, scanlines 1.
 "frames/sec" = field-passes/sec (one field-pass per input frame, as extra/video_convert.c:259-260 does).
 
+Batches in flight: consecutive steps are independent batches.  With S of them in flight step k runs on context k % S (its own
+stream, state, signal and picture buffers) and the launch sequences overlap on the chip.  S is tuned: the K steps are timed
+for S = 1, 2 and 3 (each bracketed by the barrier + synchronize) and the best one is `value`; `config.batches_in_flight_tuning`
+holds all three, `one_batch_in_flight` the S = 1 figure, `roofline.kernel_ms` is measured with ONE batch in flight.
+`--streams 1` pins S.  (profiles/r03_streams_sweep.txt)
+
 Multi-GPU: one process per GPU, frames sharded by rank; the only collective on the data path is the RCCL broadcast of
 the settings blob from rank 0.  Default: weak scaling (fixed batch per GPU).  `--strong F` splits F frames of
 BASELINE configs[2] (1920x1080, noise 0) over the ranks (F = 512 is the configuration BASELINE states).
@@ -168,13 +174,31 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     system, w, h, outw, outh = wl["system"], wl["w"], wl["h"], wl["outw"], wl["outh"]
     n, noise, scanlines, fir = wl["batch"], wl["noise"], wl["scanlines"], wl.get("fir", 0)
     nes = system in ("nes", "nesp0")
-    crt = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, system, device=local)
-    crt.scanlines = scanlines
-    crt.eq_fir = fir
-    crt.reserve(n)
-    crt.set_overlap(wl.get("overlap", 0))
-    crt.set_pixel_tile(wl.get("pixel_tile", 0))
-    crt.set_shape(wl.get("shape", 0))
+    # Batches in flight: consecutive steps are INDEPENDENT batches (each its own n television sets: context, state, signal
+    # and picture buffers), so with S of them step k runs on context k % S with its own stream and the launch sequences of S
+    # batches overlap -- the latency-bound sync chain and the launch gaps of one under the vector- / store-bound kernels of
+    # the others.  How much that gives depends on how the hardware queues happen to interleave (0 .. 25 % at 1080p from box
+    # to box and run to run, profiles/r03_streams_sweep.txt), so S is TUNED here: the same K steps are timed for every
+    # candidate S and the best one is the result; all of them are reported (`batches_in_flight_tuning`).  --streams N pins it.
+    want = wl.get("streams", 0)
+    cands = [1, 2, 3] if want <= 0 else [want]
+    if wl.get("sequence") or wl.get("graph"):
+        cands = [1]
+    S = max(cands)
+    crts, streams = [], []
+    for _ in range(S):
+        c_ = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, system, device=local)
+        c_.scanlines = scanlines
+        c_.eq_fir = fir
+        c_.reserve(n)
+        c_.set_overlap(wl.get("overlap", 0))
+        c_.set_pixel_tile(wl.get("pixel_tile", 0))
+        c_.set_shape(wl.get("shape", 0))
+        crts.append(c_)
+        streams.append(torch.cuda.Stream(device=dev) if S > 1 else None)
+        if S > 1:
+            c_.use_stream(streams[-1])
+    crt = crts[0]
 
     # synthetic input, generated on the device: uniform random bytes per frame; at most
     # `unique` distinct frames, tiled to the batch: the kernels' work is data-independent
@@ -193,7 +217,8 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
         s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
                             field=[a for a, _ in parity], frame=[b for _, b in parity])
     if system.startswith("vhs"):
-        crt.srand([1 + first + k for k in range(n)])
+        for c_ in crts:
+            c_.srand([1 + first + k for k in range(n)])
 
     # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
     p = crt.params(s, noise)
@@ -205,11 +230,22 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
         allc = [torch.zeros_like(crc) for _ in range(world)]
         dist.all_gather(allc, crc)
         blob_crcs = [int(c.item()) for c in allc]
-    crt._load_field_state(s)
+    for c_ in crts:
+        c_._load_field_state(s)
 
     seq_rounds = []
 
-    def step(k):
+    def step(k, inflight=1):
+        """step k of a run with `inflight` batches in flight: on context k % inflight"""
+        ci = k % inflight
+        crt = crts[ci]
+        if streams[ci] is not None:
+            with torch.cuda.stream(streams[ci]):
+                one_step(crt, k // inflight)
+        else:
+            one_step(crt, k)
+
+    def one_step(crt, k):
         if wl.get("sequence"):
             if dist is None:
                 crt.sequence(s, noise)
@@ -231,8 +267,9 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for k in range(warmup):
-        step(k)
+    torch.cuda.synchronize(dev)              # (the inputs were made on the default stream)
+    for k in range(warmup * S):
+        step(k, S)
     barrier()
     # The launch sequence of two consecutive steps (the even and the odd field of the interlaced pair: they differ in
     # the frame flip) is captured into a HIP graph and replayed: same kernels, same work, no per-launch host overhead
@@ -252,36 +289,44 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
             graph = None
             crt.use_stream(None)
             sys.stderr.write("bench.py: graph capture failed (%s), timing eager launches\n" % e)
-    barrier()
-    t0 = time.perf_counter()
-    if graph is not None:
-        for k in range(steps // 2):
-            graph.replay()
-        for k in range(steps % 2):
-            with torch.cuda.stream(side):
-                step(0)
-    else:
-        for k in range(steps):
-            step(k)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    tuning = {}
+    for cand in cands:
+        barrier()
+        t0 = time.perf_counter()
+        if graph is not None:
+            for k in range(steps // 2):
+                graph.replay()
+            for k in range(steps % 2):
+                with torch.cuda.stream(side):
+                    step(0)
+        else:
+            for k in range(steps):
+                step(k, cand)
+        barrier()
+        e_ = time.perf_counter() - t0
+        if dist is not None:
+            e_ = shard.max_over_ranks(e_, dist, dev)
+        tuning[cand] = e_
+    S = min(tuning, key=lambda c_: tuning[c_])
+    elapsed = tuning[S]
+    single = {"value": world * n * steps / tuning[1], "unit": "frames/sec", "ms_per_step": 1e3 * tuning[1] / steps} if 1 in tuning and len(tuning) > 1 else None
     launch_mode = "HIP graph of 2 steps, replayed" if graph is not None else "eager"
     if graph is not None:
         crt.use_stream(None)
         del graph
-    if dist is not None:
-        elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
-    # per-kernel durations with HIP events on the launch stream (separate short run, same workload)
+    # per-kernel durations with HIP events on the launch stream (separate short run, same workload, ONE batch in flight:
+    # a kernel's duration next to another batch's kernels says nothing about the kernel)
     crt.profile(True)
     for k in range(min(steps, 5)):
-        step(k)
+        step(k, 1)
     prof = crt.profile_read()
     crt.profile(False)
     kern_ms = {k: (v[0] / max(min(steps, 5), 1)) for k, v in prof.items()}     # ms per step (a step may launch a kernel twice)
     dom = max(kern_ms, key=lambda k: kern_ms[k])
-    crt.close()
-    del crt, images, base, s
+    for c_ in crts:
+        c_.close()
+    del crt, crts, images, base, s
     torch.cuda.empty_cache()
     if rank != 0:
         return None
@@ -329,7 +374,12 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                    "mode": ("one video cut over the ranks (shard.sequence_sharded), %s exchange round(s) per step" % sorted(set(seq_rounds))
                             if seq_rounds else "one video per GPU (crthip_sequence)") if wl.get("sequence")
                            else "independent frames (crthip_fieldpass)",
-                   "launch": launch_mode},
+                   "launch": launch_mode,
+                   "batches_in_flight": S,
+                   "batches_in_flight_tuning": {str(c_): {"value": world * n * steps / e_, "ms_per_step": 1e3 * e_ / steps} for c_, e_ in sorted(tuning.items())},
+                   "batches_in_flight_note": "step k runs on context / stream k % S; every context is an independent batch of "
+                                             "fields_per_gpu_per_step television sets with its own state, signal and picture buffers; "
+                                             "S tuned: the same steps timed for every candidate, the best one is the result"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dom,
                      # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -349,6 +399,8 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                      "pipeline_frac": abytes * n * steps / elapsed / 1e9 / HBM_PEAK_GBS,
                      "note": "640x480-class workloads are integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); 1080p leans on HBM writes"},
     }
+    if single is not None:
+        rec["one_batch_in_flight"] = single
     if blob_crcs is not None:
         rec["settings_blob_crc32_per_rank"] = blob_crcs
         rec["settings_blob_crc32_rank0_before_broadcast"] = crc_root
@@ -393,6 +445,8 @@ def main():
     ap.add_argument("--pixel-tile", type=int, default=0, help="decoder output tile: 0 auto, 16, 32")
     ap.add_argument("--overlap", type=int, default=0, help="chunks alternating between two streams (0 = library default)")
     ap.add_argument("--shape", type=int, default=0, help="kernel shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent batches in flight, each on its own stream and context (0 = tuned: 1, 2 and 3 are timed, the best is the result; 1 = off)")
     ap.add_argument("--graph", action="store_true", help="time a replayed HIP graph of two steps instead of eager launches (measured: no difference)")
     ap.add_argument("--dry-run", action="store_true", help="(tests) exercise launch / collectives / JSON without a GPU")
     ap.add_argument("--force-dist", action="store_true",
@@ -446,7 +500,7 @@ def main():
                                                     else (", %d-tap FIR decoder (USE_CONVOLUTION build)" % args.fir if args.fir else "")))
     wl = dict(name="headline" if headline else "custom", system=args.system, w=w, h=h, outw=outw, outh=outh, batch=n, noise=noise,
               scanlines=scanlines, fir=args.fir, unique=args.unique, overlap=args.overlap, pixel_tile=args.pixel_tile,
-              shape=args.shape, sequence=args.sequence, desc=desc, cpu_all_cores=True, graph=args.graph)
+              shape=args.shape, sequence=args.sequence, desc=desc, cpu_all_cores=True, graph=args.graph, streams=args.streams)
     if args.strong:
         wl["first_frame"] = shard.shard_range(args.strong, rank, world)[0]
     with_cpu = world == 1 and not args.no_cpu
@@ -477,7 +531,7 @@ def main():
         ]
         for e in EX:
             small = e["batch"] <= 256
-            r = run_workload(torch, crtlib, shard, None, dev, 0, 1, local, e, 30 if small else max(5, args.steps // 2), 3,
+            r = run_workload(torch, crtlib, shard, None, dev, 0, 1, local, e, 30 if small else max(5, args.steps), 3,
                              min(args.cpu_seconds, 4.0), not args.no_cpu and not small,
                              traffic_file=os.path.join(ROOT, "profiles", "traffic_%s.json" % e["name"]))
             extras.append(r)
@@ -496,7 +550,7 @@ def main():
                             "ran": ["broadcast(settings blob)", "all_gather(blob crc)", "all_reduce(MAX elapsed)", "barrier"]
                                    if dist is not None else []},
         }
-        for k in ("settings_blob_crc32_per_rank", "settings_blob_crc32_rank0_before_broadcast", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
+        for k in ("one_batch_in_flight", "settings_blob_crc32_per_rank", "settings_blob_crc32_rank0_before_broadcast", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
             if k in rec:
                 out[k] = rec[k]
         if extras:
