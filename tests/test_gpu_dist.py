@@ -176,3 +176,14 @@ def test_bench_sequence_mode_over_rccl():
                 "--warmup", "1", "--batch", "256"])
     assert "shard.sequence_sharded" in j["config"]["mode"] and j["collectives"]["initialized"] is True
     assert j["value"] > 1e4
+
+
+@pytest.mark.gpu
+def test_node_bench_runs_batches_in_flight_through_the_c_abi():
+    """tools/node_bench.c: S shards on one device = S independent batches in flight, plain C over libcrthip_node.so
+    (DESIGN.md 6a).  Here only: it builds, runs and reports a rate for 1, 2 and 3 shards."""
+    exe = os.path.join(ROOT, "ntsc-crt_amd", "lib", "node_bench")
+    assert os.path.exists(exe), "ntsc-crt_amd/lib/node_bench missing: run make -C ntsc-crt_amd"
+    for shards in (1, 2, 3):
+        r = subprocess.run([exe, str(shards), "96", "6"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "frames/sec" in r.stdout and "%d shard(s)" % shards in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
