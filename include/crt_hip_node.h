@@ -56,7 +56,9 @@ void crthip_node_shard_range(const crthip_node *node, int n_total, int shard, in
 
 /* The settings blob of shard 0 (`root`, finalized) to every shard: uploaded to shard 0's device, ncclBroadcast over
  * the communicator, read back from each shard's device into per_shard[shard] (host array of crthip_node_shards()
- * entries).  crthip_node_fieldpass / _sequence call this themselves; exposed for callers that stage their own batches. */
+ * entries).  crthip_node_fieldpass / _sequence call this themselves -- whenever `p` differs from the blob of their last
+ * round trip: a loop over batches with unchanged settings pays for it once, and crthip_node_fieldpass stays asynchronous
+ * from then on; exposed for callers that stage their own batches (tools/node_bench.c). */
 int  crthip_node_broadcast_params(crthip_node *node, const crthip_params *root, crthip_params *per_shard);
 
 /* One batch of n_total independent field-passes (crthip_fieldpass semantics per field).  Per-shard device pointers:

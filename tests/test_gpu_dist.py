@@ -187,3 +187,24 @@ def test_node_bench_runs_batches_in_flight_through_the_c_abi():
     for shards in (1, 2, 3):
         r = subprocess.run([exe, str(shards), "96", "6"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "frames/sec" in r.stdout and "%d shard(s)" % shards in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_tunes_the_batches_in_flight_and_reports_every_candidate():
+    """bench.py: the same K steps timed with 1, 2 and 3 independent batches in flight; `value` is the best one, all are in
+    the JSON, the one-batch figure separately"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "96", "--steps", "6", "--warmup", "1", "--no-cpu", "--no-extra"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    tuning = j["config"]["batches_in_flight_tuning"]
+    assert sorted(tuning) == ["1", "2", "3"] and j["config"]["batches_in_flight"] in (1, 2, 3)
+    best = max(tuning.values(), key=lambda t: t["value"])
+    assert abs(j["value"] - best["value"]) < 1e-6 * best["value"] and abs(j["ms_per_step"] - best["ms_per_step"]) < 1e-9 + 1e-6 * best["ms_per_step"]
+    assert abs(j["one_batch_in_flight"]["value"] - tuning["1"]["value"]) < 1e-6 * tuning["1"]["value"]
+    assert j["steps"] == 6 and j["roofline"]["kernel_ms"]["decode"] > 0
+    # pinned
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "96", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-extra", "--streams", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["config"]["batches_in_flight"] == 1 and sorted(j["config"]["batches_in_flight_tuning"]) == ["1"] and "one_batch_in_flight" not in j
