@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 out=gpurun_out/prof_$tag
 mkdir -p $out
-args="--steps 20 --warmup 3 --no-cpu --no-extra $*"
+args="--steps 20 --warmup 3 --no-cpu --no-extra --streams 1 $*"   # one batch in flight: a kernel's duration beside another batch's kernels says nothing about the kernel
 echo "python bench.py $args" > $out/args.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py $args > $out/trace.log 2>&1
 tail -1 $out/trace.log | cut -c1-300
@@ -16,7 +16,7 @@ f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $out/kernel_stats.csv && head -8 $out/kernel_stats.csv | cut -c1-160
 rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu --no-extra $* > $out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu --no-extra --streams 1 $* > $out/pmc_$c.log 2>&1
   g=$(find $out/pmc_$c -name "*counter_collection.csv" | head -1)
   [ -n "$g" ] && cp "$g" $out/pmc_$c.csv && python3 - "$g" $c <<'PY'
 import csv, sys, collections

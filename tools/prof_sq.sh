@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT" \
            "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU SQ_LDS_ADDR_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $out/p$i -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu $* > $out/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $out/p$i -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu --streams 1 $* > $out/p$i.log 2>&1
 done
 python3 - $out <<'PY'
 import csv, sys, glob, collections
