@@ -749,28 +749,31 @@ def test_sequence_mode_equals_sequential_processing(crtlib, name, noise, scanlin
         c.modulate()
         c.demodulate(noise)
         want.append((c.out.copy(), c.get("hsync"), c.get("vsync"), c.get("rn")))
-    g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, name, device=0)
-    g.scanlines = scanlines
-    g.state[0, crtlib.ST_HSYNC] = 7
-    g.state[0, crtlib.ST_VSYNC] = 2
-    if nes:
-        full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
-        full[:, :240] = torch.from_numpy(frames.astype(np.int16)).to("cuda:0")
-        s = crtlib.Settings(full[:, :240], hue=0, dot_crawl_offset=[k % 3 for k in range(n)])
-    else:
-        par = [shard.field_parity(k) for k in range(n)]
-        s = crtlib.Settings(_padded(frames), format=crtlib.FMT_BGRA, field=[a for a, _ in par], frame=[b for _, b in par],
-                            dot_crawl_offset=[k % 3 for k in range(n)] if dot_crawl else 0)
-    passes = g.sequence(s, noise, out_init=_to_dev(init))
-    g.synchronize()
-    assert 1 <= passes <= n + 1
-    out = g.out.cpu().numpy()
-    for k in range(n):
-        o, hs, vs, rn = want[k]
-        assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), "field %d state" % k
-        np.testing.assert_array_equal(out[k].reshape(-1), o, err_msg="sequence field %d (passes %d)" % (k, passes))
-    print("sequence %s noise %d: %d sync passes" % (name, noise, passes))
-    g.close()
+    # bloom builds: also through the beam-width sort + lane-per-scanline decoder (shape 1; small batches default to the other)
+    for shape in ((0, 1) if name.endswith("bloom") else (0,)):
+        g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, name, device=0)
+        g.scanlines = scanlines
+        g.set_shape(shape)
+        g.state[0, crtlib.ST_HSYNC] = 7
+        g.state[0, crtlib.ST_VSYNC] = 2
+        if nes:
+            full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
+            full[:, :240] = torch.from_numpy(frames.astype(np.int16)).to("cuda:0")
+            s = crtlib.Settings(full[:, :240], hue=0, dot_crawl_offset=[k % 3 for k in range(n)])
+        else:
+            par = [shard.field_parity(k) for k in range(n)]
+            s = crtlib.Settings(_padded(frames), format=crtlib.FMT_BGRA, field=[a for a, _ in par], frame=[b for _, b in par],
+                                dot_crawl_offset=[k % 3 for k in range(n)] if dot_crawl else 0)
+        passes = g.sequence(s, noise, out_init=_to_dev(init))
+        g.synchronize()
+        assert 1 <= passes <= n + 1
+        out = g.out.cpu().numpy()
+        for k in range(n):
+            o, hs, vs, rn = want[k]
+            assert (g.get("hsync")[k], g.get("vsync")[k], g.get("rn")[k]) == (hs, vs, rn), "field %d state" % k
+            np.testing.assert_array_equal(out[k].reshape(-1), o, err_msg="sequence field %d (passes %d)" % (k, passes))
+        print("sequence %s noise %d shape %d: %d sync passes" % (name, noise, shape, passes))
+        g.close()
 
 
 @pytest.mark.parametrize("ofmt,scanlines,outsz", [(R.FMT_BGRA, 1, (640, 480)), (R.FMT_RGB, 0, (832, 624)), (R.FMT_ARGB, 1, (320, 240))])
