@@ -61,5 +61,5 @@ for rep in range(2):
     f1, t1 = timeit(ctxs[:1], "plain")
     print("1 stream          : %8.0f fps %.3f ms" % (f1, t1))
     for S in (2, 3):
-        for mode in ("plain", "flips"):
+        for mode in ("plain",):
             print("%d streams %-8s: %8.0f fps %.3f ms" % ((S, mode) + timeit(ctxs[:S], mode, t1)))
