@@ -940,8 +940,8 @@ def test_random_configurations_bloom_lane_per_scanline(crtlib, seed):
     _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=3, shape=1)
 
 
-@pytest.mark.parametrize("n,w,h,noise", [(4096, 640, 480, 24), (64, 1920, 1080, 0)])
-def test_full_size_batch_properties(crtlib, n, w, h, noise):
+@pytest.mark.parametrize("name,n,w,h,noise", [("ntsc", 4096, 640, 480, 24), ("ntsc", 64, 1920, 1080, 0), ("ntscbloom", 4096, 640, 480, 24)])
+def test_full_size_batch_properties(crtlib, name, n, w, h, noise):
     """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24) and configs[2]'s per-GPU
     share (512 frames of 1920x1080 over 8 GPUs = 64, noise 0): (a) replication -- fields that carry the same image,
     parity and state produce the same picture and state wherever they sit in the batch; (b) a checksum over all
@@ -950,12 +950,18 @@ def test_full_size_batch_properties(crtlib, n, w, h, noise):
     import torch
     uniq = 8 if w <= 640 else 2                           # (synthesising 1080p images on the host is slow)
     base = np.stack([R.synth_image(w, h, 4, 7000 + k) for k in range(uniq)])
+    if name.endswith("bloom"):
+        # a different brightness ramp down every image: the beam energy, hence the beam width, changes from line to line
+        # and from image to image -- a million scanlines over a few dozen widths through the sort of crt_decode3.hip
+        for k in range(uniq):
+            ramp = (np.arange(h)[:, None, None] * (k + 1) * 37 // h) % 256
+            base[k] = (base[k].astype(np.int32) * ramp // 255).astype(np.uint8)
     imgs = torch.from_numpy(np.concatenate([base, base[:, -1:]], axis=1)).to("cuda:0")       # + the spare row
     data = imgs.repeat(n // uniq, 1, 1, 1)[:, :h]
     fields = [(k // uniq) & 1 for k in range(n)]                  # parity changes every `uniq` fields
     sums = []
     for run in range(2):
-        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, name, device=0)
         g.scanlines = 1
         s = crtlib.Settings(data, format=crtlib.FMT_BGRA, field=list(fields), frame=0)
         g.fieldpass(s, noise)
@@ -971,7 +977,7 @@ def test_full_size_batch_properties(crtlib, n, w, h, noise):
             host = out[reps].cpu().numpy()
         g.close()
     assert sums[0] == sums[1]
-    orc = R.Oracle("ntsc")
+    orc = R.Oracle(name)
     for j, k in enumerate(reps):
         c = orc.new_crt(w, h, R.FMT_BGRA)
         c.set("scanlines", 1)
