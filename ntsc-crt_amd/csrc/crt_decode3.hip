@@ -8,6 +8,8 @@
  * So the lines of the batch are counting-sorted by line_w and every wave decodes 64 lines of EQUAL geometry, wherever in the
  * batch they come from: source and destination of a lane are per-lane addresses already (the cooperative tiles of
  * crt_decode_lane.h move row pieces, not rows of one picture).  Lines nobody sees (nrows == 0) drop out of the sort.
+ * The sort is an optimisation, not a correctness condition: a wave that holds several geometries after all (a line table
+ * that did not come from k_bloom, through crthip_decode) is decoded in rounds, one geometry at a time.
  *
  *   k_bloom_count    line_w histogram of the batch (LDS histogram per 256 lines, then one global atomic per bucket)
  *   k_bloom_scatter  bucket starts = prefix sum of the counts rounded up to whole waves; line index -> its slot
@@ -27,7 +29,7 @@ __device__ __forceinline__ int bloom_key(const crthip_line &lp, int outw)
     const int half = S::AV_LEN / 2 + 8 - (lp.scanl >> 12);
     const int line_w = 2 * half + (lp.dx != ((2 * half) << 12) / outw ? 1 : 0);
     const int key = line_w - S::AV_LEN * 112 / 128 + BLOOM_KEY_BIAS;
-    return key < 0 ? 0 : key >= BLOOM_BUCKETS ? BLOOM_BUCKETS - 1 : key;       /* never clamps, see above */
+    return key < 0 ? 0 : key >= BLOOM_BUCKETS ? BLOOM_BUCKETS - 1 : key;       /* never clamps for k_bloom's tables, see above */
 }
 
 /* lines per workgroup of the two sort kernels: the global atomics are one per bucket and workgroup, on few hot addresses */

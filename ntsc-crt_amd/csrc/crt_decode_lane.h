@@ -245,6 +245,19 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
     if (!live || rank != want_rank) nrows = 0;
     if (__ballot(nrows > 0) == 0ull) return;          /* whole wave has nothing to do */
+    /* Bloom: the sort hands every wave lines of ONE geometry (see crt_decode3.hip for why their width is bounded).  Should
+     * a wave ever hold more than one -- a line table that did not come from k_bloom, through crthip_decode -- it is decoded
+     * in rounds, one geometry at a time, the other lanes idling: correct for any table, free for the tables that occur. */
+    int nrows_todo = nrows;
+  do {
+    int scanl_u = 0, dx_u = P.dx;
+    if (BLOOM) {
+        const int src = __ffsll((unsigned long long) __ballot(nrows_todo > 0)) - 1;
+        scanl_u = __builtin_amdgcn_readlane(lp.scanl, src);         /* crt_core.c:519-526 */
+        dx_u = __builtin_amdgcn_readlane(lp.dx, src);
+        nrows = (lp.scanl == scanl_u && lp.dx == dx_u) ? nrows_todo : 0;
+        if (nrows > 0) nrows_todo = 0;
+    }
     const bool act = nrows > 0;
     constexpr int bpp = BPP3 ? 3 : 4;
     const size_t pitch = (size_t) P.outw * bpp;
@@ -268,13 +281,6 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
             s_w5[lane * W5_STRIDE + 2 * i] = ((lp.wave0 * P.dem_cs[0][i] + lp.wave1 * P.dem_sn[0][i]) >> 15) * P.saturation * WSCALE;
             s_w5[lane * W5_STRIDE + 2 * i + 1] = ((lp.wave0 * P.dem_cs[1][i] + lp.wave1 * P.dem_sn[1][i]) >> 15) * P.saturation * WSCALE;
         }
-    }
-    /* bloom: the wave's common geometry, from its first live line (crt_core.c:519-526) */
-    int scanl_u = 0, dx_u = P.dx;
-    if (BLOOM) {
-        const int src = __ffsll((unsigned long long) __ballot(live)) - 1;
-        scanl_u = __builtin_amdgcn_readlane(lp.scanl, src);
-        dx_u = __builtin_amdgcn_readlane(lp.dx, src);
     }
     const int first = scanl_u >> 12;               /* first filtered sample, :525, :539 */
     const int xq0 = first >> 2;                    /* ... and its dword */
@@ -513,6 +519,8 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
             }
         }
     }
+    wave_lds_fence();
+  } while (BLOOM && __ballot(nrows_todo > 0) != 0ull);
 }
 
 

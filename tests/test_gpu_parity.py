@@ -301,6 +301,39 @@ def test_bloom_lane_per_scanline_tiers_and_geometries(crtlib, knobs, geom):
     _run_case(crtlib, case, fused=True, shape=1, steps=2, n=3)
 
 
+def test_bloom_decoder_takes_any_line_table(crtlib):
+    """crthip_decode with a line table that did NOT come from k_bloom: steps and starts edited per line, so that lines of
+    equal sort key carry different resampler geometries.  The lane-per-scanline decoder then decodes a wave in rounds, one
+    geometry at a time; the scanline-parallel decoder, which takes every line's geometry as it comes, is the reference."""
+    import ctypes as C
+    import torch
+    n, w, h = 6, 640, 480
+    imgs = np.stack([R.synth_image(w, h, 4, 40 + k, "random" if k % 2 else "bars") for k in range(n)])
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntscbloom", device=0)
+    s = crtlib.Settings(_padded(imgs), format=R.FMT_BGRA, as_color=1, field=[k & 1 for k in range(n)])
+    g.modulate(s)
+    g.demodulate(24)                                     # fills inp[] and the line table
+    g.synchronize()
+    lt = g.line_table                                    # [n, lines, 8]: ..., dx = [6], scanl = [7]
+    rng = np.random.default_rng(7)
+    dx_add = torch.from_numpy(rng.integers(0, 4, size=(n, lt.shape[1])).astype(np.int32)).to(lt.device)
+    sl_add = torch.from_numpy((rng.integers(0, 3, size=(n, lt.shape[1])) * 1365).astype(np.int32)).to(lt.device)
+    lt[:, :, 6] += dx_add * 3
+    lt[:, :, 7] += sl_add                                # also fractional starts, which k_bloom never produces
+    p = g.params(s, 24)
+    outs = []
+    for shape in (1, 2):
+        g.set_shape(shape)
+        g.out.zero_()
+        g._check(g.L.crthip_decode(g.ctx, C.byref(p), n, C.c_void_p(g.inp.data_ptr()), C.c_void_p(lt.data_ptr()),
+                                   C.c_void_p(g.out.data_ptr()), g.out.stride(0)), "crthip_decode")
+        g.synchronize()
+        outs.append(g.out.cpu().numpy().copy())
+    g.close()
+    assert outs[1].any()
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def test_bloom_large_batch_takes_the_lane_per_scanline_decoder(crtlib):
     """crthip_set_shape(0) with a bloom build: more than ROWS_SHAPE_MAX_FIELDS fields go through the sort + lane-per-scanline
     decoder, and decode the same pictures as the scanline-parallel shape"""
