@@ -384,8 +384,18 @@ __device__ __forceinline__ int burst_step(int acc, int s)
         return ((t127 + ((t127 >> 31) & 127)) >> 7) + s;                       /* C's truncating / 128 */
     }
     /* |acc| < 2^24: acc * 127 / 128 == acc - (acc >> 7) - (acc > 0 && (acc & 127) != 0), the last term being
-     * "(acc & 0x8000007f) > 0" as a signed compare */
-    return (acc + s) - (acc >> 7) - (int) ((int) ((unsigned) acc & 0x8000007fu) > 0);
+     * "(acc & 0x8000007f) > 0" as a signed compare = that value clamped to [0, 1].  The chain is ONE dependent stream per
+     * lane (1200 steps per field, three quarters of the sync kernel's latency), so what counts is the depth of a step:
+     * {and -> med3 | add, shift -> sub} -> sub here, three levels; as a compare into VCC and a subtract-with-borrow it was
+     * and -> cmp -> (wait state) -> subb -> add */
+    int a1 = acc + s;
+    asm volatile("" : "+v"(a1));                             /* (keeps the compiler from forming acc - (acc >> 7) first: one level deeper) */
+    int t = a1 - (acc >> 7);
+    asm volatile("" : "+v"(t));                              /* (... nor (acc >> 7) + c) */
+    const int x = (int) ((unsigned) acc & 0x8000007fu);
+    int c;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(c) : "v"(x));      /* (spelled out: the compiler makes min + compare + select of it) */
+    return t - c;
 }
 
 /* FPB = fields (= waves) per workgroup.  1: the latency shape, everything wave-synchronous.  4 (large batches): the
@@ -403,10 +413,14 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int WBACK = 24, WPIECES = 5, WLEN = WPIECES * 16;   /* per line: bytes [ln + WOFF - 24, + 80): hsync -24 .. 40 */
     constexpr int WSTR = 21;                             /* dwords per window row (84 bytes: odd stride, no bank conflicts) */
     constexpr int BPIECES = (S::CB_LEN + 15) / 16;       /* 16-byte pieces covering the CB_LEN burst bytes */
-    constexpr int BSTR = BPIECES * 4 + 1;                /* dwords per burst row */
+    /* burst row in LDS: the line's NB samples of every carrier phase side by side -- [phase][NB bytes in 3 dwords] -- so that
+     * a chain lane gets its line in three dword reads and takes the samples out of them with byte selects that are the same
+     * for every lane (SDWA).  Odd row stride: the line lanes write their rows without bank conflicts. */
+    constexpr int BDW = (NB + 3) / 4;                    /* dwords per phase string */
+    constexpr int BSTR = (CCS * BDW) | 1;                /* dwords per burst row */
     __shared__ int s_win_[FPB][(CH + 1) * WSTR];               /* sync windows of the chunk's lines (+ the line after it) */
     __shared__ int s_bur_[FPB][CH * BSTR];                     /* burst samples, one row per non-skipped line, grouped by line class */
-    __shared__ int s_acc_[FPB][CH][CCS == 4 ? 4 : 8];          /* the class's integrators after each of those lines */
+    __shared__ int s_acc_[FPB][CH + 1][CCS == 4 ? 4 : 8];      /* the class's integrators after each of those lines (+ a row nobody reads) */
     __shared__ int s_cnt_[FPB][VPER], s_off_[FPB][VPER];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -570,10 +584,22 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             const int nl = S::LINES - cc * CH < CH ? S::LINES - cc * CH : CH;
             /* the burst samples fetched one iteration ago -> LDS, one row per non-skipped line in class order */
             if (!rec_skip) {
+                /* de-interleave: sample q of phase string k is byte k + CCS * q of the fetched window */
+                int raw[BPIECES * 4];
 #pragma unroll
-                for (int q = 0; q < BPIECES; q++) {
-                    int *d = s_bur + rec_rid * BSTR + q * 4;
-                    d[0] = breg[q].x; d[1] = breg[q].y; d[2] = breg[q].z; d[3] = breg[q].w;
+                for (int q = 0; q < BPIECES; q++) { raw[4 * q] = breg[q].x; raw[4 * q + 1] = breg[q].y; raw[4 * q + 2] = breg[q].z; raw[4 * q + 3] = breg[q].w; }
+#pragma unroll
+                for (int k = 0; k < CCS; k++) {
+#pragma unroll
+                    for (int wd = 0; wd < BDW; wd++) {
+                        unsigned v = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int q = 4 * wd + b, i = k + CCS * q;       /* compile-time */
+                            if (q < NB) v |= (((unsigned) raw[i >> 2] >> (8 * (i & 3))) & 0xffu) << (8 * b);
+                        }
+                        s_bur[rec_rid * BSTR + k * BDW + wd] = (int) v;
+                    }
                 }
             }
             HSW_SYNC();
@@ -583,28 +609,51 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             int n_max = n_mine;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(n_max, o); n_max = v > n_max ? v : n_max; }
-            const signed char *bp = (const signed char *) (s_bur_[chain_lane ? my_slot : 0] + row0 * BSTR) + k0;
-            int cur[NB], nxt[NB];
+            /* my phase string of my class's first line: BDW dwords; sample q = byte q & 3 of dword q >> 2 */
+            const int *bp = s_bur_[chain_lane ? my_slot : 0] + row0 * BSTR + k0 * BDW;
+            int cur[BDW], nxt[BDW];
 #pragma unroll
-            for (int q = 0; q < NB; q++) { cur[q] = n_mine > 0 ? bp[CCS * q] : 0; nxt[q] = 0; }
-            for (int j = 0; j < n_max; j++) {
+            for (int wd = 0; wd < BDW; wd++) { cur[wd] = n_mine > 0 ? bp[wd] : 0; nxt[wd] = 0; }
+            int j = 0;
+            if (!exact_mul) {
+                /* The lines every chain lane has, in a loop without a single divergent branch: all 64 lanes run it (the lanes
+                 * without a chain integrate row 0 into a register nobody reads and store into the spare row of s_acc); a lone
+                 * wave pays ~9 cycles per dependent instruction, so the exec-mask bookkeeping of a predicated body (two
+                 * branches per line) cost as much as the ten steps of the line. */
+                int n_min = chain_lane ? n_mine : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(n_min, o); n_min = v < n_min ? v : n_min; }
+                int *ap = chain_lane ? &s_acc_[my_slot][row0][my_p] : &s_acc_[0][CH][0];
+                const int astep = chain_lane ? (int) (sizeof(s_acc_[0][0]) / sizeof(int)) : 0;
+                for (; j < n_min; j++) {
+                    const int jn = j + 1 < n_mine ? j + 1 : j;           /* (the last prefetch stays inside my rows) */
+#pragma unroll
+                    for (int wd = 0; wd < BDW; wd++) nxt[wd] = bp[jn * BSTR + wd];
+#pragma unroll
+                    for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, (cur[q >> 2] << (24 - 8 * (q & 3))) >> 24);
+                    *ap = acc;
+                    ap += astep;
+#pragma unroll
+                    for (int wd = 0; wd < BDW; wd++) cur[wd] = nxt[wd];
+                }
+            }
+            for (; j < n_max; j++) {                                     /* the rest (and caller-supplied garbage in ccf), predicated */
                 if (j + 1 < n_mine) {                                    /* next line's samples while this one's chain runs */
-                    const signed char *bn = bp + (j + 1) * (BSTR * 4);
 #pragma unroll
-                    for (int q = 0; q < NB; q++) nxt[q] = bn[CCS * q];
+                    for (int wd = 0; wd < BDW; wd++) nxt[wd] = bp[(j + 1) * BSTR + wd];
                 }
                 if (j < n_mine) {
                     if (exact_mul) {
 #pragma unroll
-                        for (int q = 0; q < NB; q++) acc = burst_step<S, true>(acc, cur[q]);
+                        for (int q = 0; q < NB; q++) acc = burst_step<S, true>(acc, (cur[q >> 2] << (24 - 8 * (q & 3))) >> 24);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, cur[q]);
+                        for (int q = 0; q < NB; q++) acc = burst_step<S, false>(acc, (cur[q >> 2] << (24 - 8 * (q & 3))) >> 24);
                     }
                     s_acc_[my_slot][row0 + j][my_p] = acc;
                 }
 #pragma unroll
-                for (int q = 0; q < NB; q++) cur[q] = nxt[q];
+                for (int wd = 0; wd < BDW; wd++) cur[wd] = nxt[wd];
             }
             }
             HSW_SYNC();
