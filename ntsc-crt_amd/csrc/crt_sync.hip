@@ -623,6 +623,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                 int n_min = chain_lane ? n_mine : 0x7fffffff;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(n_min, o); n_min = v < n_min ? v : n_min; }
+                if (n_min == 0x7fffffff) n_min = 0;                      /* (no chain lane at all: cannot happen, slot 0 always has a field) */
                 int *ap = chain_lane ? &s_acc_[my_slot][row0][my_p] : &s_acc_[0][CH][0];
                 const int astep = chain_lane ? (int) (sizeof(s_acc_[0][0]) / sizeof(int)) : 0;
                 for (; j < n_min; j++) {
