@@ -48,6 +48,19 @@ def test_node_library_exports_its_header(lib):
         assert n in exported, n
 
 
+def test_c_programs_over_the_node_library_are_built(lib):
+    """tests/node_probe.c (parity of the multi-shard entries) and tools/node_bench.c (batches in flight through the C ABI
+    alone) are plain C over include/crt_hip_node.h; the build links them against libcrthip_node.so and nothing else of ours"""
+    for exe in ("node_probe", "node_bench"):
+        path = os.path.join(ROOT, "ntsc-crt_amd", "lib", exe)
+        assert os.path.exists(path), exe
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        wanted = set(line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip())
+        ours = sorted(n for n in wanted if n.startswith("crthip_"))
+        assert ours and all(n.startswith(("crthip_node_", "crthip_")) for n in ours)
+        assert not any(n.startswith(("hip", "nccl", "orc_")) for n in wanted), "the C programs go through the C ABI only"
+
+
 def test_struct_sizes_match_header(lib):
     hdr = '#include "crt_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu\\n", sizeof(crthip_params), sizeof(crthip_state), sizeof(crthip_line));return 0;}\n'
     exe = "/tmp/crthip_sizes"
