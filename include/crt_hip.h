@@ -240,7 +240,11 @@ int  crthip_reserve(crthip_ctx *ctx, int n_fields);
  *              own keep their contents (crt_core.c:431,:608,:662)
  *   d_state  : n crthip_state, updated in place
  * Each field starts from a crt_init-clean analog[] (all zero where crt_modulate does
- * not write, crt_ntsc.c:236-238).  Asynchronous on the context's stream.
+ * not write, crt_ntsc.c:236-238).  Asynchronous on the context's stream: once crthip_reserve
+ * has sized the workspace a call allocates nothing and does not synchronise, so the launch
+ * sequence can be captured into a HIP graph -- AFTER one eager call with the same settings:
+ * the first call builds tables that the context caches (skeleton fields, the NES sample
+ * table), and a capture would record building them without having built them.
  */
 int  crthip_fieldpass(crthip_ctx *ctx, const crthip_params *p, int n,
                       const void *d_images, size_t image_stride,

@@ -88,19 +88,30 @@ k_bloom_scatter(int total, int outw, const crthip_line *__restrict__ lines, cons
     }
 }
 
+/* slots of the sorted order for n fields: every bucket may end in a partial wave */
+static size_t bloom_slots(const crthip_ctx *c, int n) { return (size_t) n * c->sd.lines + 64 * BLOOM_BUCKETS; }
+
+/* The sort's scratch (histogram, cursors, slot -> line) for n fields.  crthip_reserve sizes it with the rest of the workspace,
+ * so that a field-pass allocates nothing (graph capture); a stage-level crthip_decode of more fields than reserved grows it. */
+int crt_reserve_bloom(crthip_ctx *c, int n)
+{
+    const size_t need = sizeof(int) * (bloom_slots(c, n) + 2 * BLOOM_BUCKETS);
+    if (need <= c->bloom_cap) return CRTHIP_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_bloom) hipFree(c->d_bloom);
+    c->d_bloom = 0; c->bloom_cap = 0;
+    if (hipMalloc((void **) &c->d_bloom, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc bloom sort", hipSuccess);
+    c->bloom_cap = need;
+    return CRTHIP_OK;
+}
+
 int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                                const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier)
 {
     const int total = n * c->sd.lines;
-    const size_t slots = (size_t) total + 64 * BLOOM_BUCKETS;           /* every bucket may end in a partial wave */
-    const size_t need = sizeof(int) * (slots + 2 * BLOOM_BUCKETS);
-    if (need > c->bloom_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->d_bloom) hipFree(c->d_bloom);
-        c->d_bloom = 0; c->bloom_cap = 0;
-        if (hipMalloc((void **) &c->d_bloom, need) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc bloom sort", hipSuccess);
-        c->bloom_cap = need;
-    }
+    const size_t slots = bloom_slots(c, n);
+    const int rc_ = crt_reserve_bloom(c, n);
+    if (rc_) return rc_;
     int *hist = c->d_bloom, *cursor = hist + BLOOM_BUCKETS, *perm = cursor + BLOOM_BUCKETS;
     const bool wide = c->px_tile ? c->px_tile >= 32 : p->outw >= 1280;
     const unsigned span = (unsigned) p->outh + p->v_fac;

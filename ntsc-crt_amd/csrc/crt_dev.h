@@ -571,6 +571,7 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
                  crthip_line *d_lines, int advance_rn);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride);
+int crt_reserve_bloom(crthip_ctx *c, int n);
 int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                                const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier);
 int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,

@@ -317,6 +317,10 @@ int crthip_reserve(crthip_ctx *c, int n)
         return set_err(c, CRTHIP_E_NOMEM, "hipMalloc VHS histories", hipSuccess);
     HIPCHK(c, hipMemsetAsync(c->d_inp, 0, bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_analog, 0, bytes, c->stream));
+    if (!c->sd.nes_timing) {                    /* bloom builds (none with the NES timing): the decoder's sort scratch, 4 bytes per scanline */
+        const int rc = crt_reserve_bloom(c, n);
+        if (rc) return rc;
+    }
     c->cap_fields = n;
     return CRTHIP_OK;
 }

@@ -1059,20 +1059,24 @@ def test_full_batch_every_field_checked_against_the_oracle(crtlib):
         assert (int(st[k, crtlib.ST_HSYNC]), int(st[k, crtlib.ST_VSYNC]), int(st[k, crtlib.ST_RN])) == (hs, vs, rn), "field %d state" % k
 
 
-def test_fieldpass_is_graph_capturable(crtlib):
+@pytest.mark.parametrize("name,shape", [("ntsc", 0), ("ntsc", 1), ("ntscbloom", 1)])
+def test_fieldpass_is_graph_capturable(crtlib, name, shape):
     """crthip_fieldpass only enqueues kernels on the context's stream (no allocation, no synchronisation once the
-    workspace is reserved), so a caller can capture the launch sequence into a HIP graph and replay it."""
+    workspace is reserved -- the bloom build's sort scratch included), so a caller can capture the launch sequence into a
+    HIP graph and replay it."""
     import torch
     n, w, h = 6, 640, 480
     imgs = np.stack([R.synth_image(w, h, 4, 40 + k) for k in range(n)])
-    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, name, device=0)
     g.scanlines = 1
+    g.set_shape(shape)
     s = crtlib.Settings(_padded(imgs), format=crtlib.FMT_BGRA, field=[k & 1 for k in range(n)], frame=0)
     p = g.params(s, 24)
     g.reserve(n)
     side = torch.cuda.Stream()
     g.use_stream(side)
-    # eager: two consecutive field-passes (state carries over)
+    # eager: two consecutive field-passes (state carries over); the first one also builds the context's cached tables
+    # (skeleton fields, NES sample table), which is why a capture comes after at least one eager call (include/crt_hip.h)
     g._load_field_state(s)
     torch.cuda.synchronize()
     state0 = g.state.clone()
