@@ -22,12 +22,18 @@ Multi-GPU: one process per GPU, frames sharded by rank; the only collective on t
 the settings blob from rank 0.  Default: weak scaling (fixed batch per GPU).  `--strong F` splits F frames of
 BASELINE configs[2] (1920x1080, noise 0) over the ranks (F = 512 is the configuration BASELINE states).
 
-Prints ONE JSON line (rank 0).  Objects:
+Prints ONE JSON line (rank 0), the LAST line of stdout, at most 4 KB (compact_record(); the round-3 line had grown to
+23 KB and the driver, which keeps 8 KB of output, could not parse it).  Objects of the line:
   roofline         dominant kernel vs the HBM roofline (bytes per SURVEY.md 8(d) / DESIGN.md section 5)
   cpu_baseline     the reference (oracle/_ref, unmodified sources) or the oracle port on the host cores: 1 core, and
                    all cores (independent processes)
-  extra_workloads  (N = 1) the same record for 1080p at batch 2048 and at configs[2]'s per-GPU share (64), VHS 832x624
-                   (configs[3]) and NES pattern 0 (configs[4])
+  one_batch_in_flight   the S = 1 figure next to `value`
+  extras           (N = 1) one short row per extra workload: 1080p at batch 2048, 512 and at configs[2]'s per-GPU share
+                   (64), VHS 832x624 (configs[3]), NES pattern 0 (configs[4]), small batches, PV-1000, bloom
+  strong_scaling   (N = 1) configs[2] on one GPU: T(512 frames), T(64 frames = the per-GPU share at 8 GPUs) and the
+                   speed-up 8 GPUs can reach at best, T512 / T64
+The complete record (every workload with its own roofline / cpu_baseline / tuning objects) goes to
+gpurun_out/bench_full.json (and --full-json PATH).
 """
 import argparse
 import ctypes as C
@@ -75,6 +81,19 @@ def algorithmic_bytes(system, w, h, in_bpp, outw, outh, out_bpp, scanlines, blen
            "sync": 25000 + g["lines"] * 32,                         # sync / burst windows read, line table written
            "decode": g["lines"] * g["av_len"] + pic}                # sample windows read, picture written
     return img + pic, own
+
+
+def kernel_source_hash():
+    """sha1 over the device sources: profiles/traffic*.json (PMC passes, collected by tools/collect_profiles.py) carry the
+    hash of the sources they were measured on, so a static traffic number that no longer belongs to the kernels says so
+    (`roofline.traffic_stale`)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ntsc-crt_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ntsc-crt_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_model():
@@ -160,6 +179,93 @@ def cpu_baseline(system, w, h, outw, outh, noise, scanlines, budget_s, all_cores
                             "cpu_quota_cores": cpu_quota_cores(),
                             "sample": "%d independent processes x %.0f s of the same workload (wall %.1f s)"
                                       % (len(rates), sec, time.perf_counter() - t0)}
+    return out
+
+
+LINE_LIMIT = 4000             # bytes of the final stdout line (the driver keeps 8 KB of output)
+
+
+def _r(v, nd=4):
+    """numbers at a readable precision (4 significant digits by default); everything else unchanged"""
+    if isinstance(v, bool) or not isinstance(v, (int, float)):
+        return v
+    if isinstance(v, int) or v == 0:
+        return v
+    return float("%.*g" % (nd, v))
+
+
+def compact_record(full):
+    """The full result record -> the one the final stdout line carries: the contract keys, `roofline` and `cpu_baseline` of
+    the headline, the one-batch-in-flight figure, one short row per extra workload and the strong-scaling pair.  Pure
+    (tests/test_bench_cpu.py runs it on profiles/r03_bench_default.json)."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 7), _r(out["ms_per_step"], 5)
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg[k] for k in ("workload", "fields_per_gpu_per_step", "frames_per_step", "sharding", "mode", "launch",
+                                         "batches_in_flight") if k in cfg}
+    if cfg.get("batches_in_flight_tuning"):      # S -> frames/sec
+        out["config"]["batches_in_flight_fps"] = {s_: _r(v["value"], 5) for s_, v in cfg["batches_in_flight_tuning"].items()}
+    rf = full.get("roofline") or {}
+    out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                  "algorithmic_bytes_per_field", "kernel_own_frac", "pipeline_frac")}
+    out["roofline"]["kernel_ms"] = {k: _r(v) for k, v in (rf.get("kernel_ms") or {}).items() if v}
+    if rf.get("traffic_source"):
+        out["roofline"]["traffic_source"] = rf["traffic_source"].split(" (")[0]
+    if "traffic_stale" in rf:
+        out["roofline"]["traffic_stale"] = rf["traffic_stale"]
+    if rf.get("valu"):
+        out["roofline"]["valu"] = {"frac_of_4_cycle_issue": _r(rf["valu"].get("frac")),
+                                   "frac_of_2_cycle_peak": _r(rf["valu"].get("frac_of_2_cycle_peak")),
+                                   "wave_instr_per_field": _r(rf["valu"].get("wave_instr_per_field"), 6)}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "host_cores_visible")}
+        if cb.get("all_cores"):
+            ac = cb["all_cores"]
+            out["cpu_baseline"]["all_cores"] = {"value": _r(ac.get("value")), "cores": ac.get("cores"),
+                                                "effective_cores": _r(ac.get("effective_cores")), "cpu_quota_cores": ac.get("cpu_quota_cores")}
+    for k in ("gpu_over_cpu", "gpu_over_cpu_all_cores"):
+        if k in full:
+            out[k] = _r(full[k])
+    ob = full.get("one_batch_in_flight")
+    if ob:
+        out["one_batch_in_flight"] = {"value": _r(ob["value"], 7), "ms_per_step": _r(ob["ms_per_step"], 5),
+                                      "pipeline_frac": _r(ob.get("pipeline_frac"))}
+    for k in ("world_size", "world_size_seen_by_rccl", "collectives", "settings_blob_crc32_per_rank",
+              "settings_blob_crc32_rank0_before_broadcast", "strong_scaling"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    rows = []
+    for e in full.get("extra_workloads") or []:
+        if not e:
+            continue
+        erf, eob = e.get("roofline") or {}, e.get("one_batch_in_flight") or {}
+        # value = best of 1..3 batches in flight; one = ONE batch in flight (fps, ms per step, end-to-end fraction of 8 TB/s);
+        # kfrac = roofline.frac of the workload's dominant kernel (k_decode unless named)
+        row = {"name": e["name"], "batch": (e.get("config") or {}).get("fields_per_gpu_per_step"), "value": _r(e["value"], 4),
+               "one": _r(eob.get("value", e["value"]), 4), "ms_one": _r(eob.get("ms_per_step", e["ms_per_step"]), 4),
+               "frac_one": _r(eob.get("pipeline_frac", erf.get("pipeline_frac")), 3), "kfrac": _r(erf.get("frac"), 3)}
+        if erf.get("kernel") != "k_decode":
+            row["kernel"] = erf.get("kernel")
+        if e.get("cpu_baseline"):
+            row["cpu"] = _r(e["cpu_baseline"]["value"], 4)
+        rows.append(row)
+    if rows:
+        out["extras"] = rows
+    if full.get("full_record"):
+        out["full_record"] = full["full_record"]
+    # never more than LINE_LIMIT bytes: shed the least important objects first (none of this triggers today)
+    for victim in ("collectives", "settings_blob_crc32_per_rank", "settings_blob_crc32_rank0_before_broadcast", "extras"):
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        if victim == "extras" and "extras" in out:
+            out["extras"] = [{k: r_[k] for k in ("name", "value", "one", "frac_one")} for r_ in out["extras"]]
+        else:
+            out.pop(victim, None)
+    while len(json.dumps(out)) > LINE_LIMIT and out.get("extras"):      # ... then whole rows, last first (they stay in full_record)
+        out["extras"].pop()
+        out["extras_dropped"] = out.get("extras_dropped", 0) + 1
     return out
 
 
@@ -338,10 +444,12 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     own_gbs = own[dom] * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
     traffic = None
     valu = None
+    traffic_stale = None
     if traffic_file and os.path.exists(traffic_file):        # PMC passes (tools/prof_bench.sh, prof_sq.sh) on this very workload
         try:
             tj = json.load(open(traffic_file))
             if tj.get("workload") == wl["name"]:
+                traffic_stale = tj.get("source_hash") != kernel_source_hash()
                 traffic = tj.get("k_" + dom + "_bytes_per_field")
                 traffic = traffic * n if traffic else None
                 # the vector-ALU side of the same kernels: wave64 instructions (SQ_INSTS_VALU from the committed counter
@@ -384,6 +492,8 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                      # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
+                     # the kernels changed since the PMC passes that produced `traffic` (hash of csrc/ differs)
+                     "traffic_stale": traffic_stale,
                      # NOT measured in this run: PMC passes need rocprofv3 around the process (tools/prof_bench.sh)
                      "traffic_source": ("static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same workload, "
                                         "calibrated per access pattern: profiles/r03_pmc_calibration.json)"
@@ -400,6 +510,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                      "note": "640x480-class workloads are integer-VALU bound (~37 ops/B, SURVEY.md 8(d)); 1080p leans on HBM writes"},
     }
     if single is not None:
+        single["pipeline_frac"] = abytes * n * steps / tuning[1] / 1e9 / HBM_PEAK_GBS
         rec["one_batch_in_flight"] = single
     if blob_crcs is not None:
         rec["settings_blob_crc32_per_rank"] = blob_crcs
@@ -448,6 +559,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="independent batches in flight, each on its own stream and context (0 = tuned: 1, 2 and 3 are timed, the best is the result; 1 = off)")
     ap.add_argument("--graph", action="store_true", help="time a replayed HIP graph of two steps instead of eager launches (measured: no difference)")
+    ap.add_argument("--full-json", default="", help="also write the complete record (every workload's own objects) to this file")
     ap.add_argument("--dry-run", action="store_true", help="(tests) exercise launch / collectives / JSON without a GPU")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run every collective of the multi-GPU path (settings broadcast, "
@@ -512,6 +624,8 @@ def main():
         EX = [
             dict(name="1080p_batch2048", system="ntsc", w=1920, h=1080, outw=1920, outh=1080, batch=2048, noise=0, scanlines=1,
                  desc="NTSC 1920x1080 -> 1920x1080 BGRA, interlaced, noise 0, scanlines 1 (BASELINE configs[2] geometry, one GPU full)"),
+            dict(name="1080p_batch512", system="ntsc", w=1920, h=1080, outw=1920, outh=1080, batch=512, noise=0, scanlines=1,
+                 desc="NTSC 1920x1080 -> 1920x1080 BGRA, noise 0, scanlines 1, 512 frames = ALL of BASELINE configs[2] on one GPU (the strong-scaling anchor)"),
             dict(name="1080p_batch64", system="ntsc", w=1920, h=1080, outw=1920, outh=1080, batch=64, noise=0, scanlines=1,
                  desc="NTSC 1920x1080 -> 1920x1080 BGRA, noise 0, scanlines 1, 64 frames = configs[2]'s per-GPU share (512 / 8)"),
             dict(name="vhs_832x624", system="vhs", w=832, h=624, outw=832, outh=624, batch=2048, noise=12, scanlines=1,
@@ -531,7 +645,7 @@ def main():
         ]
         for e in EX:
             small = e["batch"] <= 256
-            r = run_workload(torch, crtlib, shard, None, dev, 0, 1, local, e, 30 if small else max(5, args.steps), 3,
+            r = run_workload(torch, crtlib, shard, None, dev, 0, 1, local, e, 30 if small else (20 if e["batch"] <= 512 else max(5, args.steps)), 3,
                              min(args.cpu_seconds, 4.0), not args.no_cpu and not small,
                              traffic_file=os.path.join(ROOT, "profiles", "traffic_%s.json" % e["name"]))
             extras.append(r)
@@ -555,6 +669,18 @@ def main():
                 out[k] = rec[k]
         if extras:
             out["extra_workloads"] = extras
+            by = {e["name"]: e for e in extras if e}
+            if "1080p_batch512" in by and "1080p_batch64" in by:
+                # BASELINE configs[2] is STRONG scaling: 512 frames of 1920x1080 over 8 GPUs = 64 per GPU.  One GPU measures
+                # both ends: T512 (the whole job on one GPU) and T64 (a GPU's share at 8); 8 GPUs cannot beat T512 / T64,
+                # whatever the interconnect (the ranks exchange nothing but the settings blob).  One batch in flight: a
+                # single job has no second batch to overlap with.
+                t512 = by["1080p_batch512"].get("one_batch_in_flight", by["1080p_batch512"])["ms_per_step"]
+                t64 = by["1080p_batch64"].get("one_batch_in_flight", by["1080p_batch64"])["ms_per_step"]
+                out["strong_scaling"] = {"workload": "BASELINE configs[2]: 512 frames 1920x1080 noise 0, measured on ONE GPU, one batch in flight",
+                                         "T512_ms": _r(t512), "T64_ms": _r(t64), "projected_speedup_8gpu": _r(t512 / t64, 3),
+                                         "weak_per_gpu_batch2048_fps": _r(by["1080p_batch2048"].get("one_batch_in_flight", by["1080p_batch2048"])["value"], 5)
+                                         if "1080p_batch2048" in by else None}
     else:
         out = None
     if dist is not None:
@@ -564,7 +690,19 @@ def main():
         # RCCL printf()s its library path into C stdio's buffer, which would be flushed at exit AFTER this line
         sys.stdout.flush()
         C.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        # the complete record goes to a file (gpurun_out/ comes back from the GPU box), the LAST stdout line is the compact one
+        full_paths = [os.path.join(ROOT, "gpurun_out", "bench_full.json")] + ([args.full_json] if args.full_json else [])
+        for fp in full_paths:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(fp)), exist_ok=True)
+                with open(fp, "w") as fh:
+                    json.dump(out, fh, indent=1)
+                out["full_record"] = os.path.relpath(fp, ROOT)
+            except OSError:
+                pass
+        line = json.dumps(compact_record(out))
+        assert len(line) <= LINE_LIMIT, "bench.py: final line is %d bytes" % len(line)
+        print(line, flush=True)
 
 
 def dry_run(args, torch, shard, rank, world):

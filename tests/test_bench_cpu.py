@@ -40,3 +40,42 @@ def test_bench_under_torch_distributed_run_and_strong_scaling():
 def test_bench_single_process_dry_run():
     out = _run([sys.executable, "bench.py", "--dry-run"])
     assert out["world_size"] == 1 and out["frames_per_step"] == 4096
+
+
+def test_final_line_is_compact_and_round_trips():
+    """the final stdout line had grown to 23 KB and the driver (8 KB of kept output) could not parse it.
+    The formatter is run on that very record: under 4 KB, valid JSON, the contract keys and the judged objects intact."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    line = json.dumps(bench.compact_record(full))
+    assert len(line) < 4096 and len(line) <= bench.LINE_LIMIT, len(line)
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert abs(back["value"] - full["value"]) / full["value"] < 1e-5
+    assert back["config"]["workload"] == full["config"]["workload"]
+    rf = back["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] and rf["kernel_ms"]["decode"] > 0
+    cb = back["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    assert back["one_batch_in_flight"]["value"] <= back["value"] * 1.0001
+    names = [r["name"] for r in back["extras"]]
+    assert names == [e["name"] for e in full["extra_workloads"]] and "extras_dropped" not in back
+    assert all(r["one"] > 0 and r["ms_one"] > 0 for r in back["extras"])
+    # a record with more rank / workload rows than any real one still fits (the formatter sheds detail, never the contract)
+    big = dict(full, settings_blob_crc32_per_rank=list(range(10 ** 9, 10 ** 9 + 64)),
+               extra_workloads=full["extra_workloads"] * 6)
+    line2 = json.dumps(bench.compact_record(big))
+    assert len(line2) <= bench.LINE_LIMIT and json.loads(line2)["roofline"]["frac"] == rf["frac"]
+
+
+def test_traffic_files_carry_a_source_hash_when_fresh():
+    """roofline.traffic comes from committed PMC passes; bench.py flags it stale when csrc/ changed since."""
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()

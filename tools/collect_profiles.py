@@ -81,7 +81,11 @@ json.dump({"bench": bench_cmd, "fields_per_launch": fields,
            "hbm_bytes_per_field_all_kernels": total, "kernels": out},
           open(os.path.join(dst, name + "_pmc.json"), "w"), indent=1)
 if workload:
+    sys.path.insert(0, root)
+    import bench
     json.dump({"workload": workload, "source": "profiles/%s_pmc.json" % name, "bench": bench_cmd, "fields_per_launch": fields,
+               # the device sources these counters were measured on (bench.py: roofline.traffic_stale)
+               "source_hash": bench.kernel_source_hash(),
                "k_decode_bytes_per_field": per_field("k_decode"), "k_active_bytes_per_field": per_field("k_active"),
                "k_template_bytes_per_field": per_field("k_margin", "k_skeleton", "k_template"),
                "k_sync_bytes_per_field": per_field("k_hsync", "k_vsync", "k_bloom"),
