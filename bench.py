@@ -275,6 +275,105 @@ WORKLOAD_NOTES = {
 }
 
 
+class Batches:
+    """The batches in flight of one workload on this rank's GPU: S independent contexts (each its own n television sets: state,
+    signal and picture buffers) with their streams, the synthetic input they share, the settings blob (built on rank 0,
+    broadcast over RCCL), and the step loop.  Step k of a run with `inflight` batches in flight runs on context k % inflight,
+    as that context's (k // inflight)-th step.  (tests/test_gpu_bench.py drives this very loop with S = 3 and S = 1 and
+    compares every output byte.)"""
+
+    def __init__(self, torch, crtlib, shard, dist, dev, rank, world, local, wl, S):
+        self.torch, self.crtlib, self.shard, self.dist, self.dev, self.rank, self.world, self.wl = torch, crtlib, shard, dist, dev, rank, world, wl
+        system, w, h, outw, outh = wl["system"], wl["w"], wl["h"], wl["outw"], wl["outh"]
+        n, noise, scanlines, fir = wl["batch"], wl["noise"], wl["scanlines"], wl.get("fir", 0)
+        self.n, self.noise = n, noise
+        self.nes = nes = system in ("nes", "nesp0")
+        self.crts, self.streams = [], []
+        for _ in range(S):
+            c_ = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, system, device=local)
+            c_.scanlines = scanlines
+            c_.eq_fir = fir
+            c_.reserve(n)
+            c_.set_overlap(wl.get("overlap", 0))
+            c_.set_pixel_tile(wl.get("pixel_tile", 0))
+            c_.set_shape(wl.get("shape", 0))
+            self.crts.append(c_)
+            self.streams.append(torch.cuda.Stream(device=dev) if S > 1 else None)
+            if S > 1:
+                c_.use_stream(self.streams[-1])
+        crt = self.crts[0]
+        # synthetic input, generated on the device: uniform random bytes per frame (SURVEY 8(d) config 2); at most
+        # `unique` distinct frames, tiled to the batch: the kernels' work is data-independent
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(12345 + rank)
+        uniq = min(n, wl.get("unique", 64))
+        first = wl.get("first_frame", rank * n)                    # this rank's contiguous block of the global batch
+        if nes:
+            self.base = torch.randint(0, 512, (uniq, h + 1, w), dtype=torch.int16, device=dev, generator=gen)
+            self.images = self.base.repeat((n + uniq - 1) // uniq, 1, 1)[:n][:, :h]
+            self.s = crtlib.Settings(self.images, hue=0, dot_crawl_offset=[(first + k) % 3 for k in range(n)])
+        else:
+            self.base = torch.randint(0, 256, (uniq, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
+            self.images = self.base.repeat((n + uniq - 1) // uniq, 1, 1, 1)[:n][:, :h]
+            parity = [shard.field_parity(first + k) for k in range(n)]
+            self.s = crtlib.Settings(self.images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
+                                     field=[a for a, _ in parity], frame=[b for _, b in parity])
+        if system.startswith("vhs"):
+            for c_ in self.crts:
+                c_.srand([1 + first + k for k in range(n)])
+        # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
+        self.p = crt.params(self.s, noise)
+        self.blob_crcs = None
+        self.crc_root = zlib.crc32(bytes(self.p))                    # rank 0's blob as built on the host, before any collective
+        if dist is not None:
+            shard.broadcast_params(self.p, dist, dev)
+            crc = torch.tensor([zlib.crc32(bytes(self.p))], dtype=torch.int64, device=dev)
+            allc = [torch.zeros_like(crc) for _ in range(world)]
+            dist.all_gather(allc, crc)
+            self.blob_crcs = [int(c.item()) for c in allc]
+        for c_ in self.crts:
+            c_._load_field_state(self.s)
+        self.seq_rounds = []
+
+    def step(self, k, inflight=1):
+        """step k of a run with `inflight` batches in flight: on context k % inflight"""
+        ci = k % inflight
+        crt = self.crts[ci]
+        if self.streams[ci] is not None:
+            with self.torch.cuda.stream(self.streams[ci]):
+                self.one_step(crt, k // inflight)
+        else:
+            self.one_step(crt, k)
+
+    def one_step(self, crt, k):
+        wl, dist, crtlib, shard = self.wl, self.dist, self.crtlib, self.shard
+        if wl.get("sequence"):
+            if dist is None:
+                crt.sequence(self.s, self.noise)
+            else:
+                # ONE video of world * n fields cut over the ranks (SURVEY.md 8(e), last row): sync state by all_gather,
+                # the picture handed from rank to rank (shard.sequence_sharded)
+                self.seq_rounds.append(shard.sequence_sharded(shard.CrtSequenceEngine(crt, self.s, self.noise), dist, self.rank, self.world,
+                                                              self.world * self.n, 0, 0, 194, None, 0, self.dev, (wl["outh"], wl["outw"], 4)))
+            return
+        crt.fieldpass(self.s, self.noise, params=self.p)
+        if not self.nes:        # next field of the interlaced sequence (video_convert.c:261-267)
+            crt.state[:, crtlib.ST_FIELD] ^= 1
+            if k % 2 == 0:
+                crt.state[:, crtlib.ST_FRAME] ^= 1
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.dev)
+
+    def close(self):
+        for c_ in self.crts:
+            c_.close()
+        self.crts, self.images, self.base, self.s = [], None, None, None
+
+
 def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps, warmup, cpu_seconds, with_cpu, traffic_file=None):
     """One workload on this rank's GPU; returns the result record (rank 0) or None."""
     system, w, h, outw, outh = wl["system"], wl["w"], wl["h"], wl["outw"], wl["outh"]
@@ -291,87 +390,9 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     if wl.get("sequence") or wl.get("graph"):
         cands = [1]
     S = max(cands)
-    crts, streams = [], []
-    for _ in range(S):
-        c_ = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, system, device=local)
-        c_.scanlines = scanlines
-        c_.eq_fir = fir
-        c_.reserve(n)
-        c_.set_overlap(wl.get("overlap", 0))
-        c_.set_pixel_tile(wl.get("pixel_tile", 0))
-        c_.set_shape(wl.get("shape", 0))
-        crts.append(c_)
-        streams.append(torch.cuda.Stream(device=dev) if S > 1 else None)
-        if S > 1:
-            c_.use_stream(streams[-1])
-    crt = crts[0]
-
-    # synthetic input, generated on the device: uniform random bytes per frame; at most
-    # `unique` distinct frames, tiled to the batch: the kernels' work is data-independent
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(12345 + rank)
-    uniq = min(n, wl.get("unique", 64))
-    first = wl.get("first_frame", rank * n)                    # this rank's contiguous block of the global batch
-    if nes:
-        base = torch.randint(0, 512, (uniq, h + 1, w), dtype=torch.int16, device=dev, generator=gen)
-        images = base.repeat((n + uniq - 1) // uniq, 1, 1)[:n][:, :h]
-        s = crtlib.Settings(images, hue=0, dot_crawl_offset=[(first + k) % 3 for k in range(n)])
-    else:
-        base = torch.randint(0, 256, (uniq, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
-        images = base.repeat((n + uniq - 1) // uniq, 1, 1, 1)[:n][:, :h]
-        parity = [shard.field_parity(first + k) for k in range(n)]
-        s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0,
-                            field=[a for a, _ in parity], frame=[b for _, b in parity])
-    if system.startswith("vhs"):
-        for c_ in crts:
-            c_.srand([1 + first + k for k in range(n)])
-
-    # settings blob: built on rank 0, broadcast over RCCL/xGMI (the path's only collective)
-    p = crt.params(s, noise)
-    blob_crcs = None
-    crc_root = zlib.crc32(bytes(p))                              # rank 0's blob as built on the host, before any collective
-    if dist is not None:
-        shard.broadcast_params(p, dist, dev)
-        crc = torch.tensor([zlib.crc32(bytes(p))], dtype=torch.int64, device=dev)
-        allc = [torch.zeros_like(crc) for _ in range(world)]
-        dist.all_gather(allc, crc)
-        blob_crcs = [int(c.item()) for c in allc]
-    for c_ in crts:
-        c_._load_field_state(s)
-
-    seq_rounds = []
-
-    def step(k, inflight=1):
-        """step k of a run with `inflight` batches in flight: on context k % inflight"""
-        ci = k % inflight
-        crt = crts[ci]
-        if streams[ci] is not None:
-            with torch.cuda.stream(streams[ci]):
-                one_step(crt, k // inflight)
-        else:
-            one_step(crt, k)
-
-    def one_step(crt, k):
-        if wl.get("sequence"):
-            if dist is None:
-                crt.sequence(s, noise)
-            else:
-                # ONE video of world * n fields cut over the ranks (SURVEY.md 8(e), last row): sync state by all_gather,
-                # the picture handed from rank to rank (shard.sequence_sharded)
-                seq_rounds.append(shard.sequence_sharded(shard.CrtSequenceEngine(crt, s, noise), dist, rank, world, world * n,
-                                                         0, 0, 194, None, 0, dev, (outh, outw, 4)))
-            return
-        crt.fieldpass(s, noise, params=p)
-        if not nes:        # next field of the interlaced sequence (video_convert.c:261-267)
-            crt.state[:, crtlib.ST_FIELD] ^= 1
-            if k % 2 == 0:
-                crt.state[:, crtlib.ST_FRAME] ^= 1
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    B = Batches(torch, crtlib, shard, dist, dev, rank, world, local, wl, S)
+    crts, crt, s, p, step, barrier = B.crts, B.crts[0], B.s, B.p, B.step, B.barrier
+    blob_crcs, crc_root, seq_rounds = B.blob_crcs, B.crc_root, B.seq_rounds
 
     torch.cuda.synchronize(dev)              # (the inputs were made on the default stream)
     for k in range(warmup * S):
@@ -430,9 +451,8 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     crt.profile(False)
     kern_ms = {k: (v[0] / max(min(steps, 5), 1)) for k, v in prof.items()}     # ms per step (a step may launch a kernel twice)
     dom = max(kern_ms, key=lambda k: kern_ms[k])
-    for c_ in crts:
-        c_.close()
-    del crt, crts, images, base, s
+    B.close()
+    del crt, crts, s, B
     torch.cuda.empty_cache()
     if rank != 0:
         return None

@@ -242,9 +242,11 @@ int  crthip_reserve(crthip_ctx *ctx, int n_fields);
  * Each field starts from a crt_init-clean analog[] (all zero where crt_modulate does
  * not write, crt_ntsc.c:236-238).  Asynchronous on the context's stream: once crthip_reserve
  * has sized the workspace a call allocates nothing and does not synchronise, so the launch
- * sequence can be captured into a HIP graph -- AFTER one eager call with the same settings:
- * the first call builds tables that the context caches (skeleton fields, the NES sample
- * table), and a capture would record building them without having built them.
+ * sequence can be captured into a HIP graph -- the first call of a context included: the
+ * tables the context caches (skeleton fields, the NES sample table) are then built at once
+ * on a stream of the library's own, outside the capture, and the graph holds only the
+ * per-call kernels.  (A graph reads the tables of the settings it was captured with: do not
+ * replay it after calls with other settings went through the same context.)
  */
 int  crthip_fieldpass(crthip_ctx *ctx, const crthip_params *p, int n,
                       const void *d_images, size_t image_stride,

@@ -76,6 +76,7 @@ struct slot {
     size_t img_cap, out_cap;
     /* lazy mirror: what the host copies looked like when this layer last read or wrote them */
     int analog_valid, out_valid, img_valid;
+    unsigned long last_use;               /* g_tick of the slot's last call: the least recently used slot is the one recycled */
     int analog_dev_newer;                 /* lazy: the device copy holds a crt_modulate result the host copy does not */
     signed char *analog_shadow;           /* lazy: crt.analog[] as this layer last saw / left it on the host */
     unsigned long out_hash, img_hash;
@@ -84,6 +85,7 @@ struct slot {
 };
 
 static crthip_ctx *g_ctx;
+static unsigned long g_tick;
 static int g_lazy = -1;             /* CRTHIP_LAZY_MIRROR: 0 strict (default), 1 sampled hashes, 2 full hashes */
 
 static int
@@ -213,6 +215,7 @@ get_slot(struct CRT *v)
     }
     for (i = 0; i < MAX_SLOTS; i++) {
         if (g_slots[i].host == v) {
+            g_slots[i].last_use = ++g_tick;
             return &g_slots[i];
         }
         if (g_slots[i].host == 0 && free_slot == 0) {
@@ -221,10 +224,20 @@ get_slot(struct CRT *v)
     }
     if (free_slot == 0) {
         /* recycle slot 0: its buffers stay allocated and are simply re-filled on the next call */
+        /* recycle the least recently used slot.  Lazy mirror: if the evicted set's last crt_modulate result exists on the
+         * device only, it is lost here -- the set's struct may be long gone (a stack object), so nothing is written back
+         * to it; should the set call again, the intact marker in its analog[] without a slot is caught in
+         * sync_analog_to_device */
         free_slot = &g_slots[0];
+        for (i = 1; i < MAX_SLOTS; i++) {
+            if (g_slots[i].last_use < free_slot->last_use) {
+                free_slot = &g_slots[i];
+            }
+        }
         unpin_slot(free_slot, 1);
     }
     free_slot->host = v;
+    free_slot->last_use = ++g_tick;
     free_slot->analog_valid = free_slot->out_valid = free_slot->img_valid = 0;
     free_slot->analog_dev_newer = 0;
     if (free_slot->d_analog == 0) {
@@ -421,6 +434,12 @@ sync_analog_to_device(struct slot *sl, const struct CRT *v)
     }
     if (sl->analog_valid && memcmp(v->analog, sl->analog_shadow, CRT_INPUT_SIZE) == 0) {
         return;                                     /* untouched since this layer last saw it */
+    }
+    if (!sl->analog_valid && memcmp(v->analog, LAZY_MARK, sizeof(LAZY_MARK)) == 0) {
+        /* the marker of a lazy crt_modulate, but no device copy behind it: this set's slot was recycled (more than
+         * MAX_SLOTS sets alive in lazy mode) and its last field went with it.  Uploading the stale host copy, marker
+         * bytes included, would silently decode the wrong signal: refuse loudly. */
+        fatal("lazy mirror: this struct CRT lost its device copy (more than 32 sets in use); run with CRTHIP_LAZY_MIRROR=0", CRTHIP_E_ARG);
     }
     if (sl->analog_valid && sl->analog_dev_newer && memcmp(v->analog, LAZY_MARK, sizeof(LAZY_MARK)) == 0) {
         /* marker intact: sparse edits on top of a stale host copy -> patch exactly the changed bytes into the device copy */

@@ -427,6 +427,8 @@ struct crthip_ctx {
     bool nes_tab_valid;
     int nes_tab_black, nes_tab_white;
     signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields (cached: the burst table they were built from) */
+    signed char *d_skel_alt, *d_nes_tab_alt;   /* second set: where the tables are built when the context's stream is being captured */
+    hipStream_t table_stream;   /* ... and the (never captured) stream they are built on then; created on first use */
     bool skel_valid;
     int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
     int skel_border[4];         /* ... NES_BORDER: flag, colour, black point, white point */

@@ -1037,7 +1037,14 @@ __global__ void k_encoder_state(const crthip_params P, int n_fields, crthip_stat
 
 /* Encoder tables that depend on the parameter blob only (clean skeleton variants, NES sample table): (re)built on
  * the context's CURRENT stream when the inputs they derive from changed.  crthip_fieldpass calls this before it
- * forks onto its second stream, so the chunks only ever read the tables. */
+ * forks onto its second stream, so the chunks only ever read the tables.
+ *
+ * Under stream capture (a caller recording the FIRST field-pass of a context, or the first one with new settings, into a
+ * HIP graph) a launch on the capturing stream would only be recorded: the tables would not exist when the capture ends,
+ * the cache would call them valid, and every replay would rebuild them.  So under capture the tables are built FOR REAL,
+ * now, on a private stream that is not being captured (the thread's capture mode relaxed for the duration, as allocators
+ * do), into the context's second set of buffers -- kernels enqueued before the capture began may still be reading the
+ * first -- and the sets are swapped.  The graph then holds only the per-call kernels, reading tables that exist. */
 int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
@@ -1047,23 +1054,59 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
         const int border_key[4] = { p->flags & CRTHIP_F_NES_BORDER, p->nes_border_color, p->black_point, p->white_point };
         const bool border_same = !(p->flags & CRTHIP_F_NES_BORDER) ? c->skel_border[0] == 0
                                                                     : memcmp(c->skel_border, border_key, sizeof(border_key)) == 0;
-        if (fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0 || c->skel_yo != p->yo || !border_same)) {
+        const bool need_skel = fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0 || c->skel_yo != p->yo || !border_same);
+        bool need_nes = false;
+        if constexpr (S::IS_NES) need_nes = !c->nes_tab_valid || c->nes_tab_black != p->black_point || c->nes_tab_white != p->white_point;
+        if (!need_skel && !need_nes) return CRTHIP_OK;
+
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { (void) hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        const bool capturing = cap == hipStreamCaptureStatusActive;
+        hipStream_t st = c->stream;
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        if (capturing) {
+            if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return set_err(c, CRTHIP_E_HIP, "hipThreadExchangeStreamCaptureMode", hipGetLastError());
+            if (!c->table_stream && hipStreamCreateWithFlags(&c->table_stream, hipStreamNonBlocking) != hipSuccess) {
+                c->table_stream = nullptr;
+                (void) hipThreadExchangeStreamCaptureMode(&mode);
+                return set_err(c, CRTHIP_E_HIP, "stream for table builds under capture", hipGetLastError());
+            }
+            st = c->table_stream;
+        }
+        if (need_skel) {
             constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
-            ProfScope ps(c, CRTHIP_K_TEMPLATE);
-            hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, c->stream, *p, c->d_skel, c->fstride);
+            signed char *dst = capturing ? c->d_skel_alt : c->d_skel;
+            if (!capturing) {
+                ProfScope ps(c, CRTHIP_K_TEMPLATE);
+                hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, st, *p, dst, c->fstride);
+            } else {
+                hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, st, *p, dst, c->fstride);
+            }
             memcpy(c->skel_burst, p->burst, sizeof(p->burst));
             c->skel_yo = p->yo;
             memcpy(c->skel_border, border_key, sizeof(border_key));
             c->skel_valid = true;
         }
         if constexpr (S::IS_NES) {
-            if (!c->nes_tab_valid || c->nes_tab_black != p->black_point || c->nes_tab_white != p->white_point) {
-                ProfScope ps(c, CRTHIP_K_ACTIVE);
-                hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, c->stream, *p, c->d_nes_tab);
+            if (need_nes) {
+                signed char *dst = capturing ? c->d_nes_tab_alt : c->d_nes_tab;
+                if (!capturing) {
+                    ProfScope ps(c, CRTHIP_K_ACTIVE);
+                    hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, st, *p, dst);
+                } else {
+                    hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, st, *p, dst);
+                }
                 c->nes_tab_black = p->black_point;
                 c->nes_tab_white = p->white_point;
                 c->nes_tab_valid = true;
             }
+        }
+        if (capturing) {
+            const hipError_t e = hipStreamSynchronize(st);
+            (void) hipThreadExchangeStreamCaptureMode(&mode);
+            if (e != hipSuccess) { c->skel_valid = false; c->nes_tab_valid = false; return set_err(c, CRTHIP_E_HIP, "table build under capture", e); }
+            if (need_skel) { signed char *t = c->d_skel; c->d_skel = c->d_skel_alt; c->d_skel_alt = t; }
+            if (need_nes) { signed char *t = c->d_nes_tab; c->d_nes_tab = c->d_nes_tab_alt; c->d_nes_tab_alt = t; }
         }
         return CRTHIP_OK;
     });

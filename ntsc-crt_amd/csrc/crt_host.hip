@@ -207,7 +207,8 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         return CRTHIP_E_HIP;
     }
     free(h);
-    if (system == CRTHIP_SYSTEM_NES && hipMalloc((void **) &c->d_nes_tab, NES_TAB_SIZE) != hipSuccess) {
+    if (system == CRTHIP_SYSTEM_NES && (hipMalloc((void **) &c->d_nes_tab, NES_TAB_SIZE) != hipSuccess ||
+                                        hipMalloc((void **) &c->d_nes_tab_alt, NES_TAB_SIZE) != hipSuccess)) {
         crthip_destroy(c);
         return CRTHIP_E_NOMEM;
     }
@@ -216,6 +217,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
         j1[0] = make_uint2(1u, 0u);
         for (int k = 1; k < 16; k++) j1[k] = make_uint2(LCG_MUL * j1[k - 1].x, LCG_MUL * j1[k - 1].y + LCG_ADD);
         if (hipMalloc((void **) &c->d_skel, (size_t) SKEL_VARIANTS * c->fstride) != hipSuccess ||
+            hipMalloc((void **) &c->d_skel_alt, (size_t) SKEL_VARIANTS * c->fstride) != hipSuccess ||
             hipMalloc((void **) &c->d_jump1, sizeof(j1)) != hipSuccess ||
             hipMemcpy(c->d_jump1, j1, sizeof(j1), hipMemcpyHostToDevice) != hipSuccess) {
             crthip_destroy(c);
@@ -268,8 +270,11 @@ void crthip_destroy(crthip_ctx *c)
     if (c->d_vhs_next) hipFree(c->d_vhs_next);
     if (c->d_seq) hipFree(c->d_seq);
     if (c->d_bloom) hipFree(c->d_bloom);
+    if (c->table_stream) { hipStreamSynchronize(c->table_stream); hipStreamDestroy(c->table_stream); }
     if (c->d_nes_tab) hipFree(c->d_nes_tab);
+    if (c->d_nes_tab_alt) hipFree(c->d_nes_tab_alt);
     if (c->d_skel) hipFree(c->d_skel);
+    if (c->d_skel_alt) hipFree(c->d_skel_alt);
     if (c->d_jump1) hipFree(c->d_jump1);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
@@ -672,7 +677,9 @@ int crthip_seq_sync(crthip_ctx *c, const crthip_params *p, int n, crthip_state *
         int flag = 0;
         HIPCHK(c, hipMemcpyAsync(&flag, sc.changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!flag || passes > n + 1) break;
+        if (!flag) break;
+        if (passes > n + 1)               /* after pass k fields 0 .. k-1 are final: cannot happen (say so instead of returning a half-converged chain) */
+            return set_err(c, CRTHIP_E_HIP, "crthip_seq_sync: the sync chain over the fields did not converge", hipSuccess);
     }
     if (passes_out) *passes_out = passes;
     if (hsync_out || vsync_out) {

@@ -216,6 +216,40 @@ static int hand_over_picture(crthip_node *nd, int a, const void *src, int b, voi
     return CRTHIP_OK;
 }
 
+/* Everything crthip_node_sequence holds beyond its arguments, released on EVERY way out (the early returns of
+ * the NODE_* macros used to skip the reset of the shards' vhs_prechained flag -- a context left prechained silently skips
+ * the rand() chain of any later sequence -- and leaked the scratch buffers).  The destructor first waits for all shard
+ * streams: nothing that still reads the buffers may be in flight when they are freed. */
+struct SeqGuard {
+    crthip_node *nd;
+    bool prechained = false;            /* some shard was switched to "histories already chained" */
+    unsigned *hist_all = nullptr;       /* on device[0] */
+    crthip_state *st_all = nullptr;     /* on device[0] */
+    std::vector<void *> init;           /* per shard: the predecessor's last picture */
+    explicit SeqGuard(crthip_node *n) : nd(n), init((size_t) n->n_shards, nullptr) {}
+    void free_chain_scratch()
+    {
+        if (!hist_all && !st_all) return;
+        (void) hipSetDevice(nd->device[0]);
+        (void) hipStreamSynchronize(nd->stream[0]);
+        if (hist_all) (void) hipFree(hist_all);
+        if (st_all) (void) hipFree(st_all);
+        hist_all = nullptr; st_all = nullptr;
+    }
+    ~SeqGuard()
+    {
+        for (int s = 0; s < nd->n_shards; s++) {
+            (void) hipSetDevice(nd->device[s]);
+            (void) hipStreamSynchronize(nd->stream[s]);
+        }
+        free_chain_scratch();
+        for (int s = 0; s < nd->n_shards; s++) {
+            if (init[s]) { (void) hipSetDevice(nd->device[s]); (void) hipFree(init[s]); }
+            if (prechained && nd->system == CRTHIP_SYSTEM_NTSCVHS) (void) crthip_seq_vhs_prechained(nd->ctx[s], 0);
+        }
+    }
+};
+
 int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, const void *const *d_images, size_t istride,
                          void *const *d_out, size_t ostride, const void *d_out_init, crthip_state *const *d_state, int *rounds_out)
 {
@@ -231,6 +265,7 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
         crthip_node_shard_range(nd, n_total, s, &first[s], &cnt[s]);
         if (cnt[s] > 0) last_shard = s;
     }
+    SeqGuard g(nd);                     /* from here on every return releases what the call holds */
     /* the set's state before field 0 */
     crthip_state st0;
     NODE_HIP(nd, hipSetDevice(nd->device[0]));
@@ -243,29 +278,34 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
         for (int s = 0; s < S; s++)
             if (cnt[s] > 0 && !nd->vhs_hist[s]) return node_err(nd, CRTHIP_E_ARG, "crthip_node_sequence", "VHS: bind every shard's histories (crthip_node_vhs_bind_history)");
         const bool draw = (p->flags & CRTHIP_F_VHS_DRAW_ABERRATION) != 0;
-        unsigned *hist_all = nullptr;
-        crthip_state *st_all = nullptr;
         NODE_HIP(nd, hipSetDevice(nd->device[0]));
-        NODE_HIP(nd, hipMalloc((void **) &hist_all, sizeof(unsigned) * 32 * (size_t) n_total));
-        NODE_HIP(nd, hipMalloc((void **) &st_all, sizeof(crthip_state) * (size_t) n_total));
-        NODE_HIP(nd, hipMemsetAsync(st_all, 0, sizeof(crthip_state) * (size_t) n_total, nd->stream[0]));
-        NODE_HIP(nd, hipMemcpyAsync(hist_all, nd->vhs_hist[0], sizeof(unsigned) * 32, hipMemcpyDeviceToDevice, nd->stream[0]));
-        NODE_CRT(nd, 0, crthip_vhs_bind_history(nd->ctx[0], hist_all));
-        rc = crthip_vhs_chain(nd->ctx[0], n_total, st_all, draw);
+        NODE_HIP(nd, hipMalloc((void **) &g.hist_all, sizeof(unsigned) * 32 * (size_t) n_total));
+        NODE_HIP(nd, hipMalloc((void **) &g.st_all, sizeof(crthip_state) * (size_t) n_total));
+        NODE_HIP(nd, hipMemsetAsync(g.st_all, 0, sizeof(crthip_state) * (size_t) n_total, nd->stream[0]));
+        NODE_HIP(nd, hipMemcpyAsync(g.hist_all, nd->vhs_hist[0], sizeof(unsigned) * 32, hipMemcpyDeviceToDevice, nd->stream[0]));
+        NODE_CRT(nd, 0, crthip_vhs_bind_history(nd->ctx[0], g.hist_all));
+        rc = crthip_vhs_chain(nd->ctx[0], n_total, g.st_all, draw);
         crthip_vhs_bind_history(nd->ctx[0], nd->vhs_hist[0]);
-        if (rc) { hipFree(hist_all); hipFree(st_all); return node_err(nd, rc, "crthip_vhs_chain", crthip_error_string(nd->ctx[0])); }
-        NODE_HIP(nd, hipStreamSynchronize(nd->stream[0]));
+        if (rc) return node_err(nd, rc, "crthip_vhs_chain", crthip_error_string(nd->ctx[0]));
+        NODE_HIP(nd, hipStreamSynchronize(nd->stream[0]));          /* the chain is complete: the scatter below reads it */
         for (int s = 0; s < S; s++) {
             if (cnt[s] <= 0) continue;
-            /* (hipMemcpy between devices: peer copy or staged through the host, the runtime's choice) */
-            NODE_HIP(nd, hipMemcpy(nd->vhs_hist[s], hist_all + 32 * (size_t) first[s], sizeof(unsigned) * 32 * (size_t) cnt[s], hipMemcpyDefault));
+            /* Scatter on the RECEIVING shard's stream (the shard streams are non-blocking: a copy on the null stream would
+             * not be ordered against them), so the shard's encoder, enqueued behind it, sees the histories.  Between devices:
+             * peer copy or staged through the host, the runtime's choice. */
+            NODE_HIP(nd, hipSetDevice(nd->device[s]));
+            NODE_HIP(nd, hipMemcpyAsync(nd->vhs_hist[s], g.hist_all + 32 * (size_t) first[s], sizeof(unsigned) * 32 * (size_t) cnt[s],
+                                        hipMemcpyDefault, nd->stream[s]));
             if (draw)
-                NODE_HIP(nd, hipMemcpy2D(&d_state[s][0].aux, sizeof(crthip_state), &st_all[first[s]].aux, sizeof(crthip_state),
-                                         sizeof(int), (size_t) cnt[s], hipMemcpyDefault));
+                NODE_HIP(nd, hipMemcpy2DAsync(&d_state[s][0].aux, sizeof(crthip_state), &g.st_all[first[s]].aux, sizeof(crthip_state),
+                                              sizeof(int), (size_t) cnt[s], hipMemcpyDefault, nd->stream[s]));
+            g.prechained = true;
             NODE_CRT(nd, s, crthip_seq_vhs_prechained(nd->ctx[s], 1));
         }
-        NODE_HIP(nd, hipSetDevice(nd->device[0]));
-        hipFree(hist_all); hipFree(st_all);
+        /* the scratch is read by those copies: wait for every receiving stream before it goes */
+        for (int s = 0; s < S; s++)
+            if (cnt[s] > 0) { NODE_HIP(nd, hipSetDevice(nd->device[s])); NODE_HIP(nd, hipStreamSynchronize(nd->stream[s])); }
+        g.free_chain_scratch();
     }
 
     /* phase 1 + the first sync round: every shard on its own host thread (crthip_seq_sync reads its flag back, i.e.
@@ -295,7 +335,9 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
                 dirty[s] = 1; any = true;
             }
         }
-        if (!any || rounds > S + 1) break;
+        if (!any) break;
+        if (rounds > S + 1)             /* after round k shards 0 .. k-1 are final: more than S + 1 rounds cannot happen */
+            return node_err(nd, CRTHIP_E_HIP, "crthip_node_sequence", "the sync state over the shards did not converge");
     }
     if (rounds_out) *rounds_out = rounds;
 
@@ -305,41 +347,30 @@ int crthip_node_sequence(crthip_node *nd, const crthip_params *p, int n_total, c
 
     /* the output picture across the seams */
     const size_t pic = (size_t) blob[0].outw * blob[0].outh * blob[0].out_bpp;
-    std::vector<void *> init(S, nullptr);
-    auto free_inits = [&]() { for (int s = 0; s < S; s++) if (init[s]) { hipSetDevice(nd->device[s]); hipFree(init[s]); init[s] = nullptr; } };
+    std::vector<void *> &init = g.init;
     auto last_picture = [&](int s) { return (const unsigned char *) d_out[s] + (size_t) (cnt[s] - 1) * ostride; };
-    rc = CRTHIP_OK;
     if (!blob[0].blend) {
         /* every shard weaves with a placeholder (zeros) at once; then, down the chain, only the rows nobody in the shard
          * wrote are patched from the predecessor's last picture */
-        for (int s = 0; s < S && rc == CRTHIP_OK; s++)
-            if (cnt[s] > 0) {
-                rc = crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, s == 0 ? d_out_init : nullptr, 0);
-                if (rc) node_err(nd, rc, "crthip_seq_weave", crthip_error_string(nd->ctx[s]));
-            }
+        for (int s = 0; s < S; s++)
+            if (cnt[s] > 0) NODE_CRT(nd, s, crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, s == 0 ? d_out_init : nullptr, 0));
     }
     int prev = -1;
-    for (int s = 0; s < S && rc == CRTHIP_OK; s++) {
+    for (int s = 0; s < S; s++) {
         if (cnt[s] <= 0) continue;
         if (prev >= 0) {
-            if (hipSetDevice(nd->device[s]) != hipSuccess || hipMalloc(&init[s], pic) != hipSuccess) { rc = node_err(nd, CRTHIP_E_NOMEM, "hipMalloc", "picture hand-over buffer"); break; }
+            if (hipSetDevice(nd->device[s]) != hipSuccess || hipMalloc(&init[s], pic) != hipSuccess)
+                return node_err(nd, CRTHIP_E_NOMEM, "hipMalloc", "picture hand-over buffer");
             rc = hand_over_picture(nd, prev, last_picture(prev), s, init[s], pic);
-            if (rc == CRTHIP_OK) {
-                rc = crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, init[s], blob[0].blend ? 0 : 1);
-                if (rc) node_err(nd, rc, "crthip_seq_weave", crthip_error_string(nd->ctx[s]));
-            }
+            if (rc) return rc;
+            NODE_CRT(nd, s, crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, init[s], blob[0].blend ? 0 : 1));
         } else if (blob[0].blend) {
-            rc = crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, d_out_init, 0);
-            if (rc) node_err(nd, rc, "crthip_seq_weave", crthip_error_string(nd->ctx[s]));
+            NODE_CRT(nd, s, crthip_seq_weave(nd->ctx[s], &blob[s], cnt[s], d_out[s], ostride, d_out_init, 0));
         }
         prev = s;
     }
-    if (rc != CRTHIP_OK) { crthip_node_synchronize(nd); free_inits(); return rc; }
     (void) last_shard;
-    rc = crthip_node_synchronize(nd);
-    if (vhs) for (int s = 0; s < S; s++) if (cnt[s] > 0) crthip_seq_vhs_prechained(nd->ctx[s], 0);
-    free_inits();
-    return rc;
+    return crthip_node_synchronize(nd);          /* (the guard then frees the hand-over buffers and clears the VHS flag) */
 }
 
 }  /* extern "C" */

@@ -624,12 +624,12 @@ crt_setup_signal_range(const crthip_params *p, int *lo, int *hi)
     } else {
         if (110 > a_hi) a_hi = 110;                         /* clamped to 0..110, crt_ntsc.c:319-320 */
     }
-    /* noise term ((byte - 0x7f) * noise) >> 8, byte = 0..255 */
-    t0 = (-127 * p->noise) >> 8;
-    t1 = (128 * p->noise) >> 8;
+    /* noise term ((byte - 0x7f) * noise) >> 8, byte = 0..255 (range check first: the products below must not overflow) */
     if (p->noise > (1 << 20) || p->noise < -(1 << 20)) {
         return;
     }
+    t0 = (-127 * p->noise) >> 8;
+    t1 = (128 * p->noise) >> 8;
     a_lo += t0 < t1 ? t0 : t1;
     a_hi += t0 < t1 ? t1 : t0;
     if (a_lo < -127) a_lo = -127;                           /* crt_core.c:363-364 */
