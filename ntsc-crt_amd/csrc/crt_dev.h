@@ -406,6 +406,18 @@ __host__ __device__ constexpr int vhs_tail_start(int input_size, int hres)
 /* ------------------------------------------------------------------------- */
 /* host side: context, dispatch by system, C ABI                               */
 /* ------------------------------------------------------------------------- */
+#define SYNC_FULL 0              /* crt_run_sync modes, see k_hsync_wave (crt_sync.hip) */
+#define SYNC_SPEC 1
+#define SYNC_VERIFY 2
+/* what the speculative sync pass (k_hsync_wave<SYNC_SPEC>) found for a field, for the verifying pass to commit or discard */
+struct crthip_spec {
+    int ok;                     /* no window of the chain reached into the encoder's active rectangle */
+    int vsync, odd_field;       /* the vertical sync it assumed (picture part of the candidate lines masked) */
+    int hsync;                  /* the field's final hsync */
+    int ccf[CRTHIP_MAX_VPER][CRTHIP_MAX_CCS];   /* ... and burst integrators */
+    int pad[3];
+};                              /* 128 bytes */
+
 struct crthip_ctx {
     int device;
     int system, pattern;
@@ -419,6 +431,9 @@ struct crthip_ctx {
     int cap_fields;
     signed char *d_analog, *d_inp;
     crthip_line *d_lines;
+    crthip_spec *d_spec;        /* per field: the speculative sync pass's record */
+    bool spec_ran;              /* the last crthip_fieldpass speculated (crthip_spec_sync_stats) */
+    int spec_sync;              /* CRTHIP_SPEC_SYNC: 1 (default) = the sync chain beside the encoder on the second stream, 0 = after it */
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
     bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tiers */
@@ -563,6 +578,9 @@ static inline int crt_ensure_aux(crthip_ctx *c)
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                     signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state);
 int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state);
+int crt_run_encoder_margins(crthip_ctx *c, const crthip_params *p, int n, signed char *dst, crthip_state *d_state);
+int crt_run_encoder_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                           signed char *dst, crthip_state *d_state);
 int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused);
 int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
                   crthip_state *d_state, bool advance_rn);
@@ -570,7 +588,7 @@ int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
 int crt_run_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration);
 int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthip_state *d_state);
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
-                 crthip_line *d_lines, int advance_rn);
+                 crthip_line *d_lines, int advance_rn, int mode = 0);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride);
 int crt_reserve_bloom(crthip_ctx *c, int n);

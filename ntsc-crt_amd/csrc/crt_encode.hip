@@ -969,25 +969,39 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
 #undef CRTHIP_LAUNCH_ACTIVE
 }
 
+/* fused path: skeleton + noise for everything outside the active rectangle */
+template <class S>
+static void launch_margins(crthip_ctx *c, const crthip_params *p, int n, signed char *dst, const crthip_state *d_state)
+{
+    ProfScope ps(c, CRTHIP_K_TEMPLATE);
+    const int s0 = p->yo * S::HRES + p->xo;
+    const int head = (s0 + 15) / 16;
+    const int gap = (S::HRES - p->destw + 15) / 16;
+    const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
+    const int tail = (tail_len + 15) / 16;
+    const int total = n * (head + (p->desth - 1) * gap + tail);
+    if (p->noise != 0)
+        hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+    else
+        hipLaunchKernelGGL((k_margin<S, false>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+}
+
+template <class S, bool FULL>
+static void launch_active_any(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                              signed char *dst, const crthip_state *d_state)
+{
+    if (encoder_fast_ok<S>(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
+    else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state);
+}
+
 template <class S, bool FULL>
 static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                           signed char *dst, const crthip_state *d_state, int nes_setup)
 {
     if (FULL) {
-        /* fused path: skeleton + noise for everything outside the active rectangle */
-        ProfScope ps(c, CRTHIP_K_TEMPLATE);
-        const int s0 = p->yo * S::HRES + p->xo;
-        const int head = (s0 + 15) / 16;
-        const int gap = (S::HRES - p->destw + 15) / 16;
-        const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
-        const int tail = (tail_len + 15) / 16;
-        const int total = n * (head + (p->desth - 1) * gap + tail);
-        if (p->noise != 0)
-            hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                               *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
-        else
-            hipLaunchKernelGGL((k_margin<S, false>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                               *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+        launch_margins<S>(c, p, n, dst, d_state);
     } else {
         constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
         ProfScope ps(c, CRTHIP_K_TEMPLATE);
@@ -995,8 +1009,7 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
         hipLaunchKernelGGL((k_template<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
                            *p, n, dst, c->fstride, d_state, nes_setup);
     }
-    if (encoder_fast_ok<S>(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
-    else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state);
+    launch_active_any<S, FULL>(c, p, n, d_images, istride, dst, d_state);
     return CRTHIP_OK;
 }
 
@@ -1121,6 +1134,24 @@ int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_
                       : launch_encoder<S, false>(c, p, n, d_images, istride, dst, d_state, nes_setup);
         if (with_state) hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
         return r;
+    });
+}
+
+/* the two halves of the fused encoder on their own (the speculative sync chain is forked between them, crt_host.hip) */
+int crt_run_encoder_margins(crthip_ctx *c, const crthip_params *p, int n, signed char *dst, crthip_state *d_state)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        launch_margins<decltype(tag)>(c, p, n, dst, d_state);
+        return CRTHIP_OK;
+    });
+}
+
+int crt_run_encoder_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
+                           signed char *dst, crthip_state *d_state)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        launch_active_any<decltype(tag), true>(c, p, n, d_images, istride, dst, d_state);
+        return CRTHIP_OK;
     });
 }
 

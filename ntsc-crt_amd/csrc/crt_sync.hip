@@ -42,8 +42,12 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 /* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR.  Wave-wide: all 2 * VWIN candidate lines
  * are fetched up front, then searched in order with a prefix sum across the wave.  Returns the line found (the last
  * candidate if none) and j (HRES if none), the same in every lane. */
-template <class S>
-__device__ __forceinline__ void vsync_search(const signed char *__restrict__ in, const int vsync, const int lane, int &vline, int &vj)
+/* MASKED (the speculative sync pass, see k_hsync_wave): the samples of the encoder's active rectangle -- flat index S0 + y * HRES
+ * + x, y < desth, x < destw, exactly like crt_ntsc.c:322 -- are not written yet; they count as 0, i.e. the search assumes that
+ * no candidate line crosses the threshold inside its picture part.  The verifying pass repeats the search on the complete field. */
+template <class S, bool MASKED = false>
+__device__ __forceinline__ void vsync_search(const signed char *__restrict__ in, const int vsync, const int lane, int &vline, int &vj,
+                                             const int m_xo = 0, const int m_yo = 0, const int m_destw = 0, const int m_desth = 0)
 {
     vline = 0; vj = S::HRES;
     constexpr int PIECES = (S::HRES + 1023) / 1024;      /* 64 lanes x 16 samples per piece; 2 pieces for the PV-1000's 1920 */
@@ -75,12 +79,20 @@ __device__ __forceinline__ void vsync_search(const signed char *__restrict__ in,
                     vline = posmod(vsync + g0 + i - S::VWIN, S::VRES);
                     const int wds[4] = { cand[i][pc].x, cand[i][pc].y, cand[i][pc].z, cand[i][pc].w };
                     const int s0 = pc * 1024 + lane * 16;
+                    /* MASKED: columns of this line inside the rectangle: [a_lo, a_hi) of its own row, [0, b_hi) of the row above
+                     * running over the line end (wave-uniform) */
+                    int a_lo = 0, a_hi = 0, b_hi = 0;
+                    if (MASKED) {
+                        if (vline >= m_yo && vline < m_yo + m_desth) { a_lo = m_xo; a_hi = m_xo + m_destw; }
+                        if (vline - 1 >= m_yo && vline - 1 < m_yo + m_desth && m_xo + m_destw > S::HRES) b_hi = m_xo + m_destw - S::HRES;
+                    }
                     int pre[16];
                     int run = 0;
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
                         if (s0 + k >= S::HRES) s = 0;
+                        if (MASKED && ((s0 + k >= a_lo && s0 + k < a_hi) || s0 + k < b_hi)) s = 0;
                         run += s;
                         pre[k] = run;
                     }
@@ -402,10 +414,22 @@ __device__ __forceinline__ int burst_step(int acc, int s)
  * burst integrators of the workgroup's 4 fields are stepped by ONE wave, 4 fields x CC_VPER x CC_SAMPLES lanes at a
  * time, while the other three wait at a barrier -- the chain is the only part that keeps the vector unit busy for long,
  * and with 4 of 64 lanes working per field it costs a quarter this way. */
-template <class S, int FPB>
+/* MODE -- taking the chain off the critical path of a fused field-pass.  Everything the chain reads
+ * lies OUTSIDE the encoder's active rectangle -- sync pulses, bursts, blanking: the margins, complete after k_margin -- with
+ * two exceptions: the vertical sync search integrates whole candidate lines, some of which carry picture (crt_core.c:379-396),
+ * and a sync state far from lock moves the hsync / burst windows into the picture.  So:
+ *   SYNC_SPEC    runs BESIDE the encoder (k_active) on the context's second stream, on a field whose picture part is not
+ *                written yet: vertical search with the picture part masked, the whole chain, the line table; the field's state
+ *                is not touched -- results go to a crthip_spec record; `ok` = no window ever reached into the rectangle;
+ *   SYNC_VERIFY  runs where the chain used to: repeats ONLY the vertical search, on the complete field; same answer and ok
+ *                => commit the record to the state (and advance rn), done; anything else => the full chain, as if nothing
+ *                had been speculated (the state is still the incoming one).
+ * Exact by construction: the speculative result is used only if the one assumption it rests on was checked on final data. */
+template <class S, int FPB, int MODE = SYNC_FULL>
 __global__ void __launch_bounds__(64 * FPB, 4)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-             crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn)
+             crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn,
+             crthip_spec *__restrict__ spec)
 {
     constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS, VPER = S::VPER;
     constexpr int WOFF = S::SYNC_BEG - S::HWIN;          /* first byte of the search window relative to ln + hsync */
@@ -442,15 +466,45 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
         vsync = __builtin_amdgcn_readfirstlane(st->vsync);
         odd_field = __builtin_amdgcn_readfirstlane(st->odd_field);
     } else {
-        vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
+        if (MODE == SYNC_SPEC) vsync_search<S, true>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_, P.xo, P.yo, P.destw, P.desth);
+        else vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
         vsync = __builtin_amdgcn_readfirstlane(vsync);
         odd_field = __builtin_amdgcn_readfirstlane(vj_) > S::HRES / 2;
     }
-    if (live && lane == 0) {
+    crthip_spec *const sp = spec + f;
+    if (MODE == SYNC_VERIFY) {
+        /* the speculative pass's answer stands iff it rested on the right vertical sync and never looked into the picture */
+        const bool mine_ok = sp->ok != 0 && sp->vsync == vsync && sp->odd_field == odd_field;
+        /* a workgroup's fields share the chain wave and its barriers: all of them redo, or none (redoing a good one is harmless) */
+        const bool redo = FPB > 1 ? __syncthreads_or(live && !mine_ok) != 0 : !mine_ok;
+        if (!redo) {
+            if (live) {
+                if (lane == 0) {
+                    st->vsync = vsync;
+                    st->odd_field = odd_field;
+                    st->hsync = sp->hsync;
+                    if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
+                }
+                if (lane < S::VPER * S::CCS) st->ccf[lane / S::CCS][lane % S::CCS] = sp->ccf[lane / S::CCS][lane % S::CCS];
+            }
+            return;
+        }
+    }
+    if (MODE != SYNC_SPEC && live && lane == 0) {
         st->vsync = vsync;
         st->odd_field = odd_field;
         if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
     }
+    bool touched = false;                                /* SYNC_SPEC: some window of this field reached into the active rectangle */
+    /* does the flat range [a, a + len) (len <= HRES) meet the encoder's rectangle?  (rows S0 + y * HRES + [0, destw), y < desth) */
+    auto hits_active = [&](long a, int len) {
+        long r0 = a - ((long) P.yo * S::HRES + P.xo);
+        if (r0 + len <= 0) return false;
+        if (r0 < 0) { len += (int) r0; r0 = 0; }
+        const int row0 = (int) (r0 / S::HRES), c0 = (int) (r0 - (long) row0 * S::HRES);
+        if (row0 >= P.desth) return false;
+        return c0 < P.destw || (c0 + len > S::HRES && row0 + 1 < P.desth);
+    };
     const int field_rows = odd_field * (P.ratio / 2);                                          /* crt_core.c:407 */
     const unsigned span = (unsigned) P.outh + P.v_fac;
     crthip_line *out_lines = lines + (size_t) f * S::LINES;
@@ -529,6 +583,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                 if (!new_skip) {
                     /* the 2*HWIN bytes from ln + h_in + SYNC_BEG - HWIN: from my parked window, the next line's (wrapped
                      * hsync), or -- rarely -- from memory */
+                    if (MODE == SYNC_SPEC && hits_active((long) my_lidx * S::HRES + h_in + WOFF, 2 * S::HWIN)) touched = true;
                     int a = -1;
                     if (h_in >= 0 && h_in <= WLEN - 2 * S::HWIN - WBACK && own_ok) a = lane * (WSTR * 4) + h_in + WBACK;
                     else if (h_in >= S::HRES - WBACK && h_in < S::HRES && next_ok) a = (lane + 1) * (WSTR * 4) + h_in - S::HRES + WBACK;
@@ -743,6 +798,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             /* burst samples: CB_LEN bytes from ln + halign + CB_BEG (:459-461) */
             const int halign = CCS == 4 ? (rec_hs & ~3) : rec_hs - rec_hs % CCS;
             const int baddr = lidx * S::HRES + halign + S::CB_BEG;
+            if (MODE == SYNC_SPEC && !rec_skip && hits_active((long) baddr, S::CB_LEN)) touched = true;
 #pragma unroll
             for (int q = 0; q < BPIECES; q++) {
                 breg[q] = !rec_skip ? load16u(in + baddr + q * 16) : v4i{0, 0, 0, 0};
@@ -750,8 +806,14 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             wave_lds_fence();
         }
     }
-    if (chain_lane) st_chain->ccf[my_r][my_p] = acc;
-    if (lane == 0 && live) st->hsync = hsync;
+    if (MODE == SYNC_SPEC) {
+        if (chain_lane) spec[blockIdx.x * FPB + my_slot].ccf[my_r][my_p] = acc;
+        const bool any_touched = __ballot(touched) != 0ull;
+        if (lane == 0 && live) { sp->ok = any_touched ? 0 : 1; sp->vsync = vsync; sp->odd_field = odd_field; sp->hsync = hsync; }
+    } else {
+        if (chain_lane) st_chain->ccf[my_r][my_p] = acc;
+        if (lane == 0 && live) st->hsync = hsync;
+    }
 #undef HSW_SYNC
 }
 
@@ -869,13 +931,16 @@ int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthi
     });
 }
 
+/* mode: SYNC_FULL, or the two halves of the speculative scheme (see k_hsync_wave): SYNC_SPEC -- on whatever stream c->stream is
+ * at the moment, the line table and c->d_spec only -- and SYNC_VERIFY (+ the bloom pass, which reads the picture part) */
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
-                 crthip_line *d_lines, int advance_rn)
+                 crthip_line *d_lines, int advance_rn, int mode)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
         const bool legacy = c->legacy_sync || c->sync_kernel == 1;
+        if (mode != SYNC_FULL && (legacy || !c->d_spec)) return set_err(c, CRTHIP_E_ARG, "speculative sync without its scratch", hipSuccess);
         if (legacy)
             if (!(p->flags & CRTHIP_F_NO_VSYNC))
                 hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn, 0);
@@ -887,18 +952,20 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
             hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
         else {
             bool done = false;
+#define CRT_LAUNCH_HSW(FPB, GRID, BLOCK) do { \
+            if (mode == SYNC_SPEC) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_SPEC>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
+            else if (mode == SYNC_VERIFY) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_VERIFY>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
+            else hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_FULL>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); } while (0)
             if constexpr (FPB4_OK) {                     /* 4 fields per workgroup share one wave for their burst chains */
                 if (c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {
-                    hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                                       c->whole_field, advance_rn);
+                    CRT_LAUNCH_HSW(4, dim3((n + 3) / 4), dim3(256));
                     done = true;
                 }
             }
-            if (!done)
-                hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                                   c->whole_field, advance_rn);
+            if (!done) CRT_LAUNCH_HSW(1, dim3(n), dim3(64));
+#undef CRT_LAUNCH_HSW
         }
-        if (p->bloom)
+        if (p->bloom && mode != SYNC_SPEC)
             hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;
     });

@@ -211,6 +211,38 @@ __global__ void __launch_bounds__(64) k_rows_read(const v4i *p, size_t pitch16, 
     if (acc == 0x12345678) *out = acc;
 }
 
+// round 4: store patterns of a decoder whose wave owns FEWER lines and writes WIDER runs (lane = pixel group in the pixel stage):
+//   LPW lines per wave, RUN16 16-byte pieces per contiguous run of one row (64 = 1 KB, 32 = 512 B ...), dups alternate 3 / 4
+//   (scanlines 1 at 1080 rows: 3.5 rows per line on average).  FULLROW: the run loop inside the line (whole rows at once).
+template <int LPW, int RUN16, bool FULLROW>
+__global__ void __launch_bounds__(64) k_rows_wide(v4i *p, size_t pitch16, int lines_per_pic, int rows_per_pic, int n_pics)
+{
+    const int lane = threadIdx.x;
+    const size_t wave = blockIdx.x;
+    constexpr int ROWS_PER_INSTR = 64 / RUN16;                // rows (lines) covered by one store instruction
+    const int sub = lane / RUN16, piece = lane % RUN16;
+    v4i v = { 1, 2, 3, 4 };
+    if (FULLROW) {
+        for (int i = 0; i < LPW; i += ROWS_PER_INSTR) {
+            const size_t line = wave * LPW + i + sub, pic = line / lines_per_pic, l = line % lines_per_pic;
+            if (pic >= (size_t) n_pics) continue;
+            const int dups = 3 + (int) (l & 1);
+            v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + piece;
+            for (int d = 0; d < dups; d++)
+                for (size_t x = 0; x + RUN16 <= pitch16; x += RUN16) __builtin_nontemporal_store(v, row + (size_t) d * pitch16 + x);
+        }
+        return;
+    }
+    for (size_t x = 0; x + RUN16 <= pitch16; x += RUN16)
+        for (int i = 0; i < LPW; i += ROWS_PER_INSTR) {
+            const size_t line = wave * LPW + i + sub, pic = line / lines_per_pic, l = line % lines_per_pic;
+            if (pic >= (size_t) n_pics) continue;
+            const int dups = 3 + (int) (l & 1);
+            v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + x + piece;
+            for (int d = 0; d < dups; d++) __builtin_nontemporal_store(v, row + (size_t) d * pitch16);
+        }
+}
+
 static hipEvent_t e0, e1;
 template <class F> static double best_ms(F launch, int iters = 5)
 {
@@ -258,7 +290,8 @@ int main(int argc, char **argv)
     };
     char geom[96];
     const int blocks[] = { 256, 512, 1024 };
-    for (int bi = 0; bi < 3; bi++) {
+    const bool rows_only = argc > 1 && !strcmp(argv[1], "rows");      // only the picture-row patterns
+    for (int bi = 0; bi < (rows_only ? 0 : 3); bi++) {
         const int bs = blocks[bi];
         for (int mult = 2; mult <= 64; mult *= 2) {          // grid-stride: 256 CUs x mult blocks
             const int grid = 256 * mult;
@@ -305,6 +338,22 @@ int main(int argc, char **argv)
         VARIANT(3, "XCD-aware line-group map", 64);
         VARIANT(4, "1 KB of one row per instruction", 64);
         VARIANT(5, "256-thread blocks", 256);
+        {
+            const double gbw = (double) pics * 240 * 3.5 * 7680.0 / 1e9;
+#define WIDE(LPW, RUN16, FULL, name) printf("%-6s %-44s %8.1f GB/s\n", "rowsw", name, gbw / (best_ms([&] { \
+            hipLaunchKernelGGL((k_rows_wide<LPW, RUN16, FULL>), dim3((pics * 240 + LPW - 1) / LPW), dim3(64), 0, 0, a, pitch16, 240, 1080, pics); }) * 1e-3))
+            WIDE(64, 8, false, "64 lines/wave, 128 B runs, 3.5 rows");
+            WIDE(64, 64, false, "64 lines/wave, 1 KB runs, 3.5 rows");
+            WIDE(32, 32, false, "32 lines/wave, 512 B runs, 3.5 rows");
+            WIDE(32, 64, false, "32 lines/wave, 1 KB runs, 3.5 rows");
+            WIDE(16, 16, false, "16 lines/wave, 256 B runs, 3.5 rows");
+            WIDE(16, 32, false, "16 lines/wave, 512 B runs, 3.5 rows");
+            WIDE(16, 64, false, "16 lines/wave, 1 KB runs, 3.5 rows");
+            WIDE(8, 64, false, "8 lines/wave, 1 KB runs, 3.5 rows");
+            WIDE(16, 64, true, "16 lines/wave, whole rows at once");
+            WIDE(4, 64, true, "4 lines/wave, whole rows at once");
+            WIDE(1, 64, true, "1 line/wave, whole rows at once");
+        }
         // dense pictures (no skipped rows: 960-row pictures)
         printf("%-6s %-44s %8.1f GB/s\n", "rowsv", "baseline, dense 960-row pictures", gb / (best_ms([&] { hipLaunchKernelGGL((k_rows_var<0>), dim3(waves), dim3(64), 0, 0, a, pitch16, 240, dups, 960, pics, waves); }) * 1e-3));
         // reads: 236 of 1080 rows per picture
