@@ -233,7 +233,7 @@ def compact_record(full):
         out["one_batch_in_flight"] = {"value": _r(ob["value"], 7), "ms_per_step": _r(ob["ms_per_step"], 5),
                                       "pipeline_frac": _r(ob.get("pipeline_frac"))}
     for k in ("world_size", "world_size_seen_by_rccl", "collectives", "settings_blob_crc32_per_rank",
-              "settings_blob_crc32_rank0_before_broadcast", "strong_scaling"):
+              "settings_blob_crc32_rank0_before_broadcast", "strong_scaling", "cli_config1"):
         if full.get(k) is not None:
             out[k] = full[k]
     rows = []
@@ -670,6 +670,18 @@ def main():
                              traffic_file=os.path.join(ROOT, "profiles", "traffic_%s.json" % e["name"]))
             extras.append(r)
 
+    cli = None
+    if world == 1 and headline and not args.no_extra and not args.no_cpu:
+        # BASELINE configs[0] as stated: whole-process wall time of `ntsc -op 640 480 0 0 in.ppm out.ppm`, the reference binary
+        # beside the same crt_main.c linked against the HIP drop-in library (tools/time_cli.py); None where the driver binaries
+        # are not prebuilt
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import time_cli
+            cli = time_cli.measure(3)
+        except Exception as e:                                   # never let the side measurement cost the headline
+            cli = {"error": str(e)[:120]}
+
     if rank == 0:
         out = {
             "metric": "frames/sec at 640x480 interlaced, bit-exact vs CPU; % HBM roofline",
@@ -687,6 +699,8 @@ def main():
         for k in ("one_batch_in_flight", "settings_blob_crc32_per_rank", "settings_blob_crc32_rank0_before_broadcast", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
             if k in rec:
                 out[k] = rec[k]
+        if cli:
+            out["cli_config1"] = cli
         if extras:
             out["extra_workloads"] = extras
             by = {e["name"]: e for e in extras if e}

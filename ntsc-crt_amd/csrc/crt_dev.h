@@ -394,6 +394,7 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
 #define NES_TAB_SIZE (512 * 12)            /* NES composite-sample table: 9-bit pixel x phase mod 12 */
 #define SKEL_VARIANTS 12                   /* cached clean skeleton fields (k_skeleton): (field, frame) or field x dot_crawl_offset */
 #define VHS_CHUNK 124                      /* samples per lane in the parallel region = 248 calls = 8 * 31 (248: measured slower) */
+#define VHS_DIG_ROW 128                    /* bytes per coefficient row in digit form: 4 planes x 32 */
 #define VHS_BLK   43                       /* calls per lane in the tail's window: 64 * 43 >= 3 * HRES + 3 */
 
 /* first sample of the tail: a chunk boundary with at least 16 samples (>= 31 calls) before I0 + 1 */
@@ -461,6 +462,8 @@ struct crthip_ctx {
     int seq_guess_n;            /* crthip_seq_sync: the guess array holds the finals of a previous call for this many fields (warm restart) */
     unsigned *d_vhs_rows;       /* VHS: jump coefficients, (vhs_chunks + 1) x 31 words, then 31 x 64 (tail blocks) */
     int vhs_chunks;
+    signed char *d_vhs_dig;     /* VHS: the same coefficients as signed byte digits, VHS_DIG_ROW bytes per row (matrix-core jump) */
+    int vhs_mfma;               /* CRTHIP_VHS_MFMA: 1 (default) = the 31 x 31 jumps on the matrix cores, 0 = on the vector unit */
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
     unsigned *d_vhs_next;       /* VHS: where k_vhs_tail leaves the histories while k_vhs_noise still reads the old ones */
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */

@@ -220,13 +220,23 @@ struct RowTiles {
                 stage[i].z = (int) ((unsigned) stage[i].z >> 8); stage[i].w = (int) ((unsigned) stage[i].w >> 8);
             }
         }
+        if (tile < last_tile || (row_bytes & (TILE * 4 - 1)) == 0) {
+            /* every piece sits where it belongs (only the row's LAST tile can hold moved-back pieces): plain stores, no
+             * per-dword predicates (16 execute-mask round trips per tile as compiled before) */
 #pragma unroll
-        for (int i = 0; i < PIECES; i++) {
-            unsigned *d = s_pix + (i * ROWS + prow) * STRIDE;
-            if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
-            if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
-            if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
-            if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+            for (int i = 0; i < PIECES; i++) {
+                unsigned *d = s_pix + (i * ROWS + prow) * STRIDE + piece * 4;
+                d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) {
+                unsigned *d = s_pix + (i * ROWS + prow) * STRIDE;
+                if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
+                if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
+                if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
+                if (dw0 + 3 >= 0) d[dw0 + 3] = (unsigned) stage[i].w;
+            }
         }
         __syncthreads();
     }

@@ -243,13 +243,32 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
             }
         }
         c->vhs_chunks = chunks;
+        /* the same coefficients as SIGNED BYTE DIGITS for the matrix-core jump (crt_noise.hip, vhs_jump_mfma): a 32-bit word
+         * x == d0 + d1 * 2^8 + d2 * 2^16 + d3 * 2^24 (mod 2^32), every d in [-128, 127]; per row 4 digit planes of 32 bytes
+         * (coefficient m at byte m, byte 31 = 0): rows 0 .. chunks-1 the parallel chunks, then the tail's 64 blocks */
+        const size_t dig_rows = (size_t) chunks + 64;
+        signed char *dig = (signed char *) calloc(dig_rows, VHS_DIG_ROW);
+        if (!dig) { free(rows); crthip_destroy(c); return CRTHIP_E_NOMEM; }
+        for (size_t r = 0; r < dig_rows; r++) {
+            for (int m = 0; m < 31; m++) {
+                unsigned x = r < (size_t) chunks ? rows[r * 31 + m] : rows[31 * (size_t) (chunks + 1) + (size_t) m * 64 + (r - chunks)];
+                for (int pl = 0; pl < 4; pl++) {
+                    const int d = (int) (signed char) (x & 255u);
+                    dig[r * VHS_DIG_ROW + pl * 32 + m] = (signed char) d;
+                    x = (x - (unsigned) d) >> 8;
+                }
+            }
+        }
+        { const char *e = getenv("CRTHIP_VHS_MFMA"); c->vhs_mfma = e ? atoi(e) != 0 : 1; }       /* A/B switch: 0 = the jump on the vector unit */
         if (hipMalloc((void **) &c->d_vhs_rows, sizeof(unsigned) * words) != hipSuccess ||
-            hipMemcpy(c->d_vhs_rows, rows, sizeof(unsigned) * words, hipMemcpyHostToDevice) != hipSuccess) {
-            free(rows);
+            hipMemcpy(c->d_vhs_rows, rows, sizeof(unsigned) * words, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMalloc((void **) &c->d_vhs_dig, dig_rows * VHS_DIG_ROW) != hipSuccess ||
+            hipMemcpy(c->d_vhs_dig, dig, dig_rows * VHS_DIG_ROW, hipMemcpyHostToDevice) != hipSuccess) {
+            free(rows); free(dig);
             crthip_destroy(c);
             return CRTHIP_E_HIP;
         }
-        free(rows);
+        free(rows); free(dig);
     }
     *out = c;
     return CRTHIP_OK;
@@ -268,6 +287,7 @@ void crthip_destroy(crthip_ctx *c)
     }
     if (c->d_jump16) hipFree(c->d_jump16);
     if (c->d_vhs_rows) hipFree(c->d_vhs_rows);
+    if (c->d_vhs_dig) hipFree(c->d_vhs_dig);
     if (c->d_vhs_next) hipFree(c->d_vhs_next);
     if (c->d_seq) hipFree(c->d_seq);
     if (c->d_bloom) hipFree(c->d_bloom);

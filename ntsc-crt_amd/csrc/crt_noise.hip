@@ -84,14 +84,120 @@ __device__ __forceinline__ int dev_cos14(int n)
     return cs;
 }
 
+/* ------------------------------------------------------------------------- */
+/* the 31 x 31 jump of the rand() model on the matrix cores                     */
+/* ------------------------------------------------------------------------- */
+/*
+ * Every lane of a wave needs the generator's 31-value history at ITS call position:  w_lane[j] = sum_m c_lane[m] * z[m + j]
+ * (mod 2^32), c_lane = x^K_lane mod (x^31 - x^28 - 1) from the host's table, z = the field's base sequence (history + the
+ * next 30 values).  Over the wave that is the matrix product  W^T (31 x 64) = H^T (31 x 31, Hankel: H[m][j] = z[m + j]) x
+ * C^T (31 x 64) -- 961 multiply-adds per lane on the vector unit, with v_mul_lo_u32 at a quarter of the full rate: half of
+ * everything the VHS noise kernels did.  Here: 32-bit words as four SIGNED byte digits
+ * (x == d0 + d1 2^8 + d2 2^16 + d3 2^24 mod 2^32, |d| <= 128), the ten digit pairs (p, q), p + q <= 3, as
+ * v_mfma_i32_32x32x32_i8 (exact: |sum| <= 4 * 31 * 128 * 128 < 2^21 per accumulator), pairs of equal weight accumulated in
+ * one accumulator, then W = acc0 + (acc1 << 8) + (acc2 << 16) + (acc3 << 24) with 32-bit wrap-around -- pairs of weight
+ * 2^32 and beyond vanish.  Two 32-lane tiles per wave.  Operand layouts: A = H^T rows j = lane & 31, B = C^T columns =
+ * chunk lane & 31; both take k = m in the SAME slot order (16 * (lane >> 5) + byte), so the order itself does not matter;
+ * D: column = lane & 31, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cdna_hip_programming.md, dtype independent).
+ */
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define VHS_ZD_STRIDE 72                   /* bytes per digit plane of the base sequence in LDS: 61 values, zero padding */
+
+/* element idx of the base sequence z[0..60] of the history h[0..30] (z[n] = z[n-31] + z[n-3]), without the recurrence:
+ * z[31 + t] = h[28 + t % 3] + h[t] + h[t - 3] + h[t - 6] + ...   (idx >= 61: 0) */
+__device__ __forceinline__ unsigned vhs_base_value(const unsigned *h, int idx)
+{
+    if (idx < 31) return h[idx];
+    if (idx >= 61) return 0u;
+    const int t = idx - 31;
+    unsigned v = h[28 + t % 3];
+#pragma unroll
+    for (int i = 0; i <= 10; i++) {
+        const int k = t - 3 * i;
+        if (k >= 0) v += h[k];
+    }
+    return v;
+}
+
+/* lane idx publishes the four digits of z[idx] (s_zd: 4 planes of VHS_ZD_STRIDE bytes); the caller fences */
+__device__ __forceinline__ void vhs_publish_digits(unsigned char *s_zd, int lane, unsigned zval)
+{
+    unsigned x = zval;
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++) {
+        const int d = (int) (signed char) (x & 255u);
+        s_zd[pl * VHS_ZD_STRIDE + lane] = (unsigned char) d;
+        if (lane < VHS_ZD_STRIDE - 64) s_zd[pl * VHS_ZD_STRIDE + 64 + lane] = 0;
+        x = (x - (unsigned) d) >> 8;
+    }
+}
+
+/* the coefficient fragments of the chunk rows row_t0 (tile 0: the row of lane & 31) and row_t1 (tile 1) */
+__device__ __forceinline__ void vhs_load_bfrag(const signed char *__restrict__ dig, int row_t0, int row_t1, int lane, v4i bfr[2][4])
+{
+    const int half = lane >> 5;
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++) {
+        bfr[0][pl] = *(const v4i *) (dig + (size_t) row_t0 * VHS_DIG_ROW + pl * 32 + half * 16);
+        bfr[1][pl] = *(const v4i *) (dig + (size_t) row_t1 * VHS_DIG_ROW + pl * 32 + half * 16);
+    }
+}
+
+/* w[j] = sum_m c_lane[m] * z[m + j] mod 2^32 for the lanes of the wave with `mine` set (the others keep their w); s_zd = the
+ * digit planes of z (published and fenced), bfr = the lanes' coefficient fragments (vhs_load_bfrag) */
+__device__ __forceinline__ void vhs_jump_mfma(const unsigned char *s_zd, const v4i bfr[2][4], int lane, unsigned w[31], bool mine = true)
+{
+    /* A fragments: 16 consecutive digits of z from index (lane & 31) + 16 * (lane >> 5) */
+    v4i afr[4];
+    const int o = (lane & 31) + 16 * (lane >> 5);
+    const unsigned sh = (unsigned) (o & 3);
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        const unsigned *wp = (const unsigned *) (s_zd + qd * VHS_ZD_STRIDE) + (o >> 2);
+        const unsigned d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+        afr[qd].x = (int) __builtin_amdgcn_alignbyte(d1, d0, sh);
+        afr[qd].y = (int) __builtin_amdgcn_alignbyte(d2, d1, sh);
+        afr[qd].z = (int) __builtin_amdgcn_alignbyte(d3, d2, sh);
+        afr[qd].w = (int) __builtin_amdgcn_alignbyte(d4, d3, sh);
+    }
+    const bool lo = lane < 32;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        unsigned W[16];
+#pragma unroll
+        for (int sdeg = 0; sdeg < 4; sdeg++) {                 /* digit pairs of weight 2^(8 * sdeg): coefficient digit p, sequence digit sdeg - p */
+            v16i acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+            for (int pl = 0; pl <= sdeg; pl++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[sdeg - pl], bfr[t][pl], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) W[r] = sdeg == 0 ? (unsigned) acc[r] : W[r] + ((unsigned) acc[r] << (8 * sdeg));
+            /* (one accumulator at a time: four of them side by side cost the kernel half its occupancy) */
+#pragma unroll
+            for (int r = 0; r < 16; r++) asm volatile("" : "+v"(W[r]));
+        }
+        /* Tile t holds the results of chunks 32 t .. 32 t + 31: column lane & 31, rows j0 = (r & 3) + 8 (r >> 2) in lanes 0..31 and
+         * j0 + 4 in lanes 32..63.  The half-wave that owns those chunks (lanes 0..31 for tile 0, 32..63 for tile 1) keeps its
+         * own rows and receives the others from the lane 32 away. */
+        const bool own = lo == (t == 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned recv = (unsigned) __shfl_xor((int) W[r], 32);
+            const int j0 = (r & 3) + 8 * (r >> 2);
+            const unsigned v0 = lo ? W[r] : recv, v4 = lo ? recv : W[r];     /* rows j0 / j0 + 4 of the owner's chunk */
+            if (own && mine) w[j0] = v0;
+            if (j0 + 4 < 31 && own && mine) w[j0 + 4] = v4;
+        }
+    }
+}
+
 /* Parallel region.  A wave's 64 chunks are (mostly) one contiguous 15872-byte run of the field: it is moved
  * through an LDS tile of 64 x 62 dwords with coalesced 256-byte requests (lane-per-chunk byte accesses cost
  * 12x the algorithmic HBM write traffic); the lane's own dwords sit at an odd stride = conflict-free. */
-template <class S>
-__global__ void __launch_bounds__(64)
+template <class S, bool MFMA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
             signed char *__restrict__ inp, size_t fstride,
-            const unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a)
+            const unsigned *__restrict__ hist, const unsigned *__restrict__ rows, int chunks_a, const signed char *__restrict__ dig)
 {
     constexpr int DW = VHS_CHUNK / 4;                            /* dwords per chunk */
     constexpr int DWS = DW | 1;                                  /* odd LDS stride: conflict-free lane-per-chunk access */
@@ -109,13 +215,40 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
      * memory counter is in-order: a wait for these behind the tile requests would wait for the tile too) */
     const unsigned *h = hist + (size_t) f * 32;
     const unsigned *c = rows + (size_t) q * 31;
-    unsigned z[61], cm[31];
+    unsigned z[MFMA ? 1 : 61], cm[MFMA ? 1 : 31];
+    __shared__ unsigned s_zd_[MFMA ? 4 * VHS_ZD_STRIDE / 4 : 1];
+    unsigned char *const s_zd = (unsigned char *) s_zd_;
+    v4i bfr[2][4];
+    /* the fields this wave's chunks belong to: one, or two where the wave straddles a field boundary (1 wave in 27) */
+    const int total = n_fields * chunks_a;
+    const int gid_first = blockIdx.x * 64, gid_last = gid_first + 63 < total ? gid_first + 63 : total - 1;
+    const int f_first = gid_first / chunks_a, f_last = gid_last / chunks_a;
+    unsigned zmine[2] = { 0u, 0u };
+    if (MFMA) {
+        /* coefficient fragments: tile t column lane & 31 is the chunk of lane 32 t + (lane & 31) */
+        int row_t[2];
 #pragma unroll
-    for (int j = 0; j < 31; j++) z[j] = h[j];
+        for (int t = 0; t < 2; t++) {
+            const int g = gid_first + 32 * t + (lane & 31);
+            row_t[t] = g < total ? g - (g / chunks_a) * chunks_a : 0;
+        }
+        vhs_load_bfrag(dig, row_t[0], row_t[1], lane, bfr);
+        /* element `lane` of the base sequence of the wave's field(s) */
+        zmine[0] = vhs_base_value(hist + (size_t) f_first * 32, lane);
+        if (f_last != f_first) zmine[1] = vhs_base_value(hist + (size_t) f_last * 32, lane);
 #pragma unroll
-    for (int m = 0; m < 31; m++) cm[m] = c[m];
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-    for (int j = 0; j < 31; j++) asm volatile("" : "+v"(z[j]), "+v"(cm[j]));
+            for (int pl = 0; pl < 4; pl++) asm volatile("" : "+v"(bfr[t][pl]));
+        asm volatile("" : "+v"(zmine[0]), "+v"(zmine[1]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 31; j++) z[j] = h[j];
+#pragma unroll
+        for (int m = 0; m < 31; m++) cm[m] = c[m];
+#pragma unroll
+        for (int j = 0; j < 31; j++) asm volatile("" : "+v"(z[j]), "+v"(cm[j]));
+    }
     /* the tile straight into LDS (global_load_lds_dword: dword n of the tile belongs to lane n % 64 of request n / 64, which
      * is exactly where the hardware puts it), all 31 requests in flight at once and none of them waited for before the
      * jump below is done.  Through registers, four loads at a time, a wave spent 54 % of its life in s_waitcnt (SQ_WAIT_ANY,
@@ -132,17 +265,27 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *) (analog + off + 4 * d),
                                              (void __attribute__((address_space(3))) *) (s_t + it * 64), 4, 0, 0);
     }
-    /* base sequence z[0..60]: the history and the next 30 values */
-#pragma unroll
-    for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
     /* history of call K = 1 + 2 * VHS_CHUNK * q */
     unsigned w[31];
 #pragma unroll
     for (int j = 0; j < 31; j++) w[j] = 0;
+    if (MFMA) {
+        for (int pass = 0; pass < (f_last != f_first ? 2 : 1); pass++) {
+            const int fp = pass ? f_last : f_first;
+            wave_lds_fence();                                  /* (not __syncthreads(): that would wait for the tile requests too) */
+            vhs_publish_digits(s_zd, lane, pass ? zmine[1] : zmine[0]);
+            wave_lds_fence();
+            vhs_jump_mfma(s_zd, bfr, lane, w, f == fp);
+        }
+    } else {
+        /* base sequence z[0..60]: the history and the next 30 values */
 #pragma unroll
-    for (int m = 0; m < 31; m++) {
+        for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
 #pragma unroll
-        for (int j = 0; j < 31; j++) w[j] += cm[m] * z[m + j];
+        for (int m = 0; m < 31; m++) {
+#pragma unroll
+            for (int j = 0; j < 31; j++) w[j] += cm[m] * z[m + j];
+        }
     }
     const int noise = P.noise;
     __syncthreads();
@@ -158,7 +301,8 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
             if ((k & 3) == 0) in4 = mine[k >> 2];
             const int rn = (int) (v >> 1);
             const int a = (int) (in4 << (24 - 8 * (k & 3))) >> 24;
-            const int sv = clampi(a + ((((rn >> 16) & 0xff) - 0x7f) * noise >> 8), -127, 127);
+            /* (the wrapped 32-bit product through the full-rate 64-bit multiply-add: v_mul_lo_u32 runs at a quarter of it) */
+            const int sv = clampi(a + (mul_lo_mad64(((rn >> 16) & 0xff) - 0x7f, noise) >> 8), -127, 127);
             out4 = (k & 3) == 0 ? (unsigned) (sv & 255) : out4 | (unsigned) (sv & 255) << (8 * (k & 3));
             if ((k & 3) == 3) mine[k >> 2] = out4;
         }
@@ -185,11 +329,12 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
  *   4. every lane walks its block once more, now producing samples (through LDS byte staging); the
  *      lane that meets the segment's last sample publishes the next window's start and `rn`.
  */
-template <class S>
-__global__ void __launch_bounds__(64)
+template <class S, bool MFMA>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
            signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
-           const unsigned *hist, unsigned *hist_out, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows)
+           const unsigned *hist, unsigned *hist_out, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows,
+           const signed char *__restrict__ dig_blocks)
 {
     constexpr int N = S::INPUT_SIZE, H = S::HRES, B = VHS_BLK;
     constexpr int T0 = vhs_tail_start(N, H);
@@ -230,9 +375,16 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
         __syncthreads();
         if (lane < 31) s_h[lane] = acc;
     }
-    unsigned cb[31];                                               /* x^(43*lane) */
+    unsigned cb[MFMA ? 1 : 31];                                    /* x^(43*lane) */
+    __shared__ unsigned s_zd_[MFMA ? 4 * VHS_ZD_STRIDE / 4 : 1];
+    unsigned char *const s_zd = (unsigned char *) s_zd_;
+    v4i bfr[2][4];                                                 /* ... as digit fragments for the matrix cores (rows = blocks) */
+    if (MFMA) {
+        vhs_load_bfrag(dig_blocks, lane & 31, 32 + (lane & 31), lane, bfr);
+    } else {
 #pragma unroll
-    for (int m = 0; m < 31; m++) cb[m] = blk_rows[m * 64 + lane];
+        for (int m = 0; m < 31; m++) cb[m] = blk_rows[m * 64 + lane];
+    }
     __syncthreads();
 
     int seg_start = T0;
@@ -250,18 +402,24 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
         }
 
         /* 1. my block of the window */
-        unsigned z[61];
-#pragma unroll
-        for (int j = 0; j < 31; j++) z[j] = s_h[j];
-#pragma unroll
-        for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
         unsigned w[31];
+        if (MFMA) {
+            vhs_publish_digits(s_zd, lane, vhs_base_value(s_h, lane));
+            __syncthreads();
+            vhs_jump_mfma(s_zd, bfr, lane, w);
+        } else {
+            unsigned z[61];
 #pragma unroll
-        for (int j = 0; j < 31; j++) w[j] = 0;
+            for (int j = 0; j < 31; j++) z[j] = s_h[j];
 #pragma unroll
-        for (int m = 0; m < 31; m++) {
+            for (int j = 31; j < 61; j++) z[j] = z[j - 31] + z[j - 3];
 #pragma unroll
-            for (int j = 0; j < 31; j++) w[j] += cb[m] * z[m + j];
+            for (int j = 0; j < 31; j++) w[j] = 0;
+#pragma unroll
+            for (int m = 0; m < 31; m++) {
+#pragma unroll
+                for (int j = 0; j < 31; j++) w[j] += cb[m] * z[m + j];
+            }
         }
         unsigned glo = 0, ghi = 0;                                 /* c1 flags of my 43 calls (as B calls of this segment) */
 #pragma unroll
@@ -328,7 +486,7 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
                             nn = dev_cos14(ln * 8192 / 180) >> 8;
                         }
                     }
-                    const int sv = (int) s_a[s] + (((int) ((rnv >> 16) & 0xffu) - 0x7f) * nn >> 8);
+                    const int sv = (int) s_a[s] + (mul_lo_mad64((int) ((rnv >> 16) & 0xffu) - 0x7f, nn) >> 8);
                     s_o[s] = (signed char) clampi(sv, -127, 127);
                     pos += 2 + c1;
                     if (s == n_s - 1) { s_misc[0] = (unsigned) (lane * B + pos); s_misc[1] = rnv; }
@@ -540,16 +698,21 @@ int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed cha
                  * round the tail's workgroups queue behind the parallel region's 60 000 and run when those are done
                  * (measured: 1.06 ms side by side = 0.51 + 0.55 one after the other). */
                 hipStream_t ns = side ? c->aux_stream : c->stream;
-                if (side)
-                    hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
-                                       *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_next,
-                                       c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
-                hipLaunchKernelGGL((k_vhs_noise<S>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, ns,
-                                   *p, n, d_analog, d_inp, c->fstride, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks);
-                if (!side)
-                    hipLaunchKernelGGL((k_vhs_tail<S>), dim3(n), dim3(64), 0, c->stream,
-                                       *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, c->d_vhs_hist,
-                                       c->d_vhs_rows + (size_t) c->vhs_chunks * 31, c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31);
+                const unsigned *tail_row = c->d_vhs_rows + (size_t) c->vhs_chunks * 31, *blk_rows = c->d_vhs_rows + (size_t) (c->vhs_chunks + 1) * 31;
+                const signed char *dig_blocks = c->d_vhs_dig + (size_t) c->vhs_chunks * VHS_DIG_ROW;
+                const bool mfma = c->vhs_mfma != 0;            /* the 31 x 31 jumps on the matrix cores (CRTHIP_VHS_MFMA=0: on the vector unit) */
+#define CRT_LAUNCH_TAIL(HOUT) do { \
+                if (mfma) hipLaunchKernelGGL((k_vhs_tail<S, true>), dim3(n), dim3(64), 0, c->stream, *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, HOUT, tail_row, blk_rows, dig_blocks); \
+                else hipLaunchKernelGGL((k_vhs_tail<S, false>), dim3(n), dim3(64), 0, c->stream, *p, n, d_analog, d_inp, c->fstride, d_state, c->d_vhs_hist, HOUT, tail_row, blk_rows, dig_blocks); } while (0)
+                if (side) CRT_LAUNCH_TAIL(c->d_vhs_next);
+                if (mfma)
+                    hipLaunchKernelGGL((k_vhs_noise<S, true>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, ns,
+                                       *p, n, d_analog, d_inp, c->fstride, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks, c->d_vhs_dig);
+                else
+                    hipLaunchKernelGGL((k_vhs_noise<S, false>), dim3((n * c->vhs_chunks + 63) / 64), dim3(64), 0, ns,
+                                       *p, n, d_analog, d_inp, c->fstride, c->d_vhs_hist, c->d_vhs_rows, c->vhs_chunks, c->d_vhs_dig);
+                if (!side) CRT_LAUNCH_TAIL(c->d_vhs_hist);
+#undef CRT_LAUNCH_TAIL
                 if (side) {
                     if (hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess ||
                         hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess ||

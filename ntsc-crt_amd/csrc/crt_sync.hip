@@ -448,7 +448,12 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     __shared__ int s_cnt_[FPB][VPER], s_off_[FPB][VPER];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int f_raw = blockIdx.x * FPB + wv;
+    /* SYNC_SPEC runs as a PERSISTENT grid (crt_run_sync): a few waves per CU walk the fields one after the other, so that the
+     * chain -- latency bound, 10 KB of LDS per field -- occupies a fixed small share of every CU beside the encoder instead of
+     * flooding the chip with one workgroup per field (measured: 1024 workgroups of 48 KB LDS starve k_active of LDS and the
+     * field-pass gets slower, profiles/r04_spec_sync.txt).  The other modes: one workgroup per FPB fields, one trip. */
+  for (int vblock = blockIdx.x; vblock * FPB < n_fields; vblock += (MODE == SYNC_SPEC ? (int) gridDim.x : 0x20000000)) {
+    const int f_raw = vblock * FPB + wv;
     const bool live = f_raw < n_fields;                  /* a wave without a field shadows the last one and stores nothing */
     const int f = live ? f_raw : n_fields - 1;
     int *const s_win = s_win_[wv], *const s_bur = s_bur_[wv];
@@ -514,8 +519,8 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     constexpr int LPF = VPER * CCS;                      /* chain lanes per field */
     const int my_slot = lane / LPF, my_rp = lane - my_slot * LPF;
     const int my_r = my_rp / CCS, my_p = my_rp - my_r * CCS;
-    const bool chain_lane = wv == 0 && my_slot < FPB && blockIdx.x * FPB + my_slot < n_fields;
-    crthip_state *st_chain = state + (chain_lane ? blockIdx.x * FPB + my_slot : 0);
+    const bool chain_lane = wv == 0 && my_slot < FPB && vblock * FPB + my_slot < n_fields;
+    crthip_state *st_chain = state + (chain_lane ? vblock * FPB + my_slot : 0);
     int acc = chain_lane ? st_chain->ccf[my_r][my_p] : 0;
     const bool big = chain_lane && (acc >= (1 << 23) || acc <= -(1 << 23));
     const bool exact_mul = __ballot(big) != 0ull;        /* caller-supplied garbage in ccf: keep the wrapping multiply (wave 0 only) */
@@ -807,13 +812,15 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
         }
     }
     if (MODE == SYNC_SPEC) {
-        if (chain_lane) spec[blockIdx.x * FPB + my_slot].ccf[my_r][my_p] = acc;
+        if (chain_lane) spec[vblock * FPB + my_slot].ccf[my_r][my_p] = acc;
         const bool any_touched = __ballot(touched) != 0ull;
         if (lane == 0 && live) { sp->ok = any_touched ? 0 : 1; sp->vsync = vsync; sp->odd_field = odd_field; sp->hsync = hsync; }
     } else {
         if (chain_lane) st_chain->ccf[my_r][my_p] = acc;
         if (lane == 0 && live) st->hsync = hsync;
     }
+    HSW_SYNC();                                          /* (the next field of a persistent wave reuses the LDS rows) */
+  }
 #undef HSW_SYNC
 }
 
@@ -931,6 +938,18 @@ int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthi
     });
 }
 
+/* workgroups of the speculative pass: at most CRTHIP_SPEC_WAVES (default 2) per CU, each walking several fields */
+static unsigned spec_grid(crthip_ctx *c, unsigned blocks)
+{
+    static int per_cu = -1;
+    if (per_cu < 0) { const char *e = getenv("CRTHIP_SPEC_WAVES"); per_cu = e && atoi(e) > 0 ? atoi(e) : 2; }
+    hipDeviceProp_t prop;
+    static int cus = 0;
+    if (!cus) cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const unsigned cap = (unsigned) (per_cu * cus);
+    return blocks < cap ? blocks : cap;
+}
+
 /* mode: SYNC_FULL, or the two halves of the speculative scheme (see k_hsync_wave): SYNC_SPEC -- on whatever stream c->stream is
  * at the moment, the line table and c->d_spec only -- and SYNC_VERIFY (+ the bloom pass, which reads the picture part) */
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
@@ -953,11 +972,11 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         else {
             bool done = false;
 #define CRT_LAUNCH_HSW(FPB, GRID, BLOCK) do { \
-            if (mode == SYNC_SPEC) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_SPEC>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
+            if (mode == SYNC_SPEC) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_SPEC>), dim3(spec_grid(c, (GRID).x)), BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
             else if (mode == SYNC_VERIFY) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_VERIFY>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
             else hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_FULL>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); } while (0)
             if constexpr (FPB4_OK) {                     /* 4 fields per workgroup share one wave for their burst chains */
-                if (c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {
+                if (mode != SYNC_SPEC && c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {    /* (the speculative pass: a wave per field, persistent) */
                     CRT_LAUNCH_HSW(4, dim3((n + 3) / 4), dim3(256));
                     done = true;
                 }
