@@ -452,7 +452,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
      * chain -- latency bound, 10 KB of LDS per field -- occupies a fixed small share of every CU beside the encoder instead of
      * flooding the chip with one workgroup per field (measured: 1024 workgroups of 48 KB LDS starve k_active of LDS and the
      * field-pass gets slower, profiles/r04_spec_sync.txt).  The other modes: one workgroup per FPB fields, one trip. */
-  for (int vblock = blockIdx.x; vblock * FPB < n_fields; vblock += (MODE == SYNC_SPEC ? (int) gridDim.x : 0x20000000)) {
+  for (int vblock = blockIdx.x; vblock * FPB < n_fields; vblock += (int) gridDim.x) {        /* (the other modes' grids cover every field: one trip) */
     const int f_raw = vblock * FPB + wv;
     const bool live = f_raw < n_fields;                  /* a wave without a field shadows the last one and stores nothing */
     const int f = live ? f_raw : n_fields - 1;
