@@ -70,10 +70,7 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
         const dim3 grid((total + 63) / 64), block(64);
         unsigned char *o = (unsigned char *) d_out;
         ProfScope ps(c, CRTHIP_K_DECODE);
-        static int stagger = -1;                       /* experiment: CRTHIP_DECODE_STAGGER=<periods> (see k_decode) */
-        if (stagger < 0) { const char *e = getenv("CRTHIP_DECODE_STAGGER"); stagger = e ? atoi(e) & 0x7fff : 0; }
-        for (int rank_ = 0; rank_ < passes; rank_++) {
-            const int rank = rank_ | (stagger << 16);
+        for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_DECODE(T, B3) \
     do { if constexpr (S::CCS != 4 && T >= 4) break; /* no FIR build of the 5-sample system */ \
          else if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); \

@@ -212,16 +212,8 @@ template <class S, int TIER, bool BPP3, int PXT, bool BLOOM = false>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
-         int want_rank_, const int *__restrict__ perm)
+         int want_rank, const int *__restrict__ perm)
 {
-    /* bits 16.. of the rank argument: experiment switch CRTHIP_DECODE_STAGGER (crt_decode.hip) -- waves start up to that many
-     * s_sleep(127) periods (3.4 us each) apart, by workgroup index, so that the waves sharing a SIMD do not reach their tile
-     * drains together */
-    const int want_rank = want_rank_ & 0xffff;
-    if (want_rank_ >> 16) {
-        const int k = (int) ((blockIdx.x * 7u) % 16u) * (want_rank_ >> 16) / 16;
-        for (int i = 0; i < k; i++) __builtin_amdgcn_s_sleep(127);
-    }
     constexpr bool FAST = TIER <= 2 || TIER == 4;   /* 24-bit multiplies outside the filter stages */
     constexpr bool FIR = TIER >= 4;
     constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;

@@ -189,7 +189,9 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
     { const char *e = getenv("CRTHIP_SYNC_KERNEL"); c->sync_kernel = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_ROW_TILE"); c->row_tile = e ? atoi(e) : 0; }
-    { const char *e = getenv("CRTHIP_SPEC_SYNC"); c->spec_sync = e ? atoi(e) != 0 : 1; }            /* A/B switch: 0 = the sync chain after the encoder */
+    /* the sync chain beside the encoder (k_hsync_wave SYNC_SPEC / SYNC_VERIFY): off unless asked for -- measured neutral to
+     * slightly negative except for mid-size wide batches (profiles/r04_spec_sync.txt) */
+    { const char *e = getenv("CRTHIP_SPEC_SYNC"); c->spec_sync = e ? atoi(e) != 0 : 0; }
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */

@@ -330,7 +330,7 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
  *      lane that meets the segment's last sample publishes the next window's start and `rn`.
  */
 template <class S, bool MFMA>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
            signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,
            const unsigned *hist, unsigned *hist_out, const unsigned *__restrict__ tail_row, const unsigned *__restrict__ blk_rows,

@@ -318,6 +318,31 @@ class RefCRT:
         return t, m.value, d.value
 
 
+def reads_past_inp(orc, trace, vsync_found, hsync_before):
+    """Does crt_demodulate, for the field whose per-line trace this is, read inp[] beyond the ORC_TAIL bytes behind it?  The
+    reference then reads whatever follows `inp` in struct CRT / the heap (undefined behaviour: the oracle and the library see
+    different bytes there, and so do two runs of the oracle on two machines).  Three reads can run off the end when the sync
+    state is far from lock on the field's last analog line: the hsync search window (crt_core.c:437-445: from ln + hsync +
+    SYNC_BEG - HWIN), the burst samples (:456-467: up to ln + (hsync aligned) + CB_BEG + CB_LEN) and the video window (:452-454,
+    :534: pos + AV_LEN).  trace: Oracle demodulate(trace=True) rows (valid, pos, wave0, wave1, beg, nrows, hsync, dx, scanl)."""
+    sd = orc.sys
+    limit = sd.input_size + ORC_TAIL
+    hs = int(hsync_before)
+    for i in range(trace.shape[0]):
+        if int(trace[i, 0]) != 1:
+            continue                                       # skipped lines (beg >= outh) touch nothing
+        ln = ((sd.top + i + int(vsync_found)) % sd.vres) * sd.hres
+        if ln + hs + sd.sync_beg + sd.hsync_window > limit:
+            return True
+        hs = int(trace[i, 6])
+        ha = hs & ~3 if sd.cc_samples == 4 else hs - hs % sd.cc_samples
+        if ln + ha + sd.cb_beg + sd.cb_len > limit:
+            return True
+        if int(trace[i, 1]) + sd.av_len > limit:
+            return True
+    return False
+
+
 # ----------------------------------------------------------------------------
 # our CPU restatement
 # ----------------------------------------------------------------------------

@@ -107,6 +107,7 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1):
         c.settings(pad, format=ifmt, w=w, h=h, field=fields[k], frame=frames[k], **skw)
         if dot_crawl:
             c.sset("dot_crawl_offset", dcos[k])
+    undefined = [False] * n
     for step in range(steps):
         if fused:
             g.fieldpass(s, noise)
@@ -125,10 +126,16 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1):
         for k, c in enumerate(ocrts):
             what = "%s fused=%s step %d field %d" % (name, fused, step, k)
             c.modulate()
-            if not fused:
+            if not fused and not undefined[k]:
                 np.testing.assert_array_equal(analog[k, :orc.input_size], c.analog, err_msg=what + " analog")
                 np.testing.assert_array_equal(ccf_mod[k, :orc.vper, :orc.ccs], c.ccf, err_msg=what + " ccf after modulate")
+            hs_before = c.get("hsync")
             c.demodulate(noise, trace=True)
+            # a sync state far from lock on the field's last analog line makes the REFERENCE read past inp[] + 16 (heavy noise):
+            # undefined there, different bytes here -- the field is out of the comparison from then on
+            undefined[k] = undefined[k] or R.reads_past_inp(orc, c.trace, c.get("vsync"), hs_before)
+            if undefined[k]:
+                continue
             if not fused:
                 np.testing.assert_array_equal(ginp[k, :orc.input_size], c.inp, err_msg=what + " inp")
                 tr = c.trace
@@ -149,6 +156,7 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1):
             c.sset("field", fields[k])
             c.sset("frame", frames[k])
     g.close()
+    assert not all(undefined), "every field fell into the reference's undefined behaviour: the case checks nothing"
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -1161,11 +1169,10 @@ def test_speculative_sync_commit_and_redo(crtlib, name, n, noise):
             if nes:
                 c.sset("field_initialized", 0)
             c.modulate()
+            hs_before = c.get("hsync")
             c.demodulate(noise, trace=True)
-            tr = c.trace
-            valid = tr[:, 0] == 1
-            if valid.any() and int((tr[valid][:, 1]).max()) + orc.av_len > orc.input_size + R.ORC_TAIL:
-                break                                      # the reference itself reads past inp[] + 16 here (hsync far out on the field's last line): UB, not compared
+            if R.reads_past_inp(orc, c.trace, c.get("vsync"), hs_before):
+                break                                      # the reference itself reads past inp[] + 16 here (sync far out on the field's last analog line): UB, not compared
             checked += 1
             st = outs[1][step][1][k]
             what = "%s noise %d field %d (hsync0 %d vsync0 %d) step %d" % (name, noise, k, hs[k], vs[k], step)
