@@ -329,6 +329,9 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
  *   4. every lane walks its block once more, now producing samples (through LDS byte staging); the
  *      lane that meets the segment's last sample publishes the next window's start and `rn`.
  */
+/* (three waves per SIMD: 168 registers and a few spilled dwords instead of 242.  The kernel runs BESIDE k_vhs_noise, and two of its
+ * waves per SIMD at 242 registers left that kernel none: the two ran one after the other -- 0.41 + 0.46 ms -- whatever the
+ * streams said; at 168 one wave of k_vhs_noise fits next to them: 0.845 -> 0.785 ms for the pair, profiles/r04_experiments.txt) */
 template <class S, bool MFMA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
