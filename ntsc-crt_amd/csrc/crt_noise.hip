@@ -22,16 +22,21 @@ k_noise(const crthip_params P, int n_fields, const signed char *__restrict__ ana
     const v4i in = load16u(src);
     const int wds[4] = { in.x, in.y, in.z, in.w };
     int outw[4];
+    /* LCG step and noise product through the full-rate 64-bit multiply-add (same wrapped 32-bit arithmetic as lcg_step() /
+     * noisy(); v_mul_lo_u32 runs at a quarter of its rate) */
+    v2u lcg_add = { LCG_ADD, 0u };
+    asm volatile("" : "+v"(lcg_add));
+    const int noise = P.noise;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        unsigned o = 0;
+        int v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int s = (wds[d] << (24 - 8 * k)) >> 24;
-            rn = lcg_step(rn);
-            o |= (unsigned) (noisy(s, rn, P.noise) & 255) << (8 * k);
+            const int s = (wds[d] << (24 - 8 * k)) >> 24;
+            rn = lcg_step_mad64(rn, lcg_add);
+            v[k] = clampi(s + (mul_lo_mad64((int) ((rn >> 16) & 0xffu) - 0x7f, noise) >> 8), -127, 127);
         }
-        outw[d] = (int) o;
+        outw[d] = (int) pack4(v[0], v[1], v[2], v[3]);
     }
     if (q * 16 + 16 <= S::INPUT_SIZE) {
         v4i o4; o4.x = outw[0]; o4.y = outw[1]; o4.z = outw[2]; o4.w = outw[3];
