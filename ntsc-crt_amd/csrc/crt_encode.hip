@@ -183,8 +183,6 @@ struct RowTiles {
     const unsigned long long *s_src, *s_dst;
     int lane, prow, piece, oprow, opiece;
     int row_bytes, last_tile, have;
-    int warm;                    /* experiment (CRTHIP_ACTIVE_WARM): tiles ahead whose cache lines are touched early, 0 = off */
-    unsigned *s_warm;            /* 64 dwords of LDS nobody reads: where the touching loads land */
     bool shift8;                 /* alpha-first pixel formats: the colour bytes are moved to bits 0-23 once per tile, here */
     v4i stage[PIECES];
 
@@ -195,7 +193,6 @@ struct RowTiles {
         lane = lane_; prow = lane_ / PIECES; piece = lane_ % PIECES;
         oprow = lane_ / OPIECES; opiece = lane_ % OPIECES;
         shift8 = false;
-        warm = 0; s_warm = nullptr;
         row_bytes = row_bytes_;
         last_tile = (row_bytes_ - 1) / (TILE * 4);
         have = 0;
@@ -210,18 +207,6 @@ struct RowTiles {
         const int off = piece_offset(tile);
 #pragma unroll
         for (int i = 0; i < PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * ROWS + prow] + off);
-    }
-    /* Touch the lines of a tile further ahead, so that its real fetch (one tile before use) finds them in L2: one dword per
-     * 16-byte piece, loaded STRAIGHT INTO LDS (global_load_lds: no destination register whose late arrival could clobber
-     * anything, nothing ever waits for these loads in particular) */
-    __device__ __forceinline__ void touch(int tile)
-    {
-        if (tile > last_tile) return;
-        const int off = piece_offset(tile);
-#pragma unroll
-        for (int i = 0; i < PIECES; i++)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *) (s_src[i * ROWS + prow] + off),
-                                             (void __attribute__((address_space(3))) *) s_warm, 4, 0, 0);
     }
     __device__ __forceinline__ void stash(int tile)
     {
@@ -269,7 +254,6 @@ struct RowTiles {
             stash(need);
             have = need;
             if (need < last_tile) fetch(need + 1);
-            if (warm) touch(need + 1 + warm);
         }
     }
     __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[lane * STRIDE + (idx & (TILE - 1))]; }
@@ -376,9 +360,6 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     __syncthreads();
     T tiles;
     tiles.init(s_pix, s_out, s_src, s_dst, lane, w * 4);
-    __shared__ unsigned s_warm[64];
-    tiles.s_warm = s_warm;
-    tiles.warm = (P.flags >> 28) & 3;                        /* CRTHIP_FDBG_WARM_SHIFT: experiment, set by the host from CRTHIP_ACTIVE_WARM */
 
     if constexpr (S::IS_NES) {
         /* crt_nes.c:162-193, images too narrow for the tile path (k_active_nes otherwise) */
@@ -995,11 +976,6 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
             return;
         }
     }
-    static int warm_env = -1;                                /* experiment: CRTHIP_ACTIVE_WARM=1|2 (RowTiles::touch) */
-    if (warm_env < 0) { const char *e = getenv("CRTHIP_ACTIVE_WARM"); warm_env = e ? atoi(e) & 3 : 0; }
-    crthip_params pw = *p;
-    pw.flags = (pw.flags & ~(3 << 28)) | (warm_env << 28);
-    p = &pw;
     const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
     const bool wide_in = c->ac_tile_env ? c->ac_tile_env == 32 : c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
