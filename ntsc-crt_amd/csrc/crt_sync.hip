@@ -938,11 +938,12 @@ int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthi
     });
 }
 
-/* workgroups of the speculative pass: at most CRTHIP_SPEC_WAVES (default 2) per CU, each walking several fields */
+/* workgroups of the speculative pass: at most CRTHIP_SPEC_WAVES (default 4: the chain of 4096 fields then finishes under the
+ * encoder; 2 do not, profiles/r04_spec_sync.txt) per CU, each walking several fields */
 static unsigned spec_grid(crthip_ctx *c, unsigned blocks)
 {
     static int per_cu = -1;
-    if (per_cu < 0) { const char *e = getenv("CRTHIP_SPEC_WAVES"); per_cu = e && atoi(e) > 0 ? atoi(e) : 2; }
+    if (per_cu < 0) { const char *e = getenv("CRTHIP_SPEC_WAVES"); per_cu = e && atoi(e) > 0 ? atoi(e) : 4; }
     hipDeviceProp_t prop;
     static int cus = 0;
     if (!cus) cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
