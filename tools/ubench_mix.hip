@@ -141,6 +141,50 @@ __global__ void k_stage64_ind(int *out, int c, int u)
     out[blockIdx.x * blockDim.x + threadIdx.x] = (int) ((x0 ^ x1 ^ x2 ^ x3) >> 32);
 }
 
+// round 4: the same four filter stages on PACKED 16-bit state -- two independent cascades (a, b) share the registers X0 = {a0, b0},
+// X1 = {a1, b1}; a stage pair is v_pk_sub_i16, two v_mad_i32_i16 (op_sel picks the half; the addend carries the rounding constant),
+// v_perm_b32 of the two high words, v_pk_add_i16: 10 instructions for what stage64_* does in 12
+#define PKSUB(d, a, b) asm volatile("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define PKADD(d, a, b) asm volatile("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define MAD16LO(d, a, c, k) asm volatile("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(c), "v"(k))
+#define MAD16HI(d, a, c, k) asm volatile("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(c), "v"(k))
+#define PERMHI(d, b, a, sel) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "v"(sel))
+__global__ void k_stage16_pk(int *out, int c, int u)
+{
+    int x0 = threadIdx.x, x1 = x0 + 1, d, ra, rb, t, vc = c, vk = 32768, sel = 0x07060302, vu = u + (threadIdx.x & 3);
+    for (int i = 0; i < ITERS; i++) {
+        // two iterations' worth per loop trip would change nothing: the chain X0 -> X1 is the dependency that counts
+        PKSUB(d, vu, x0); MAD16LO(ra, d, vc, vk); MAD16HI(rb, d, vc, vk); PERMHI(t, rb, ra, sel); PKADD(x0, x0, t);
+        PKSUB(d, x0, x1); MAD16LO(ra, d, vc, vk); MAD16HI(rb, d, vc, vk); PERMHI(t, rb, ra, sel); PKADD(x1, x1, t);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1;
+}
+// ... and the form with SDWA adds writing the halves directly (no permute): pk_sub, 2 x mad, 2 x v_add_u32_sdwa
+#define ADDHI_LO(x, r) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(x) : "v"(r))
+#define ADDHI_HI(x, r) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(x) : "v"(r))
+__global__ void k_stage16_sdwa(int *out, int c, int u)
+{
+    int x0 = threadIdx.x, x1 = x0 + 1, d, ra, rb, vc = c, vk = 32768, vu = u + (threadIdx.x & 3);
+    for (int i = 0; i < ITERS; i++) {
+        PKSUB(d, vu, x0); MAD16LO(ra, d, vc, vk); MAD16HI(rb, d, vc, vk); ADDHI_LO(x0, ra); ADDHI_HI(x0, rb);
+        PKSUB(d, x0, x1); MAD16LO(ra, d, vc, vk); MAD16HI(rb, d, vc, vk); ADDHI_LO(x1, ra); ADDHI_HI(x1, rb);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1;
+}
+// the dot2 form of ONE cascade on {input, state} pairs: v_dot2_i32_i16 (c * u - c * x + K in one instruction), two SDWA adds
+#define DOT2(d, a, c, k) asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(c), "v"(k))
+__global__ void k_stage16_dot2(int *out, int c, int u)
+{
+    int r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = 0, d, vc = (c & 0xffff) | (-c << 16), vk = 32768;
+    for (int i = 0; i < ITERS; i++) {
+        DOT2(d, r0, vc, vk); ADDHI_HI(r0, d); ADDHI_LO(r1, d);
+        DOT2(d, r1, vc, vk); ADDHI_HI(r1, d); ADDHI_LO(r2, d);
+        DOT2(d, r2, vc, vk); ADDHI_HI(r2, d); ADDHI_LO(r3, d);
+        DOT2(d, r3, vc, vk); ADDHI_HI(r3, d); ADDHI_LO(r4, d);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4;
+}
+
 template <class K> void run(const char *name, K kern, int *d, int per_iter)
 {
     hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
@@ -171,5 +215,8 @@ int main()
     run("stage64_seq", k_stage64_seq, d, 12);
     run("stage64_ind", k_stage64_ind, d, 12);
     run("stage64_grp", k_stage64_grp, d, 12);
+    run("stage16_pk", k_stage16_pk, d, 10);          // 4 stages in 10 instructions: multiply cycles/instr by 10 (vs 12 for stage64_*)
+    run("stage16_sdwa", k_stage16_sdwa, d, 10);
+    run("stage16_dot2", k_stage16_dot2, d, 12);
     return 0;
 }
