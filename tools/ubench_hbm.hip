@@ -243,6 +243,38 @@ __global__ void __launch_bounds__(64) k_rows_wide(v4i *p, size_t pitch16, int li
         }
 }
 
+// round 4: MIMIC of a decoder wave -- the store pattern of k_rows_wide with `valu` dependent integer instructions (three chains of
+// sub / add / 24-bit multiply-add, the decoder's mix) in front of every tile's stores, at the occupancy the real kernel would have
+// (dynamic LDS sized by the caller).  Question: does a wave that owns 16 lines, writes 1 KB runs and spends 35 % more vector
+// instructions per line beat one that owns 64 lines and writes 128-byte runs -- with the vector work in the picture?
+template <int LPW, int RUN16>
+__global__ void __launch_bounds__(64) k_mimic(v4i *p, size_t pitch16, int lines_per_pic, int rows_per_pic, int n_pics, int valu, int *sink)
+{
+    extern __shared__ int s_pad[];
+    const int lane = threadIdx.x;
+    const size_t wave = blockIdx.x;
+    constexpr int ROWS_PER_INSTR = 64 / RUN16;
+    const int sub = lane / RUN16, piece = lane % RUN16;
+    int a = lane, b = lane * 3 + 1, c = lane ^ 5, k1 = 40503, k2 = 7;
+    for (size_t x = 0; x + RUN16 <= pitch16; x += RUN16) {
+        for (int i = 0; i < valu; i += 9) {
+            asm volatile("v_sub_u32 %0, %1, %0\n\tv_add_u32 %0, %0, %2\n\tv_mad_i32_i24 %0, %0, %3, %1\n\t"
+                         "v_sub_u32 %4, %1, %4\n\tv_add_u32 %4, %4, %2\n\tv_mad_i32_i24 %4, %4, %3, %1\n\t"
+                         "v_sub_u32 %5, %1, %5\n\tv_add_u32 %5, %5, %2\n\tv_mad_i32_i24 %5, %5, %3, %1"
+                         : "+v"(a), "+v"(k2), "+v"(k1), "+v"(k1), "+v"(b), "+v"(c));
+        }
+        v4i v = { a, b, c, 4 };
+        for (int i = 0; i < LPW; i += ROWS_PER_INSTR) {
+            const size_t line = wave * LPW + i + sub, pic = line / lines_per_pic, l = line % lines_per_pic;
+            if (pic >= (size_t) n_pics) continue;
+            const int dups = 3 + (int) (l & 1);
+            v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + x + piece;
+            for (int d = 0; d < dups; d++) __builtin_nontemporal_store(v, row + (size_t) d * pitch16);
+        }
+    }
+    if (a == 0x7fffffff) { s_pad[lane] = a; *sink = s_pad[63 - lane]; }
+}
+
 static hipEvent_t e0, e1;
 template <class F> static double best_ms(F launch, int iters = 5)
 {
@@ -353,6 +385,22 @@ int main(int argc, char **argv)
             WIDE(16, 64, true, "16 lines/wave, whole rows at once");
             WIDE(4, 64, true, "4 lines/wave, whole rows at once");
             WIDE(1, 64, true, "1 line/wave, whole rows at once");
+        }
+        {
+            // 2048 pictures like the bench's 1080p batch (13.2 GB of stores)
+            const int mp = 2048;
+            const double gbm = (double) mp * 240 * 3.5 * 7680.0 / 1e9;
+#define MIMIC(LPW, RUN16, VALU, LDSB, name) do { const double ms = best_ms([&] { \
+            hipLaunchKernelGGL((k_mimic<LPW, RUN16>), dim3((mp * 240 + LPW - 1) / LPW), dim3(64), LDSB, 0, a, pitch16, 240, 1080, mp, VALU, o); }, 3); \
+            printf("%-6s %-70s %8.3f ms  %8.1f GB/s\n", "mimic", name, ms, gbm / (ms * 1e-3)); } while (0)
+            MIMIC(64, 8, 0, 14080, "64 lines/wave, 128 B runs, stores only, 11 waves/CU");
+            MIMIC(64, 8, 1670, 14080, "64 lines/wave, 128 B runs, 1670 VALU/tile (100 k/wave), 11 waves/CU  [= today]");
+            MIMIC(64, 8, 1670, 9984, "64 lines/wave, 128 B runs, 1670 VALU/tile, 16 waves/CU");
+            MIMIC(16, 64, 0, 17408, "16 lines/wave, 1 KB runs, stores only, 9 waves/CU");
+            MIMIC(16, 64, 4500, 17408, "16 lines/wave, 1 KB runs, 4500 VALU/tile (34 k/wave = +35 % per line), 9 waves/CU  [= the wide-run decoder]");
+            MIMIC(16, 64, 3330, 17408, "16 lines/wave, 1 KB runs, 3330 VALU/tile (25 k/wave = today's per line), 9 waves/CU");
+            MIMIC(16, 64, 4500, 10240, "16 lines/wave, 1 KB runs, 4500 VALU/tile, 16 waves/CU");
+            MIMIC(32, 64, 9000, 20480, "32 lines/wave, 1 KB runs, 9000 VALU/tile (68 k/wave), 8 waves/CU");
         }
         // dense pictures (no skipped rows: 960-row pictures)
         printf("%-6s %-44s %8.1f GB/s\n", "rowsv", "baseline, dense 960-row pictures", gb / (best_ms([&] { hipLaunchKernelGGL((k_rows_var<0>), dim3(waves), dim3(64), 0, 0, a, pitch16, 240, dups, 960, pics, waves); }) * 1e-3));
