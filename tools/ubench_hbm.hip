@@ -387,8 +387,8 @@ int main(int argc, char **argv)
             WIDE(1, 64, true, "1 line/wave, whole rows at once");
         }
         {
-            // 2048 pictures like the bench's 1080p batch (13.2 GB of stores)
-            const int mp = 2048;
+            // 1536 pictures (9.9 GB of stores; the bench batch of 2048 would be 13.2 GB)
+            const int mp = pics < 1536 ? pics : 1536;          // (the 12 GiB buffer holds 1553 pictures of 1080 rows; the bench batch is 2048)
             const double gbm = (double) mp * 240 * 3.5 * 7680.0 / 1e9;
 #define MIMIC(LPW, RUN16, VALU, LDSB, name) do { const double ms = best_ms([&] { \
             hipLaunchKernelGGL((k_mimic<LPW, RUN16>), dim3((mp * 240 + LPW - 1) / LPW), dim3(64), LDSB, 0, a, pitch16, 240, 1080, mp, VALU, o); }, 3); \
