@@ -60,6 +60,7 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
      * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
     const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
     const bool wide = c->px_tile ? c->px_tile >= 32 : p->outw >= 1280;
+    const bool use_wide = crt_decode_wide_ok(c, p, min_tier, wide);
     /* lines per output row when the picture is shorter than the raster: one pass per rank */
     const unsigned span = (unsigned) p->outh + p->v_fac;
     const int passes = span >= (unsigned) c->sd.lines ? 1 : (int) (((unsigned) c->sd.lines + span - 1) / (span ? span : 1));
@@ -75,6 +76,15 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
     do { if constexpr (S::CCS != 4 && T >= 4) break; /* no FIR build of the 5-sample system */ \
          else if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); \
          else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); } while (0)
+            /* wide pictures in tiers 0 / 1: the 16-scanlines-per-wave kernel with 1 KB row runs (crt_decode4.hip); the groups
+             * of the higher tiers stay with k_decode below */
+            if (use_wide) {
+                const int rc = crt_run_decode_wide(c, p, n, d_inp, d_lines, d_out, ostride, min_tier, rank);
+                if (rc) return rc;
+                CRTHIP_LAUNCH_DECODE(2, false);
+                CRTHIP_LAUNCH_DECODE(3, false);
+                continue;
+            }
             /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */
             if (p->out_bpp == 3) {
                 if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, true);

@@ -1,0 +1,237 @@
+/* crt_decode4.hip -- D8-D10 for WIDE pictures: 16 scanlines per wavefront, the four filter cascades of a scanline on four
+ * lanes, pixels emitted lane-per-pixel in 1 KB runs of one picture row.  See crt_dev.h / crt_decode_lane.h for the
+ * lane-per-scanline decoder (the throughput shape at 640x480) and crt_decode2.hip for the scanline-parallel one (small batches).
+ *
+ * Why a third shape (round 4; profiles/r04_store_patterns.txt, r04_experiments.txt section 9).  At 1920x1080 the decoder is bound
+ * by its picture stores -- 6.5 MB per field, rows duplicated 3-4 times (crt_core.c:661-664).  A lane-per-scanline wave owns 64
+ * scanlines = 288 picture rows and can only buffer 32 pixels of each before it has to store: 128-byte runs, for which the memory
+ * system gives 5.2 TB/s; for 1 KB runs it gives 5.85.  Emitting a 256-pixel run needs ~100 samples of y/i/q of that scanline at
+ * once, i.e. 800 bytes of LDS per scanline -- 51 KB for 64 scanlines.  So this kernel takes 16 scanlines per wave and gets its
+ * 64 lanes busy in the filter stage by giving every scanline FOUR lanes, one per cascade that tiers 0 / 1 run (luma low, luma
+ * high, I high, Q high: crt_decode_lane.h, eq_step64 -- four independent chains of four one-pole stages): a lane runs 12
+ * stage instructions per sample instead of 48, the band sums (crt_core.c:218-232) are formed with one quad DPP exchange, and
+ * every lane files its result into the scanline's y/i/q ring in LDS with one 16-bit store at its own offset.  The pixel stage then
+ * walks the 16 scanlines one after the other, lane = four consecutive pixels: ppos, the two taps from the ring, the same
+ * packed-chroma / v_dot2 / 64-bit-mad arithmetic as the lane-per-scanline decoder (crt_core.c:555-562), one 16-byte store per lane
+ * = 1 KB of ONE row per instruction, repeated for the duplicated rows.  About 35 % more vector instructions per scanline than the
+ * lane-per-scanline kernel (the per-lane input and band-sum work is done four times), which the decoder mimic prices at +15 %
+ * throughput all the same.
+ *
+ * Scope: the 4-samples-per-cycle systems, tiers 0 / 1 (what a wide picture at ordinary knobs runs in), 4-byte pixel formats, no
+ * blend, no bloom, a resampler step small enough for the ring (outw >= ~1650).  Everything else stays with k_decode; the tier of a
+ * 64-scanline group is decided exactly as there, so the two kernels partition the batch between them.  Same arithmetic, bit for
+ * bit (tests/test_gpu_parity.py: every 1080p case runs through here).
+ */
+#include "crt_decode_lane.h"
+
+#define WIDE_LPW   16                 /* scanlines per wave */
+#define WIDE_RING  128                /* samples per scanline in the y/i/q ring */
+#define WIDE_PXT   256                /* pixels per row run: 64 lanes x 4 */
+
+/* v_mad_i64_i32 with a per-lane multiplier */
+__device__ __forceinline__ long mad64_vv(int d, int m, long acc)
+{
+    long r, carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(d), "v"(m), "v"(acc));
+    return r;
+}
+
+template <class S, int TIER>
+__global__ void __launch_bounds__(64)
+k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
+              const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
+              int want_rank, int n_px, unsigned ppos_end)
+{
+    static_assert(S::CCS == 4 && TIER <= 1, "tiers 0 / 1 of the 4-samples-per-cycle systems");
+    constexpr int LPW = WIDE_LPW, RING = WIDE_RING;
+    constexpr int IN_DW = 16, IN_STRIDE = IN_DW + 1;
+    __shared__ unsigned s_in[LPW * IN_STRIDE];                 /* input tile: 64 samples per scanline */
+    __shared__ unsigned long long s_ring[LPW * RING];          /* y/i/q ring, entry = halves { y, -, q, i } */
+
+    const int lane = threadIdx.x, l = lane >> 2, c = lane & 3; /* my scanline of the wave, my cascade */
+    const int total = n_fields * S::LINES;
+    {
+        /* the tier of the 64-scanline group my scanlines belong to: the decision of k_decode, flag for flag */
+        const int g = (int) (blockIdx.x * LPW) / 64 * 64 + lane;
+        int fl = 0;
+        if (g < total) fl = lines[g].nrows;
+        int tier = __ballot(fl & CRTHIP_LINE_EXACT) ? 3 : __ballot(fl & CRTHIP_LINE_NOT64) ? 2 : __ballot(fl & CRTHIP_LINE_WIDE) ? 1 : 0;
+        if (tier < 2 && __ballot(fl & (int) CRTHIP_LINE_KEEPLO) != 0ull) tier = 2;
+        if (tier < min_tier) tier = min_tier;
+        if (tier != TIER) return;
+    }
+    const int gl = blockIdx.x * LPW + l;
+    const bool live = gl < total;
+    crthip_line lp;
+    lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0; lp.dx = 0; lp.scanl = 0;
+    if (live) lp = lines[gl];
+    int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
+    if (!live || ((lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK) != want_rank) nrows = 0;
+    if (__ballot(nrows > 0) == 0ull) return;
+    const int f = live ? gl / S::LINES : 0;
+    const size_t pitch = (size_t) P.outw * 4;
+    const unsigned long long src = (unsigned long long) (inp + (size_t) f * fstride + (nrows > 0 ? lp.pos : 0));
+    const unsigned long long dst = (unsigned long long) (outp + (size_t) f * ostride + (size_t) (nrows > 0 ? lp.beg : 0) * pitch);
+
+    /* my cascade: input multiplier by sample phase (luma: 2^16, i.e. the sample itself; chroma: the demodulation carriers << 7,
+     * crt_core.c:476-479, 541-542), input offset, stage multiplier and form (eq_step64: coefficients >= 2^15 take x' = u + ...),
+     * top-band gain, output shift */
+    const int w0 = lp.wave0 * 128, w1 = lp.wave1 * 128;
+    int wk[4];
+    wk[0] = c < 2 ? 65536 : c == 2 ? w0 : -w1;
+    wk[1] = c < 2 ? 65536 : c == 2 ? w1 : w0;
+    wk[2] = c < 2 ? 65536 : c == 2 ? -w0 : w1;
+    wk[3] = c < 2 ? 65536 : c == 2 ? -w1 : -w0;
+    const int bl = c < 2 ? P.bright : 0;
+    const bool near1 = c < 2;
+    const int M = c == 0 ? (P.eq_lf[0] - 65536) * 65536 : c == 1 ? (P.eq_hf[0] - 65536) * 65536 : c == 2 ? P.eq_hf[1] * 65536 : P.eq_hf[2] * 65536;
+    const int g2 = c == 1 ? 9175 : c == 2 ? 1311 : 0;          /* crt_core.c:272-286 (the host refuses other gains) */
+    const int sh = c == 1 ? 0 : 3;                             /* luma stays unshifted (see k_decode, D9), chroma >> 3 */
+    /* where my result goes in the ring entry (in halves): y 0, q 2, i 3; the luma-low lane writes the unused half */
+    const int hoff = c == 1 ? 0 : c == 0 ? 1 : c == 3 ? 2 : 3;
+    unsigned short *const ring_h = (unsigned short *) s_ring + (size_t) l * RING * 4 + hoff;
+
+    int x0 = 0, x1 = 0, x2 = 0, x3 = 0;                        /* my four stages */
+    int h0 = 0, h1 = 0, h2 = 0;                                /* my input history (top band, crt_core.c:229-231) */
+
+    const unsigned dx = (unsigned) P.dx;
+    const int contrast12 = P.contrast * 4096;
+    long alpha_pair = (long) 0xff00ul << 32;
+    asm volatile("" : "+v"(alpha_pair));
+    const unsigned psel = pack_selector(P.out_format);
+
+    constexpr int NQ = (S::AV_LEN + 3) / 4, NT = (NQ + IN_DW - 1) / IN_DW;
+    v4i nxt = gload16u(src + c * 16);                          /* input tile 0: lane (l, c) moves piece c of scanline l */
+    int have_tile = -1;
+    int xq = 0;                                                /* next dword of samples to filter (wave-uniform) */
+
+    for (int px0 = 0; px0 < n_px; px0 += WIDE_PXT) {
+        /* ---- filter: every sample the run's pixels need (taps idx and idx + 1, crt_core.c:555-558) ---- */
+        const int pxl = px0 + WIDE_PXT - 1 < n_px - 1 ? px0 + WIDE_PXT - 1 : n_px - 1;
+        const int x_need = (int) (((unsigned) pxl * dx) >> 12) + 2;
+        while (xq * 4 < x_need && xq < NQ) {
+            const int t = xq >> 4;
+            if (t != have_tile) {
+                wave_lds_fence();
+                unsigned *d = s_in + l * IN_STRIDE + c * 4;
+                d[0] = (unsigned) nxt.x; d[1] = (unsigned) nxt.y; d[2] = (unsigned) nxt.z; d[3] = (unsigned) nxt.w;
+                wave_lds_fence();
+                have_tile = t;
+                if (t + 1 < NT) nxt = gload16u(src + (t + 1) * (IN_DW * 4) + c * 16);
+            }
+            const int word = (int) s_in[l * IN_STRIDE + (xq & (IN_DW - 1))];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = xq * 4 + k;
+                const int s = (word << (24 - 8 * k)) >> 24;
+                /* my cascade's input: s + bright | (s * wave) >> 9, as the high word of the product with the pre-scaled multiplier */
+                const int ut = TIER == 0 ? __mul24(s, wk[k]) : mul_lo_mad64(s, wk[k]);
+                const int u = add_hiword(bl, ut);
+                /* four stages, eq_step64: x' = hi32(M * (in - x) + {2^31, near1 ? in : x}) */
+#define WIDE_STAGE(X, IN) X = hi32(mad64_vv((IN) - X, M, pair_of(near1 ? (IN) : X)))
+                WIDE_STAGE(x0, u);
+                WIDE_STAGE(x1, x0);
+                WIDE_STAGE(x2, x1);
+                WIDE_STAGE(x3, x2);
+#undef WIDE_STAGE
+                /* band sums (crt_core.c:218-232; eq_step64 / eq_step64_chroma): top band on my own history; the luma-high lane
+                 * takes the luma-low lane's output from its left neighbour in the quad, the others take themselves (difference 0) */
+                const int r = x3 + (__mul24(h2 - x3, g2) >> 16);
+                h2 = h1; h1 = h0; h0 = u;
+                const int nb = __builtin_amdgcn_update_dpp(x3, x3, 0xe0 /* quad_perm:[0,0,2,3] */, 0xf, 0xf, false);
+                const int tt = x3 - nb;
+                const int out = (r - tt + (tt >> 3)) >> sh;
+                ring_h[(x & (RING - 1)) * 4] = (unsigned short) out;
+            }
+            xq++;
+        }
+        wave_lds_fence();
+        /* ---- pixels: scanline after scanline, lane = four consecutive pixels of the run ---- */
+        const int px = px0 + 4 * lane;
+        for (int ll = 0; ll < LPW; ll++) {
+            const int nr = __builtin_amdgcn_readlane(nrows, 4 * ll);
+            if (nr == 0) continue;
+            const unsigned dlo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) dst, 4 * ll);
+            const unsigned dhi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (dst >> 32), 4 * ll);
+            const unsigned long long drow = ((unsigned long long) dhi << 32 | dlo) + (unsigned long long) px * 4;
+            const uint2 *ring = (const uint2 *) (s_ring + ll * RING);
+            unsigned ppos = __umul24((unsigned) px, dx);       /* px < 2^24, dx < 2^24 (host-checked) */
+            unsigned v[4];
+            int have = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool ok = px + j < n_px && ppos < ppos_end;
+                const unsigned idx = ppos >> 12;
+                const int R4 = (int) ((ppos & 0xfffu) << 2), L4 = 0x3ffc - R4;
+                const uint2 e0 = ring[idx & (RING - 1)], e1 = ring[(idx + 1) & (RING - 1)];
+                const int py = (int) (short) e0.x, cy = (int) (short) e1.x;
+                const int pq = (int) (short) e0.y, pi = (int) e0.y >> 16, cq = (int) (short) e1.y, ci = (int) e1.y >> 16;
+                /* crt_core.c:556-562 exactly as in k_decode (tiers 0 / 1): weights scaled by 4, chroma packed, one v_dot2 per
+                 * colour row, contrast as a pre-shifted 64-bit multiply-add with the alpha riding on the red row */
+                const int yy = __mul24(cy, R4) + __mul24(py, L4);
+                int iq = add_hiwords(__mul24(pq, L4), __mul24(cq, R4));
+                iq = add_hiwords_to_hi(iq, __mul24(pi, L4), __mul24(ci, R4));
+                const int vr = dot2_vs(iq, (3879 << 16) | 2556, yy);
+                const int vg = dot2_vs(iq, (int) (((unsigned) -1126 << 16) | ((unsigned) -2605 & 0xffffu)), yy);
+                const int vb = dot2_vs(iq, (int) (((unsigned) -4530 << 16) | 7021u), yy);
+                int r8 = pair_hi(mad64_vs(vr & ~0xfff, contrast12, alpha_pair));
+                int g8 = pair_hi(mad64_vs0(vg & ~0xfff, contrast12));
+                int b8 = pair_hi(mad64_vs0(vb & ~0xfff, contrast12));
+                r8 = clampi(r8, 0xff00, 0xffff); g8 = clampi(g8, 0, 255); b8 = clampi(b8, 0, 255);
+                unsigned rgb = lshl_or(lshl_or((unsigned) r8, 8, (unsigned) g8), 8, (unsigned) b8);       /* 0xffRRGGBB */
+                if (psel != 0x03020100u) rgb = __builtin_amdgcn_perm(rgb, rgb, psel);
+                v[j] = rgb;
+                have += ok ? 1 : 0;                            /* (valid pixels are a prefix: ppos grows) */
+                ppos += dx;
+            }
+            if (have > 0) {
+                for (int dup = 0; dup < nr; dup++) {
+                    const unsigned long long dd = drow + (size_t) dup * pitch;
+                    if (have >= 4) {
+                        v4i o; o.x = (int) v[0]; o.y = (int) v[1]; o.z = (int) v[2]; o.w = (int) v[3];
+                        gstore16u_nt(dd, o);
+                    } else {
+                        gstore32(dd, v[0]);
+                        if (have > 1) gstore32(dd + 4, v[1]);
+                        if (have > 2) gstore32(dd + 8, v[2]);
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+/* the configurations this kernel takes (everything else: k_decode) */
+bool crt_decode_wide_ok(const crthip_ctx *c, const crthip_params *p, int min_tier, bool wide)
+{
+    static int env = -1;                                       /* CRTHIP_WIDE_DECODE=0: A/B switch */
+    if (env < 0) { const char *e = getenv("CRTHIP_WIDE_DECODE"); env = e ? atoi(e) != 0 : 1; }
+    if (!env || !wide || c->sd.cc_samples != 4 || p->out_bpp != 4 || p->blend || p->bloom || p->eq_kernel || min_tier > 1) return false;
+    if (p->dx <= 0 || p->dx >= (1 << 24) || p->outw >= (1 << 22)) return false;
+    /* a run of 256 pixels must fit the ring with the filter's look-ahead: taps up to ((255 dx) >> 12) + 1 samples apart + 3 */
+    return ((255ll * p->dx) >> 12) + 8 <= WIDE_RING;
+}
+
+int crt_run_decode_wide(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, const crthip_line *d_lines,
+                        void *d_out, size_t ostride, int min_tier, int rank)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        if constexpr (S::CCS == 4) {
+            const int total = n * S::LINES;
+            const dim3 grid((total + WIDE_LPW - 1) / WIDE_LPW), block(64);
+            /* pixels the reference emits per scanline: px * dx < min(dx * outw, (AV_LEN - 1) << 12)  (crt_core.c:528-531, 555) */
+            const unsigned long long all = (unsigned long long) (unsigned) p->dx * (unsigned) p->outw;
+            const unsigned scan_r = (unsigned) (S::AV_LEN - 1) << 12;
+            const unsigned ppos_end = all < scan_r ? (unsigned) all : scan_r;
+            const int n_px = (int) ((ppos_end + (unsigned) p->dx - 1) / (unsigned) p->dx);
+            if (min_tier <= 0)
+                hipLaunchKernelGGL((k_decode_wide<S, 0>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
+                                   min_tier, rank, n_px, ppos_end);
+            hipLaunchKernelGGL((k_decode_wide<S, 1>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
+                               min_tier, rank, n_px, ppos_end);
+        }
+        return CRTHIP_OK;
+    });
+}

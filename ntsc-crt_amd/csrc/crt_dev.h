@@ -594,6 +594,9 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
                  crthip_line *d_lines, int advance_rn, int mode = 0);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride);
+bool crt_decode_wide_ok(const crthip_ctx *c, const crthip_params *p, int min_tier, bool wide);
+int crt_run_decode_wide(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, const crthip_line *d_lines,
+                        void *d_out, size_t ostride, int min_tier, int rank);
 int crt_reserve_bloom(crthip_ctx *c, int n);
 int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                                const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier);

@@ -186,6 +186,61 @@ def test_fir_decoder_outside_the_24bit_envelope(crtlib, knobs):
     _run_case(crtlib, ("ntscfir7", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1), knobs), fused=True, steps=2)
 
 
+WIDE_CASES = [
+    # name, outw, outh, ofmt, w, h, ifmt, noise, settings, knobs -- pictures the 16-scanlines-per-wave decoder takes (crt_decode4.hip)
+    ("ntsc", 1920, 1080, R.FMT_BGRA, 1920, 1080, R.FMT_BGRA, 0, dict(as_color=1), dict(scanlines=1)),
+    ("ntsc", 1920, 1080, R.FMT_ARGB, 640, 480, R.FMT_RGB, 24, dict(as_color=1, hue=40), dict(scanlines=0, hue=-20, saturation=14)),
+    ("ntsc", 2047, 777, R.FMT_ABGR, 333, 100, R.FMT_ABGR, 60, dict(as_color=0), dict(scanlines=1, v_fac=100, brightness=12, contrast=250)),
+    ("ntsc", 1700, 300, R.FMT_RGBA, 1281, 601, R.FMT_BGRA, 12, dict(as_color=1, raw=1), dict(scanlines=1, black_point=-5, white_point=120)),
+    ("snes", 1920, 1080, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(scanlines=1)),
+    ("temp", 1664, 1248, R.FMT_BGRA, 832, 624, R.FMT_BGRA, 0, dict(as_color=1), dict(scanlines=1)),
+    ("ntscp0", 1920, 1200, R.FMT_BGRA, 1920, 1080, R.FMT_RGBA, 24, dict(as_color=1), dict(scanlines=1)),
+    # strong carriers: some 64-scanline groups leave tiers 0 / 1 and stay with the lane-per-scanline kernel, their neighbours do not
+    ("ntsc", 1920, 1080, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 24, dict(as_color=1), dict(scanlines=1, saturation=25)),
+    ("ntsc", 1920, 1080, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 40, dict(as_color=1), dict(scanlines=1, saturation=60, contrast=300)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(WIDE_CASES)))
+def test_wide_decoder_parity(crtlib, case):
+    """crt_decode4.hip (round 4): 16 scanlines per wave, a scanline's four filter cascades on four lanes, pixels lane-per-pixel in
+    1 KB row runs -- fused, three steps, every field against the oracle (out, state, ccf)"""
+    _run_case(crtlib, WIDE_CASES[case], fused=True, steps=3, n=5)
+
+
+@pytest.mark.parametrize("case", [0, 1, 7])
+def test_wide_decoder_stagewise_and_tiers(crtlib, case):
+    """... stage by stage (line table compared too), and with the decoder tiers forced: tier 1 runs in the wide kernel,
+    tiers 2 / 3 hand the whole batch back to the lane-per-scanline kernel"""
+    _run_case(crtlib, WIDE_CASES[case], fused=False, steps=2, n=3)
+    for mode in (1, 2, 3):
+        _run_case(crtlib, WIDE_CASES[case], fused=True, exact=mode, steps=1, n=2)
+
+
+def test_wide_decoder_against_the_lane_per_scanline_decoder(crtlib):
+    """the two decoders on the same batch (100 fields of 1920x1080, both parities): byte-identical pictures.  crthip_set_pixel_tile(16)
+    keeps the batch on k_decode (a narrow pixel tile is no wide picture to the dispatcher)."""
+    import torch
+    n, w, h = 100, 1920, 1080
+    base = np.stack([R.synth_image(w, h, 4, 8300 + k, "bars" if k & 1 else "random") for k in range(4)])
+    imgs = torch.from_numpy(np.concatenate([base, base[:, -1:]], axis=1)).to("cuda:0")
+    data = imgs.repeat(n // 4, 1, 1, 1)[:, :h]
+    outs = []
+    for tile in (0, 16):
+        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+        g.scanlines = 1
+        g.set_shape(1)
+        g.set_pixel_tile(tile)
+        s = crtlib.Settings(data, format=crtlib.FMT_BGRA, field=[(k // 4) & 1 for k in range(n)], frame=0)
+        for step in range(2):
+            g.fieldpass(s, 7)
+        g.synchronize()
+        outs.append((g.out.clone(), g.state.clone()))
+        g.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert int(outs[0][0].to(torch.int64).sum().item()) > 0
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("case", [1, 2, 3, 5])
 def test_slower_decoder_tiers_parity(crtlib, case, mode):
