@@ -10,12 +10,15 @@
  * 64 lanes busy in the filter stage by giving every scanline FOUR lanes, one per cascade that tiers 0 / 1 run (luma low, luma
  * high, I high, Q high: crt_decode_lane.h, eq_step64 -- four independent chains of four one-pole stages): a lane runs 12
  * stage instructions per sample instead of 48, the band sums (crt_core.c:218-232) are formed with one quad DPP exchange, and
- * every lane files its result into the scanline's y/i/q ring in LDS with one 16-bit store at its own offset.  The pixel stage then
- * walks the 16 scanlines one after the other, lane = four consecutive pixels: ppos, the two taps from the ring, the same
- * packed-chroma / v_dot2 / 64-bit-mad arithmetic as the lane-per-scanline decoder (crt_core.c:555-562), one 16-byte store per lane
- * = 1 KB of ONE row per instruction, repeated for the duplicated rows.  About 35 % more vector instructions per scanline than the
- * lane-per-scanline kernel (the per-lane input and band-sum work is done four times), which the decoder mimic prices at +15 %
- * throughput all the same.
+ * every lane files its result into the scanline's rings in LDS with one 16-bit store at its own offset.  The pixel stage then
+ * walks the 16 scanlines one after the other, lane = four consecutive pixels: the two taps from the rings (offsets and weights
+ * computed once per run: they do not depend on the scanline), the same packed-chroma / v_dot2 / 64-bit-mad arithmetic as the
+ * lane-per-scanline decoder (crt_core.c:555-562), one 16-byte store per lane = 1 KB of ONE row per instruction, repeated for the
+ * duplicated rows.
+ *
+ * Measured (profiles/r04_experiments.txt, section 10; 1920x1080 x 2048): 2.6-2.85 ms against 2.95-3.1 for the lane-per-scanline
+ * kernel on the same box.  The kernel costs its stores -- 2.46 ms with everything else cut out, 5.4 TB/s -- plus the part of its
+ * arithmetic (1.6 ms alone) that does not hide under them; neither fewer instructions nor more waves moved it further.
  *
  * Scope: the 4-samples-per-cycle systems, tiers 0 / 1 (what a wide picture at ordinary knobs runs in), 4-byte pixel formats, no
  * blend, no bloom, a resampler step small enough for the ring (outw >= ~1650).  Everything else stays with k_decode; the tier of a
@@ -27,6 +30,15 @@
 #define WIDE_LPW   16                 /* scanlines per wave */
 #define WIDE_RING  128                /* samples per scanline in the y/i/q ring */
 #define WIDE_PXT   256                /* pixels per row run: 64 lanes x 4 */
+
+/* a 16-bit LDS store by the lanes of `lanes` only (the others keep their registers and the LDS pipe free); the wave's stores and
+ * loads reach the LDS in program order, so the compiler not counting this one only makes its waits conservative */
+__device__ __forceinline__ void lds_store16_lanes(unsigned addr, int v, unsigned long long lanes)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(addr), "v"(v), "s"(lanes) : "memory");
+}
 
 /* v_mad_i64_i32 with a per-lane multiplier */
 __device__ __forceinline__ long mad64_vv(int d, int m, long acc)
@@ -45,8 +57,16 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
     static_assert(S::CCS == 4 && TIER <= 1, "tiers 0 / 1 of the 4-samples-per-cycle systems");
     constexpr int LPW = WIDE_LPW, RING = WIDE_RING;
     constexpr int IN_DW = 16, IN_STRIDE = IN_DW + 1;
-    __shared__ unsigned s_in[LPW * IN_STRIDE];                 /* input tile: 64 samples per scanline */
-    __shared__ unsigned long long s_ring[LPW * RING];          /* y/i/q ring, entry = halves { y, -, q, i } */
+    /* LDS, 13.5 KB (12 waves per CU): the { q, i } ring -- one dword per sample --, the luma ring -- 16-bit values, scanlines l and
+     * l + 8 sharing a dword so that both rings are addressed by sample * 4 -- and the input tile (64 samples per scanline).
+     * A scanline's ring is 129 dwords apart from the next and the luma ring starts 16 banks after the chroma ring: the filter stage
+     * stores sample x of all 16 scanlines with ONE instruction, and at a stride of 128 dwords its 32-lane halves met on a single bank
+     * (SQ_LDS_BANK_CONFLICT: 80 % of all LDS cycles, the filter stage alone 1.35 ms at 1080p x 2048 -- profiles/r04_experiments.txt 10) */
+    constexpr int RSTRIDE = RING + 1;
+    constexpr int OFF_IQ = 0, OFF_Y = LPW * RSTRIDE * 4, OFF_IN = OFF_Y + LPW / 2 * RSTRIDE * 4;
+    static_assert((OFF_Y / 4) % 32 == 16 && OFF_IN % 16 == 0, "bank offset of the luma ring, alignment of the input tile");
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[OFF_IN + LPW * IN_STRIDE * 4];
+    unsigned *const s_in = (unsigned *) (s_mem + OFF_IN);
 
     const int lane = threadIdx.x, l = lane >> 2, c = lane & 3; /* my scanline of the wave, my cascade */
     const int total = n_fields * S::LINES;
@@ -87,9 +107,9 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
     const int M = c == 0 ? (P.eq_lf[0] - 65536) * 65536 : c == 1 ? (P.eq_hf[0] - 65536) * 65536 : c == 2 ? P.eq_hf[1] * 65536 : P.eq_hf[2] * 65536;
     const int g2 = c == 1 ? 9175 : c == 2 ? 1311 : 0;          /* crt_core.c:272-286 (the host refuses other gains) */
     const int sh = c == 1 ? 0 : 3;                             /* luma stays unshifted (see k_decode, D9), chroma >> 3 */
-    /* where my result goes in the ring entry (in halves): y 0, q 2, i 3; the luma-low lane writes the unused half */
-    const int hoff = c == 1 ? 0 : c == 0 ? 1 : c == 3 ? 2 : 3;
-    unsigned short *const ring_h = (unsigned short *) s_ring + (size_t) l * RING * 4 + hoff;
+    /* where my result goes: the luma-high lane files y, the chroma lanes their half of the { q, i } dword; the luma-low lane's
+     * output only feeds its neighbour (it sits out the store) */
+    const unsigned wbase = c == 1 ? OFF_Y + (l & 7) * (RSTRIDE * 4) + (l >> 3) * 2 : OFF_IQ + l * (RSTRIDE * 4) + (c == 2 ? 2 : 0);
 
     int x0 = 0, x1 = 0, x2 = 0, x3 = 0;                        /* my four stages */
     int h0 = 0, h1 = 0, h2 = 0;                                /* my input history (top band, crt_core.c:229-231) */
@@ -138,53 +158,63 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
                  * takes the luma-low lane's output from its left neighbour in the quad, the others take themselves (difference 0) */
                 const int r = x3 + (__mul24(h2 - x3, g2) >> 16);
                 h2 = h1; h1 = h0; h0 = u;
-                const int nb = __builtin_amdgcn_update_dpp(x3, x3, 0xe0 /* quad_perm:[0,0,2,3] */, 0xf, 0xf, false);
+                const int nb = __builtin_amdgcn_mov_dpp(x3, 0xe0 /* quad_perm:[0,0,2,3] */, 0xf, 0xf, true);
                 const int tt = x3 - nb;
                 const int out = (r - tt + (tt >> 3)) >> sh;
-                ring_h[(x & (RING - 1)) * 4] = (unsigned short) out;
+                lds_store16_lanes(wbase + (unsigned) (x & (RING - 1)) * 4u, out, 0xeeeeeeeeeeeeeeeeull);
             }
             xq++;
         }
         wave_lds_fence();
         /* ---- pixels: scanline after scanline, lane = four consecutive pixels of the run ---- */
         const int px = px0 + 4 * lane;
-        for (int ll = 0; ll < LPW; ll++) {
-            const int nr = __builtin_amdgcn_readlane(nrows, 4 * ll);
-            if (nr == 0) continue;
-            const unsigned dlo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) dst, 4 * ll);
-            const unsigned dhi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (dst >> 32), 4 * ll);
-            const unsigned long long drow = ((unsigned long long) dhi << 32 | dlo) + (unsigned long long) px * 4;
-            const uint2 *ring = (const uint2 *) (s_ring + ll * RING);
+        /* what does not depend on the scanline: the taps' ring offsets and weights (scaled by 4, as in k_decode) and how many of
+         * my pixels exist (px * dx < ppos_end  <=>  px < n_px) */
+        unsigned o0[4], o1[4];
+        int R4[4], L4[4];
+        {
             unsigned ppos = __umul24((unsigned) px, dx);       /* px < 2^24, dx < 2^24 (host-checked) */
-            unsigned v[4];
-            int have = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool ok = px + j < n_px && ppos < ppos_end;
-                const unsigned idx = ppos >> 12;
-                const int R4 = (int) ((ppos & 0xfffu) << 2), L4 = 0x3ffc - R4;
-                const uint2 e0 = ring[idx & (RING - 1)], e1 = ring[(idx + 1) & (RING - 1)];
-                const int py = (int) (short) e0.x, cy = (int) (short) e1.x;
-                const int pq = (int) (short) e0.y, pi = (int) e0.y >> 16, cq = (int) (short) e1.y, ci = (int) e1.y >> 16;
-                /* crt_core.c:556-562 exactly as in k_decode (tiers 0 / 1): weights scaled by 4, chroma packed, one v_dot2 per
-                 * colour row, contrast as a pre-shifted 64-bit multiply-add with the alpha riding on the red row */
-                const int yy = __mul24(cy, R4) + __mul24(py, L4);
-                int iq = add_hiwords(__mul24(pq, L4), __mul24(cq, R4));
-                iq = add_hiwords_to_hi(iq, __mul24(pi, L4), __mul24(ci, R4));
-                const int vr = dot2_vs(iq, (3879 << 16) | 2556, yy);
-                const int vg = dot2_vs(iq, (int) (((unsigned) -1126 << 16) | ((unsigned) -2605 & 0xffffu)), yy);
-                const int vb = dot2_vs(iq, (int) (((unsigned) -4530 << 16) | 7021u), yy);
-                int r8 = pair_hi(mad64_vs(vr & ~0xfff, contrast12, alpha_pair));
-                int g8 = pair_hi(mad64_vs0(vg & ~0xfff, contrast12));
-                int b8 = pair_hi(mad64_vs0(vb & ~0xfff, contrast12));
-                r8 = clampi(r8, 0xff00, 0xffff); g8 = clampi(g8, 0, 255); b8 = clampi(b8, 0, 255);
-                unsigned rgb = lshl_or(lshl_or((unsigned) r8, 8, (unsigned) g8), 8, (unsigned) b8);       /* 0xffRRGGBB */
-                if (psel != 0x03020100u) rgb = __builtin_amdgcn_perm(rgb, rgb, psel);
-                v[j] = rgb;
-                have += ok ? 1 : 0;                            /* (valid pixels are a prefix: ppos grows) */
+                o0[j] = (ppos >> 10) & ((RING - 1) << 2);
+                o1[j] = ((ppos + 4096u) >> 10) & ((RING - 1) << 2);
+                R4[j] = (int) ((ppos & 0xfffu) << 2);
+                L4[j] = 0x3ffc - R4[j];
                 ppos += dx;
             }
-            if (have > 0) {
+        }
+        const int have = n_px - px;
+        if (have > 0) {
+#pragma unroll
+            for (int ll = 0; ll < LPW; ll++) {
+                const int nr = __builtin_amdgcn_readlane(nrows, 4 * ll);
+                if (nr == 0) continue;
+                const unsigned dlo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) dst, 4 * ll);
+                const unsigned dhi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (dst >> 32), 4 * ll);
+                const unsigned long long drow = ((unsigned long long) dhi << 32 | dlo) + (unsigned long long) px * 4;
+                const unsigned char *const ry = s_mem + (OFF_Y + (ll & 7) * (RSTRIDE * 4) + (ll >> 3) * 2);
+                const unsigned char *const riq = s_mem + (OFF_IQ + ll * (RSTRIDE * 4));
+                unsigned v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int py = *(const short *) (ry + o0[j]), cy = *(const short *) (ry + o1[j]);
+                    const unsigned e0 = *(const unsigned *) (riq + o0[j]), e1 = *(const unsigned *) (riq + o1[j]);
+                    const int pq = (int) (short) e0, pi = (int) e0 >> 16, cq = (int) (short) e1, ci = (int) e1 >> 16;
+                    /* crt_core.c:556-562 exactly as in k_decode (tiers 0 / 1): weights scaled by 4, chroma packed, one v_dot2 per
+                     * colour row, contrast as a pre-shifted 64-bit multiply-add with the alpha riding on the red row */
+                    const int yy = __mul24(cy, R4[j]) + __mul24(py, L4[j]);
+                    int iq = add_hiwords(__mul24(pq, L4[j]), __mul24(cq, R4[j]));
+                    iq = add_hiwords_to_hi(iq, __mul24(pi, L4[j]), __mul24(ci, R4[j]));
+                    const int vr = dot2_vs(iq, (3879 << 16) | 2556, yy);
+                    const int vg = dot2_vs(iq, (int) (((unsigned) -1126 << 16) | ((unsigned) -2605 & 0xffffu)), yy);
+                    const int vb = dot2_vs(iq, (int) (((unsigned) -4530 << 16) | 7021u), yy);
+                    int r8 = pair_hi(mad64_vs(vr & ~0xfff, contrast12, alpha_pair));
+                    int g8 = pair_hi(mad64_vs0(vg & ~0xfff, contrast12));
+                    int b8 = pair_hi(mad64_vs0(vb & ~0xfff, contrast12));
+                    r8 = clampi(r8, 0xff00, 0xffff); g8 = clampi(g8, 0, 255); b8 = clampi(b8, 0, 255);
+                    const unsigned rgb = lshl_or(lshl_or((unsigned) r8, 8, (unsigned) g8), 8, (unsigned) b8);   /* 0xffRRGGBB */
+                    v[j] = __builtin_amdgcn_perm(rgb, rgb, psel);                  /* (the identity for the native order) */
+                }
                 for (int dup = 0; dup < nr; dup++) {
                     const unsigned long long dd = drow + (size_t) dup * pitch;
                     if (have >= 4) {
