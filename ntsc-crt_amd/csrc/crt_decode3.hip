@@ -89,6 +89,19 @@ k_bloom_scatter(int total, int outw, const crthip_line *__restrict__ lines, cons
 }
 
 /* slots of the sorted order for n fields: every bucket may end in a partial wave */
+/* histogram and cursors to 0, every slot to "no line" (-1).  A kernel of our own instead of two hipMemsetAsync calls: with the two
+ * memsets -- adjacent ranges, different fill values -- as nodes of a captured graph, the SECOND replay of a bloom field-pass died
+ * with a write fault (ROCm 7.2; every eager launch and the first replay were fine, and so was the same graph with this kernel:
+ * tools/debug/graph_bloom.py, gpurun_out/r4s18-r4s20); it depended on the box, the test had passed for a round.  One launch is
+ * cheaper than two as well. */
+__global__ void __launch_bounds__(256)
+k_bloom_clear(int *__restrict__ hist2, int n_hist2, int *__restrict__ perm, size_t slots)
+{
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, stride = (size_t) gridDim.x * 256;
+    if (gid < (size_t) n_hist2) hist2[gid] = 0;
+    for (size_t i = gid; i < slots; i += stride) perm[i] = -1;
+}
+
 static size_t bloom_slots(const crthip_ctx *c, int n) { return (size_t) n * c->sd.lines + 64 * BLOOM_BUCKETS; }
 
 /* The sort's scratch (histogram, cursors, slot -> line) for n fields.  crthip_reserve sizes it with the rest of the workspace,
@@ -125,8 +138,12 @@ int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, con
             return set_err(c, CRTHIP_E_ARG, "no bloom build of the NES systems", hipSuccess);
         } else {
             ProfScope ps(c, CRTHIP_K_DECODE);
-            HIPCHK(c, hipMemsetAsync(hist, 0, sizeof(int) * 2 * BLOOM_BUCKETS, c->stream));
-            HIPCHK(c, hipMemsetAsync(perm, 0xff, sizeof(int) * slots, c->stream));
+            {
+                const size_t want = (slots + 255) / 256;
+                static_assert(2 * BLOOM_BUCKETS <= 256 * 4, "the first blocks clear the histogram and the cursors");
+                hipLaunchKernelGGL(k_bloom_clear, dim3((unsigned) (want < 4 ? 4 : want > 2048 ? 2048 : want)), dim3(256), 0, c->stream,
+                                   hist, 2 * BLOOM_BUCKETS, perm, slots);
+            }
             const dim3 sgrid((total + 256 * BLOOM_SORT_ROUNDS - 1) / (256 * BLOOM_SORT_ROUNDS)), sblock(256);
             hipLaunchKernelGGL((k_bloom_count<S>), sgrid, sblock, 0, c->stream, total, p->outw, d_lines, hist);
             hipLaunchKernelGGL((k_bloom_scatter<S>), sgrid, sblock, 0, c->stream, total, p->outw, d_lines, hist, cursor, perm);
