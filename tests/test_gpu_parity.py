@@ -1275,14 +1275,17 @@ def test_full_batch_every_field_checked_against_the_oracle(crtlib):
         assert (int(st[k, crtlib.ST_HSYNC]), int(st[k, crtlib.ST_VSYNC]), int(st[k, crtlib.ST_RN])) == (hs, vs, rn), "field %d state" % k
 
 
-@pytest.mark.parametrize("name,shape", [("ntsc", 0), ("ntsc", 1), ("ntscbloom", 1), ("nes", 0)])
+@pytest.mark.parametrize("name,shape", [("ntsc", 0), ("ntsc", 1), ("ntscbloom", 1), ("nes", 0), ("ntsc-1080p", 1)])
 def test_fieldpass_is_graph_capturable(crtlib, name, shape):
     """crthip_fieldpass only enqueues kernels on the context's stream (no allocation, no synchronisation once the
     workspace is reserved -- the bloom build's sort scratch included), so a caller can capture the launch sequence into a
     HIP graph and replay it -- also as the very FIRST call of a context: the tables the context caches (skeleton fields,
-    the NES sample table) are then built outside the capture."""
+    the NES sample table) are then built outside the capture.  The 1080p case runs the wide-run
+    decoder (crt_decode4.hip); the bloom case is the one whose two memset nodes broke the second replay (round 4)."""
     import torch
     n, w, h = 6, 640, 480
+    if name.endswith("-1080p"):
+        name, n, w, h = name[:-6], 3, 1920, 1080
     nes = name == "nes"
     if nes:
         ppu = np.stack([R.synth_ppu(256, 240, 40 + k) for k in range(n)])
