@@ -562,6 +562,9 @@ NES_CASES = [
     # NES_BORDER 1 (crt_nes.c:69,138-160): the border colour right of the picture
     ("nesborder", 640, 480, 12, dict(scanlines=1)),
     ("nesborder", 512, 480, 0, dict(black_point=4, white_point=90)),
+    # wide pictures: the wide-run decoder (crt_decode4.hip), which the NES enters in tier 1 (its carriers do not fit 24 bits)
+    ("nesp0", 1920, 1080, 12, dict(scanlines=1)),
+    ("nes", 1700, 600, 24, dict(saturation=16)),
 ]
 
 
@@ -574,6 +577,8 @@ def test_nes_parity(crtlib, case, fused):
     n = 3
     orc = R.Oracle(name)
     g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, name, device=0)
+    if outw >= 1664:
+        g.set_shape(1)                       # three fields would otherwise take the scanline-parallel kernels
     ocrts = [orc.new_crt(outw, outh, R.FMT_BGRA) for _ in range(n)]
     for k, v in knobs.items():
         setattr(g, k, v)
@@ -700,7 +705,12 @@ def test_vhs_bloom_lane_per_scanline_parity(crtlib, fused):
     _vhs_fieldpass(crtlib, fused, 12, "vhsbloom", 1)
 
 
-def _vhs_fieldpass(crtlib, fused, noise, sysname, shape):
+def test_vhs_wide_run_decoder_parity(crtlib):
+    """the VHS build at 1920x1080 through the wide-run decoder (crt_decode4.hip)"""
+    _vhs_fieldpass(crtlib, True, 12, "vhs", 1, size=(1920, 1080))
+
+
+def _vhs_fieldpass(crtlib, fused, noise, sysname, shape, size=(832, 624)):
     """BASELINE configs[3]: CRT_SYSTEM_NTSCVHS, 832x624 (and its CRT_DO_BLOOM build).  The decoder's noise is the C library's rand()
     stream (crt_core.c:344-351): field k's generator starts at srand(seed_k) and carries over from
     step to step, so the oracle processes each field's whole sequence under its own libc stream.
@@ -708,7 +718,7 @@ def _vhs_fieldpass(crtlib, fused, noise, sysname, shape):
     drop-in test, where the host draws it exactly like the reference.)"""
     import ctypes as C
     libc = C.CDLL(None)
-    n, w, h, steps = 3, 832, 624, 3
+    n, (w, h), steps = 3, size, 3
     seeds = [1, 77, 20260924]
     imgs = np.stack([R.synth_image(w, h, 4, 60 + k, "random" if k != 1 else "bars") for k in range(n)])
     orc = R.Oracle(sysname)
