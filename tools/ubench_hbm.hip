@@ -275,6 +275,43 @@ __global__ void __launch_bounds__(64) k_mimic(v4i *p, size_t pitch16, int lines_
     if (a == 0x7fffffff) { s_pad[lane] = a; *sink = s_pad[63 - lane]; }
 }
 
+// round 4, second question: WHERE in a tile's work its stores are issued.  The wide-run decoder as built runs its filter stage (55 % of a
+// tile's vector work) without a store and then alternates a scanline's pixel arithmetic with that scanline's 3-4 row stores (MODE 1);
+// MODE 2 spreads the same stores evenly over ALL of the tile's vector work (what deferring the duplicated rows into the next run's
+// filter stage would approach); MODE 0 = k_mimic's "all work, then all stores".
+template <int MODE>
+__global__ void __launch_bounds__(64) k_mimic_spread(v4i *p, size_t pitch16, int lines_per_pic, int rows_per_pic, int n_pics, int valu, int *sink)
+{
+    extern __shared__ int s_pad[];
+    constexpr int LPW = 16, RUN16 = 64;
+    const int lane = threadIdx.x;
+    const size_t wave = blockIdx.x;
+    int a = lane, b = lane * 3 + 1, c = lane ^ 5, k1 = 40503, k2 = 7;
+    auto work = [&](int n) {
+        for (int i = 0; i < n; i += 9) {
+            asm volatile("v_sub_u32 %0, %1, %0\n\tv_add_u32 %0, %0, %2\n\tv_mad_i32_i24 %0, %0, %3, %1\n\t"
+                         "v_sub_u32 %4, %1, %4\n\tv_add_u32 %4, %4, %2\n\tv_mad_i32_i24 %4, %4, %3, %1\n\t"
+                         "v_sub_u32 %5, %1, %5\n\tv_add_u32 %5, %5, %2\n\tv_mad_i32_i24 %5, %5, %3, %1"
+                         : "+v"(a), "+v"(k2), "+v"(k1), "+v"(k1), "+v"(b), "+v"(c));
+        }
+    };
+    for (size_t x = 0; x + RUN16 <= pitch16; x += RUN16) {
+        if (MODE == 0) work(valu);
+        if (MODE == 1) work(valu * 55 / 100);
+        for (int i = 0; i < LPW; i++) {
+            if (MODE == 1) work(valu * 45 / 100 / LPW);
+            if (MODE == 2) work(valu / LPW);
+            const size_t line = wave * LPW + i, pic = line / lines_per_pic, l = line % lines_per_pic;
+            if (pic >= (size_t) n_pics) continue;
+            const int dups = 3 + (int) (l & 1);
+            v4i v = { a, b, c, 4 };
+            v4i *row = p + (pic * rows_per_pic + l * rows_per_pic / lines_per_pic) * pitch16 + x + lane;
+            for (int d = 0; d < dups; d++) __builtin_nontemporal_store(v, row + (size_t) d * pitch16);
+        }
+    }
+    if (a == 0x7fffffff) { s_pad[lane] = a; *sink = s_pad[63 - lane]; }
+}
+
 static hipEvent_t e0, e1;
 template <class F> static double best_ms(F launch, int iters = 5)
 {
@@ -349,6 +386,20 @@ int main(int argc, char **argv)
     // the decoder's store pattern at 1080p: pitch 7680 B, 240 lines per picture, each written to 3 or 4 rows of 1080
     const size_t pitch16 = 7680 / 16;
     const int pics = (int) (bytes / (7680ull * 1080));
+    if (argc > 1 && !strcmp(argv[1], "spread")) {                     // only: where in a tile's work the stores are issued
+        const int mp = pics < 1536 ? pics : 1536;
+        const double gbm = (double) mp * 240 * 3.5 * 7680.0 / 1e9;
+#define SPREAD(MODE, VALU, LDSB, name) do { const double ms = best_ms([&] { \
+            hipLaunchKernelGGL((k_mimic_spread<MODE>), dim3((mp * 240 + 15) / 16), dim3(64), LDSB, 0, a, pitch16, 240, 1080, mp, VALU, o); }, 3); \
+            printf("%-6s %-70s %8.3f ms  %8.1f GB/s\n", "spread", name, ms, gbm / (ms * 1e-3)); } while (0)
+            SPREAD(0, 0, 13472, "16 lines, 1 KB runs, stores only, 12 waves/CU");
+            SPREAD(0, 4200, 13472, "4200 VALU/tile: all work, then all stores of the tile");
+            SPREAD(1, 4200, 13472, "4200 VALU/tile: 55 % without stores, then work / stores per scanline  [= k_decode_wide]");
+            SPREAD(2, 4200, 13472, "4200 VALU/tile: stores spread evenly over all the work");
+            SPREAD(1, 3400, 13472, "3400 VALU/tile, as k_decode_wide");
+            SPREAD(2, 3400, 13472, "3400 VALU/tile, stores spread evenly");
+        return 0;
+    }
     const int waves = (pics * 240 + 63) / 64;
     for (int dups = 1; dups <= 4; dups++) {
         const double gb = (double) pics * 240 * dups * 7680.0 / 1e9;
