@@ -53,13 +53,18 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
                 if (p->eq_g[k][b] != want[k][b])
                     return set_err(c, CRTHIP_E_ARG, "equaliser gains differ from crt_core.c:272-286", hipSuccess);
     }
-    const bool rows_shape = !p->eq_kernel && (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS));
+    /* ... and a WIDE picture leaves the scanline-parallel shape early: from WIDE_SHAPE_MIN_FIELDS fields on the wide-run decoder
+     * (crt_decode4.hip: 16 scanlines per wave, so 32 fields are already two waves per CU) is the faster one -- 1080p x 64: 0.178 ->
+     * 0.135 ms, x 128: 0.359 -> 0.191, x 32: 0.126 / 0.130, x 16: 0.114 / 0.126 (profiles/r04_experiments.txt, section 15) */
+    const bool wide_px = c->px_tile ? c->px_tile >= 32 : p->outw >= 1280;
+    const bool rows_shape = !p->eq_kernel && (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS &&
+                            !(n >= WIDE_SHAPE_MIN_FIELDS && !p->bloom && crt_decode_wide_ok(c, p, decoder_min_tier(c, p), wide_px))));
     if (rows_shape) return crt_run_decode_rows(c, p, n, d_inp, d_lines, d_out, ostride);
     if (p->bloom) return crt_run_decode_bloom_lanes(c, p, n, d_inp, d_lines, d_out, ostride, decoder_min_tier(c, p));
     /* FIR build: the filters only add, their outputs stay inside the hull of the inputs, so the 24-bit envelope
      * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
     const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
-    const bool wide = c->px_tile ? c->px_tile >= 32 : p->outw >= 1280;
+    const bool wide = wide_px;
     const bool use_wide = crt_decode_wide_ok(c, p, min_tier, wide);
     /* lines per output row when the picture is shorter than the raster: one pass per rank */
     const unsigned span = (unsigned) p->outh + p->v_fac;

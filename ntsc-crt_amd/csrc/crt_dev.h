@@ -387,6 +387,7 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * 512 fields: 0.672 ms with the lane-shaped encoder, 0.734 with the row-shaped one) */
 #define ROWS_SHAPE_MAX_FIELDS 128          /* k_decode_row */
 #define ROWS_SHAPE_MAX_FIELDS_ENC 256      /* k_active_row */
+#define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
 
 #define CRTHIP_MAX_CHUNKS 64               /* crthip_set_overlap */
 

@@ -241,6 +241,32 @@ def test_wide_decoder_against_the_lane_per_scanline_decoder(crtlib):
     assert int(outs[0][0].to(torch.int64).sum().item()) > 0
 
 
+def test_wide_pictures_leave_the_scanline_parallel_decoder_early(crtlib):
+    """48 fields of 1920x1080: the library's own choice (shape 0) is the scanline-parallel ENCODER with the wide-run DECODER
+    (WIDE_SHAPE_MIN_FIELDS, crt_decode.hip); the same batch through the forced shapes 1 (lane-per-row encoder + wide-run decoder)
+    and 2 (scanline-parallel kernels, checked against the oracle elsewhere) gives the same bytes and the same state, two passes."""
+    import torch
+    n, w, h = 48, 1920, 1080
+    base = np.stack([R.synth_image(w, h, 4, 9100 + k, "bars" if k & 1 else "random") for k in range(4)])
+    imgs = torch.from_numpy(np.concatenate([base, base[:, -1:]], axis=1)).to("cuda:0")
+    data = imgs.repeat(n // 4, 1, 1, 1)[:, :h]
+    outs = []
+    for shape in (0, 1, 2):
+        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+        g.scanlines = 1
+        g.set_shape(shape)
+        s = crtlib.Settings(data, format=crtlib.FMT_BGRA, field=[(k // 4) & 1 for k in range(n)], frame=0)
+        for step in range(2):
+            g.fieldpass(s, 9)
+        g.synchronize()
+        outs.append((g.out.clone(), g.state.clone()))
+        g.close()
+    for k in (1, 2):
+        assert torch.equal(outs[0][0], outs[k][0]), "picture: shape 0 vs shape %d" % k
+        assert torch.equal(outs[0][1], outs[k][1]), "state: shape 0 vs shape %d" % k
+    assert int(outs[0][0].to(torch.int64).sum().item()) > 0
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("case", [1, 2, 3, 5])
 def test_slower_decoder_tiers_parity(crtlib, case, mode):
