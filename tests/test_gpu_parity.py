@@ -1048,6 +1048,25 @@ def _random_case(rng):
     return ("ntsc", outw, outh, ofmt, w, h, ifmt, noise, skw, knobs)
 
 
+def _random_wide_case(rng):
+    """_random_case with picture widths the wide-run decoder takes (crt_decode4.hip: outw from ~1650 up, 4-byte pixels, no blend);
+    three-byte formats, blend and the narrower widths in the list fall back to the lane-per-scanline kernel -- also a case"""
+    case = list(_random_case(rng))
+    case[0] = str(rng.choice(["ntsc", "ntscp0", "snes", "temp", "nesrgb"]))
+    case[1] = int(rng.choice([1500, 1650, 1664, 1700, 1919, 1920, 1921, 2047, 2560, 3001, 3840, 4095]))
+    case[2] = int(rng.choice([1, 120, 240, 241, 480, 777, 1080, 1200, 2160]))
+    case[3] = int(rng.choice([R.FMT_RGBA, R.FMT_BGRA, R.FMT_ARGB, R.FMT_ABGR, R.FMT_RGBA, R.FMT_BGRA, R.FMT_RGB]))
+    case[9] = dict(case[9], blend=int(rng.integers(0, 8) == 0))
+    return tuple(case)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_wide_configurations(crtlib, seed):
+    """random wide pictures, knobs, formats and systems through the lane shape (wide-run decoder where it applies)"""
+    rng = np.random.default_rng(7000 + seed)
+    _run_case(crtlib, _random_wide_case(rng), fused=bool(seed & 1), steps=2, n=2, shape=1)
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_configurations(crtlib, seed):
     """odd / tiny / large geometries, all format pairs, random knobs: stagewise AND fused, 2 steps each"""

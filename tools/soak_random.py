@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: tests/test_gpu_parity.py's random configurations (HIP vs oracle, bit-exact) over a seed range,
-also for the VHS / NES / FIR variants.  usage: tools/soak_random.py first_seed count"""
+also for the VHS / NES / FIR variants.  usage: tools/soak_random.py first_seed count [wide]
+(wide: picture widths of 1500-4095 pixels, i.e. the wide-run decoder of crt_decode4.hip where it applies; lane shape only)"""
 # seeds alternate systems (NTSC, FIR builds, pattern 0, bloom builds, SNES, template, NES-RGB, PV-1000) and both kernel shapes
 import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,17 @@ import crtlib
 import test_gpu_parity as T
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
+if len(sys.argv) > 3 and sys.argv[3] == "wide":
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(seed ^ 0x71de)
+        case = T._random_wide_case(rng)
+        try:
+            T._run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=2, shape=1)
+        except Exception as e:
+            bad += 1
+            print("WIDE SEED", seed, case[:8], "FAILED:", str(e).splitlines()[0][:200])
+    print("soak: %d wide cases, %d failures" % (count, bad))
+    sys.exit(1 if bad else 0)
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     case = list(T._random_case(rng))
