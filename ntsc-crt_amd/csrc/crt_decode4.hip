@@ -5,8 +5,8 @@
  * Why a third shape (round 4; profiles/r04_store_patterns.txt, r04_experiments.txt section 9).  At 1920x1080 the decoder is bound
  * by its picture stores -- 6.5 MB per field, rows duplicated 3-4 times (crt_core.c:661-664).  A lane-per-scanline wave owns 64
  * scanlines = 288 picture rows and can only buffer 32 pixels of each before it has to store: 128-byte runs, for which the memory
- * system gives 5.2 TB/s; for 1 KB runs it gives 5.85.  Emitting a 256-pixel run needs ~100 samples of y/i/q of that scanline at
- * once, i.e. 800 bytes of LDS per scanline -- 51 KB for 64 scanlines.  So this kernel takes 16 scanlines per wave and gets its
+ * system gives 5.2 TB/s; for 1 KB runs it gives 5.85.  Emitting a 256-pixel run needs ~105 samples of y/i/q of that scanline at
+ * once, i.e. 600-800 bytes of LDS per scanline -- 38-51 KB for 64 scanlines.  So this kernel takes 16 scanlines per wave and gets its
  * 64 lanes busy in the filter stage by giving every scanline FOUR lanes, one per cascade that tiers 0 / 1 run (luma low, luma
  * high, I high, Q high: crt_decode_lane.h, eq_step64 -- four independent chains of four one-pole stages): a lane runs 12
  * stage instructions per sample instead of 48, the band sums (crt_core.c:218-232) are formed with one quad DPP exchange, and
@@ -235,9 +235,7 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
 /* the configurations this kernel takes (everything else: k_decode) */
 bool crt_decode_wide_ok(const crthip_ctx *c, const crthip_params *p, int min_tier, bool wide)
 {
-    static int env = -1;                                       /* CRTHIP_WIDE_DECODE=0: A/B switch */
-    if (env < 0) { const char *e = getenv("CRTHIP_WIDE_DECODE"); env = e ? atoi(e) != 0 : 1; }
-    if (!env || !wide || c->sd.cc_samples != 4 || p->out_bpp != 4 || p->blend || p->bloom || p->eq_kernel || min_tier > 1) return false;
+    if (!c->wide_decode || !wide || c->sd.cc_samples != 4 || p->out_bpp != 4 || p->blend || p->bloom || p->eq_kernel || min_tier > 1) return false;
     if (p->dx <= 0 || p->dx >= (1 << 24) || p->outw >= (1 << 22)) return false;
     /* a run of 256 pixels must fit the ring with the filter's look-ahead: taps up to ((255 dx) >> 12) + 1 samples apart + 3 */
     return ((255ll * p->dx) >> 12) + 8 <= WIDE_RING;

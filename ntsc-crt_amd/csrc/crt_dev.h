@@ -465,6 +465,7 @@ struct crthip_ctx {
     int vhs_chunks;
     signed char *d_vhs_dig;     /* VHS: the same coefficients as signed byte digits, VHS_DIG_ROW bytes per row (matrix-core jump) */
     int vhs_mfma;               /* CRTHIP_VHS_MFMA: 1 (default) = the 31 x 31 jumps on the matrix cores, 0 = on the vector unit */
+    int wide_decode;            /* CRTHIP_WIDE_DECODE: 1 (default) = wide pictures through k_decode_wide (crt_decode4.hip), 0 = A/B switch */
     unsigned *d_vhs_hist;       /* VHS: bound per-field generator histories (caller's memory) */
     unsigned *d_vhs_next;       /* VHS: where k_vhs_tail leaves the histories while k_vhs_noise still reads the old ones */
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
