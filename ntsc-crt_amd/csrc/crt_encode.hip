@@ -171,8 +171,9 @@ __device__ __forceinline__ bool format_blue_low(int format)
  * own tile row.  Input side: `have` = tile in LDS, stage[] = tile have+1 in flight / in registers.  A piece that
  * would run past the row end is moved back to the row's last 16 bytes, so nothing beyond the row is touched
  * (row_bytes >= 16); moved-back pieces of several lanes overlap and carry identical bytes. */
-/* OT: dwords per row of the OUTPUT (sample) tile = the size of the signal pieces a drain stores.  16 (64-byte pieces) for
- * narrow images; the wide-input encoder (ACT = 32: whole 128-byte image lines per piece group) takes 64 -- see k_active. */
+/* OT: dwords per row of the OUTPUT (sample) tile.  The wide-input encoder (ACT = 32: whole 128-byte image lines per
+ * piece group) keeps the 16-dword sample tile of the narrow one: 64-byte sample pieces either way, 4 KB less LDS per
+ * wave (11 instead of 8 waves per CU behind the image fetches). */
 template <int ACT, int OT = ACT>
 struct RowTiles {
     static constexpr int TILE = ACT, STRIDE = ACT + 1, PIECES = ACT / 4;     /* 16-byte pieces per tile row */
@@ -327,11 +328,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
          const uint2 *__restrict__ jump16)
 {
-    /* sample tile: 16 dwords per row for narrow images; 64 for wide ones (256-byte signal pieces).  At 1920x1080 the kernel is bound by
-     * the memory system, not by anything inside a CU -- the same 0.95 ms at 11, 8 and 5 waves per CU -- and its 0.58 GB of signal
-     * stores cost 0.35 of those 0.95 ms in 64-byte pieces (a build without them: 0.60): 128-byte pieces 0.91, 256-byte pieces 0.85
-     * (profiles/r04_experiments.txt, sections 18-19).  26 KB of LDS, six waves per CU. */
-    using T = RowTiles<ACT, ACT == 32 ? 64 : 16>;
+    using T = RowTiles<ACT, 16>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[64 * T::STRIDE];
     __shared__ unsigned s_out[64 * T::OSTRIDE];
