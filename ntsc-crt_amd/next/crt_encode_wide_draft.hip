@@ -12,7 +12,9 @@
  *
  * Arithmetic: the FAST + 64-bit-mad path of k_active, instruction for instruction per component -- lane c of a quad converts ONLY
  * its own component (3 multiplies instead of 9), runs its own low-pass, multiplies by its own carrier (the luma lane by 2^16:
- * "itself"), the quad sum is the sample.  Same bytes by construction; the parity tests that cover k_active cover this.
+ * "itself"), the quad sum is the sample.  The split itself is checked on the CPU against the oracle's crt_modulate, sample for
+ * sample (next/check_split_arithmetic.py: NTSC / VHS, four pixel formats, both fields: 0 mismatches); the parity tests that cover
+ * k_active cover the kernel once it is wired in.
  *
  * Scope of the draft: 4-samples-per-cycle systems with band-limiting (SysNTSC, SysNTSC0, SysVHS ...), 4-byte pixels, image rows
  * that are a multiple of 512 bytes (1280, 1920, 2560, 3840 pixels), destw <= 768.  Everything else stays with k_active.
