@@ -387,6 +387,11 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * 512 fields: 0.672 ms with the lane-shaped encoder, 0.734 with the row-shaped one) */
 #define ROWS_SHAPE_MAX_FIELDS 128          /* k_decode_row */
 #define ROWS_SHAPE_MAX_FIELDS_ENC 256      /* k_active_row */
+/* k_active's 256-byte signal pieces need 16.6 KB of LDS per wave (6 waves per CU beside the wide image tile, 7 beside the narrow
+ * one): taken from this many waves on, i.e. four residency rounds of that occupancy (1080p: 1638 fields; profiles/r04_experiments.txt
+ * section 19 has the cliff below it, profiles/r05_experiments.txt the A/B) */
+#define SIG_TILE64_MIN_WAVES_WIDE 6144
+#define SIG_TILE64_MIN_WAVES      7168
 #define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
 
 #define CRTHIP_MAX_CHUNKS 64               /* crthip_set_overlap */
@@ -471,6 +476,7 @@ struct crthip_ctx {
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
     int ac_tile;                /* encoder tile, same convention, by input width */
     int ac_tile_env;            /* CRTHIP_AC_TILE: overrides both (A/B measurements) */
+    int sig_tile_env;           /* CRTHIP_SIG_TILE = 16 | 64: pins k_active's signal tile (A/B measurements); 0 = by batch size */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join, ev_chunk[CRTHIP_MAX_CHUNKS];

@@ -206,7 +206,13 @@ struct RowTiles {
     {
         const int off = piece_offset(tile);
 #pragma unroll
-        for (int i = 0; i < PIECES; i++) stage[i] = image_piece<ACT>(s_src[i * ROWS + prow] + off);
+        for (int i = 0; i < PIECES; i++) {
+#if defined(ENC_DBG) && ENC_DBG == 2          /* measurement build: no image loads (tools/sessions; never shipped) */
+            stage[i] = v4i{ off + i, lane, tile, 7 };
+#else
+            stage[i] = image_piece<ACT>(s_src[i * ROWS + prow] + off);
+#endif
+        }
     }
     __device__ __forceinline__ void stash(int tile)
     {
@@ -276,6 +282,9 @@ struct RowTiles {
             if (d != 0 && opiece * 4 < ng && nbytes > 0) {
                 const unsigned *sp = s_out + r * OSTRIDE + opiece * 4;
                 v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+#if defined(ENC_DBG) && ENC_DBG == 1          /* measurement build: no signal stores (-128 never leaves the clamp) */
+                if (o.x != (int) 0x80808080) continue;
+#endif
                 if (nbytes == 16) {
                     gstore16u(d + first, o);
                 } else {
@@ -322,13 +331,17 @@ template <class S> __device__ __forceinline__ int source_row(const crthip_params
  * piece group, 16 halves the LDS footprint (more waves per SIMD) -- chosen by input width at launch */
 /* CLAMP: output is inp[] (fused path), i.e. the +-127 clamp of crt_core.c:363-364 applies even when
  * no noise is added (only matters for NES, whose samples can be -128) */
-template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT>
+/* OT = dwords per row of the sample tile: the signal leaves in 4 * OT-byte pieces per row.  16 (64-byte pieces) keeps the LDS
+ * small; 64 (256-byte pieces, 16.6 KB) is what large batches take: the encoder is bound by its MEMORY PATTERN -- image pieces in,
+ * signal pieces out, no arithmetic at all reproduces its time (tools/ubench_enc.hip, profiles/r05_encoder_memory_shapes.txt) -- and
+ * 64-byte pieces at the reference's odd line starts are its dearest part */
+template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT, int OT = 16>
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
          const uint2 *__restrict__ jump16)
 {
-    using T = RowTiles<ACT, 16>;
+    using T = RowTiles<ACT, OT>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[64 * T::STRIDE];
     __shared__ unsigned s_out[64 * T::OSTRIDE];
@@ -978,6 +991,19 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     }
     const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
     const bool wide_in = c->ac_tile_env ? c->ac_tile_env == 32 : c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
+    /* signal pieces of 256 bytes where the batch keeps the chip full at the 6-7 waves per CU their tile leaves (fused throughput
+     * path, 4-byte pixels, fast envelope); CRTHIP_SIG_TILE=16|64 pins the choice (A/B) */
+    if constexpr (FULL && FAST && !S::IS_NES) {
+        const int big = c->sig_tile_env ? c->sig_tile_env == 64 : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE64_MIN_WAVES);
+        if (in4 && big) {
+#define CRTHIP_LAUNCH_ACTIVE64(NZ) \
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
+         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 64>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
+            if (noise) CRTHIP_LAUNCH_ACTIVE64(true); else CRTHIP_LAUNCH_ACTIVE64(false);
+#undef CRTHIP_LAUNCH_ACTIVE64
+            return;
+        }
+    }
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
     do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
          else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)

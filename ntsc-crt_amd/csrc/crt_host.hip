@@ -194,6 +194,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     { const char *e = getenv("CRTHIP_SPEC_SYNC"); c->spec_sync = e ? atoi(e) != 0 : 0; }
     { const char *e = getenv("CRTHIP_WIDE_DECODE"); c->wide_decode = e ? atoi(e) != 0 : 1; }     /* A/B switch, crt_decode4.hip */
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
+    { const char *e = getenv("CRTHIP_SIG_TILE"); c->sig_tile_env = e && (atoi(e) == 16 || atoi(e) == 64) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;

@@ -29,6 +29,14 @@ def test_bench_spawns_its_own_ranks():
     assert out["frames_per_step"] == 200 and out["scaling"] == "weak"
     assert len(set(out["settings_blob_crc32_per_rank"])) == 1, "ranks disagree about the settings blob"
     assert out["noise_after_broadcast"] == 24          # rank 0's value won
+    # `bench.py --gpus N` -- the driver's scaling command -- reports what BASELINE's north star asks for:
+    # frames/sec at 640x480 AND 1920x1080 on N GPUs, and configs[2]'s 512 frames sharded over the N ranks
+    ns = out["north_star"]
+    assert ns["n_gpus"] == 2
+    for k in ("fps_640", "fps_640_one_batch", "fps_1080p_weak", "fps_1080p_weak_one_batch", "configs2_ms", "configs2_fps", "configs2_frames"):
+        assert k in ns and ns[k], k
+    assert ns["configs2_frames"] == 512 and ns["configs2_frames_per_gpu"] == 256
+    assert out["north_star_frames_per_step"] == {"headline": 200, "1080p_weak": 4096, "configs2_strong": 512}
 
 
 def test_bench_under_torch_distributed_run_and_strong_scaling():
@@ -40,6 +48,21 @@ def test_bench_under_torch_distributed_run_and_strong_scaling():
 def test_bench_single_process_dry_run():
     out = _run([sys.executable, "bench.py", "--dry-run"])
     assert out["world_size"] == 1 and out["frames_per_step"] == 4096
+    assert out["north_star"]["n_gpus"] == 1 and out["north_star"]["configs2_frames_per_gpu"] == 512
+
+
+def test_north_star_table_and_value_spread_survive_the_compact_line():
+    """the north-star row and the spread of the re-timed value are part of the final line (bench.compact_record)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    by = {e["name"]: e for e in full["extra_workloads"] if e}
+    full["north_star"] = bench.north_star_table(1, full, by.get("1080p_batch2048"), by.get("1080p_batch512"))
+    full["value_spread"] = {"reps": 5, "min": 1.40e6, "median": 1.42e6, "max": 1.43e6, "unit": "frames/sec", "note": "x"}
+    back = json.loads(json.dumps(bench.compact_record(full)))
+    assert back["north_star"]["n_gpus"] == 1 and back["north_star"]["fps_640"] > 0 and back["north_star"]["fps_1080p_weak"] > 0
+    assert back["north_star"]["configs2_fps"] > 0 and back["value_spread"]["median"] == 1.42e6
+    assert len(json.dumps(back)) <= bench.LINE_LIMIT
 
 
 def test_final_line_is_compact_and_round_trips():
