@@ -238,16 +238,23 @@ def compact_record(full):
               "settings_blob_crc32_rank0_before_broadcast", "north_star", "strong_scaling", "cli_config1"):
         if full.get(k) is not None:
             out[k] = full[k]
+    if not (out.get("collectives") or {}).get("initialized"):
+        out.pop("collectives", None)                 # one rank, no process group: nothing ran
+    if out.get("strong_scaling"):                    # (the long form stays in the full record; the weak figure is in north_star)
+        out["strong_scaling"] = {k: v for k, v in out["strong_scaling"].items() if k in ("T512_ms", "T64_ms", "projected_speedup_8gpu")}
+        out["strong_scaling"]["what"] = "configs[2] on ONE GPU, one batch in flight: T(512 frames) / T(64 = a GPU's share at 8)"
     rows = []
     for e in full.get("extra_workloads") or []:
         if not e:
             continue
         erf, eob = e.get("roofline") or {}, e.get("one_batch_in_flight") or {}
         # value = best of 1..3 batches in flight; one = ONE batch in flight (fps, ms per step, end-to-end fraction of 8 TB/s);
-        # kfrac = roofline.frac of the workload's dominant kernel (k_decode unless named)
+        # kfrac (the bandwidth-bound 1080p rows) = roofline.frac of the workload's dominant kernel (k_decode unless named)
         row = {"name": e["name"], "batch": (e.get("config") or {}).get("fields_per_gpu_per_step"), "value": _r(e["value"], 4),
                "one": _r(eob.get("value", e["value"]), 4), "ms_one": _r(eob.get("ms_per_step", e["ms_per_step"]), 4),
-               "frac_one": _r(eob.get("pipeline_frac", erf.get("pipeline_frac")), 3), "kfrac": _r(erf.get("frac"), 3)}
+               "frac_one": _r(eob.get("pipeline_frac", erf.get("pipeline_frac")), 3)}
+        if str(e["name"]).startswith("1080p"):
+            row["kfrac"] = _r(erf.get("frac"), 3)
         if erf.get("kernel") != "k_decode":
             row["kernel"] = erf.get("kernel")
         if e.get("cpu_baseline"):
@@ -560,7 +567,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                    "batches_in_flight_tuning": {str(c_): {"value": frames * steps / e_, "ms_per_step": 1e3 * e_ / steps,
                                                            "samples_ms_per_step": [round(1e3 * x / steps, 5) for x in samples[c_]]}
                                                 for c_, e_ in sorted(tuning.items())},
-                   "batches_in_flight_note": "step k runs on context / stream k % S; every context is an independent batch of "
+                   "batches_in_flight_note": "step k runs on context / stream k %% S; every context is an independent batch of "
                                              "fields_per_gpu_per_step television sets with its own state, signal and picture buffers; "
                                              "S tuned: every candidate timed %d times (round robin), chosen on the medians, then re-timed for the result" % R},
         "roofline": {"bound": "hbm", "kernel": "k_" + dom,

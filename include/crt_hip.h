@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 4
+#define CRTHIP_ABI_VERSION 5
 
 /* CRT_SYSTEM_* of crt_core.h:30-36 */
 #define CRTHIP_SYSTEM_NTSC    0
@@ -343,20 +343,14 @@ int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
  * throughput shape from 128 fields up (256 fields, three in flight: 1.13 M against 1.01 M fields/s). */
 int  crthip_set_shape(crthip_ctx *ctx, int shape);
 
-/* The sync chain of a fused field-pass (D2-D7: everything between the encoder and the decoder; its latency is the floor of a
- * small batch) runs BESIDE the encoder on a second stream of the context: it only reads sync pulses, bursts and blanking,
- * which the first kernel of the pass writes, and what it has to assume about the picture part -- that no candidate line of
- * the vertical sync search (crt_core.c:379-396) crosses the threshold there, that no hsync / burst window reaches into it --
- * is verified on the complete field before the decoder starts; a field that fails the check runs the chain again in the
- * old place.  Same results either way.  on = 1 (default) / 0: the chain after the encoder (A/B measurements, tests).
- * Environment: CRTHIP_SPEC_SYNC=0|1 sets the default of new contexts. */
-int  crthip_set_spec_sync(crthip_ctx *ctx, int on);
-/* After a crthip_fieldpass over n fields with d_state (synchronises): how many fields' speculative chains stood
- * (*n_committed) and how many had to be redone (*n_redone); both 0 when the pass did not speculate. */
-int  crthip_spec_sync_stats(crthip_ctx *ctx, int n, const crthip_state *d_state, int *n_committed, int *n_redone);
 
 /* Decoder output tile: 16 or 32 pixels per row and flush (0 = choose by output width, default). */
 int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
+/* Encoder signal tile of the fused path: how many bytes of a scanline leave the encoder per store piece.  0 (default) = by
+ * batch size (64-byte pieces; 128 / 256-byte pieces for batches that keep the chip full at the occupancy their LDS tile
+ * leaves), 16 = always the 64-byte pieces, 32 or 64 = always the large ones.  Same bytes either way (tests, A/B measurements).
+ * Environment: CRTHIP_SIG_TILE sets the default of new contexts. */
+int  crthip_set_signal_tile(crthip_ctx *ctx, int dwords);
 
 /* The decoder and encoder normally run kernels whose multiplies are the full-rate 24-bit
  * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,

@@ -121,8 +121,7 @@ def load_library():
     L.crthip_vhs_bind_history.argtypes = [vp, vp]
     L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_set_shape.argtypes = [vp, ci]
-    L.crthip_set_spec_sync.argtypes = [vp, ci]
-    L.crthip_spec_sync_stats.argtypes = [vp, ci, vp, C.POINTER(ci), C.POINTER(ci)]
+    L.crthip_set_signal_tile.argtypes = [vp, ci]
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
     L.crthip_vhs_chain.argtypes = [vp, ci, vp, ci]
     L.crthip_seq_vhs_prechained.argtypes = [vp, ci]
@@ -428,21 +427,13 @@ class CRT:
         (latency; a DPP row of lanes per scanline)."""
         self._check(self.L.crthip_set_shape(self.ctx, int(shape)), "crthip_set_shape")
 
-    def set_spec_sync(self, on):
-        """fieldpass(): the sync chain beside the encoder on the context's second stream, verified afterwards (default),
-        or after the encoder (0)."""
-        self._check(self.L.crthip_set_spec_sync(self.ctx, int(on)), "crthip_set_spec_sync")
-
-    def spec_sync_stats(self, n=None):
-        """(committed, redone) fields of the last fieldpass()'s speculative sync chains; (0, 0) if it did not speculate"""
-        a, b = C.c_int(0), C.c_int(0)
-        self._check(self.L.crthip_spec_sync_stats(self.ctx, int(n or self.n), self.state.data_ptr(), C.byref(a), C.byref(b)),
-                    "crthip_spec_sync_stats")
-        return a.value, b.value
-
     def set_overlap(self, chunks):
         """fieldpass(): split the batch into `chunks` pieces alternating between two streams."""
         self._check(self.L.crthip_set_overlap(self.ctx, int(chunks)), "crthip_set_overlap")
+
+    def set_signal_tile(self, dwords):
+        """fieldpass(): the encoder's signal tile -- 0 by batch size (default), 16 = 64-byte store pieces, 32 / 64 = the large ones"""
+        self._check(self.L.crthip_set_signal_tile(self.ctx, int(dwords)), "crthip_set_signal_tile")
 
     def set_pixel_tile(self, px):
         self._check(self.L.crthip_set_pixel_tile(self.ctx, int(px)), "crthip_set_pixel_tile")

@@ -77,34 +77,28 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
         unsigned char *o = (unsigned char *) d_out;
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
-#define CRTHIP_LAUNCH_DECODE(T, B3) \
-    do { if constexpr (S::CCS != 4 && T >= 4) break; /* no FIR build of the 5-sample system */ \
-         else if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); \
-         else hipLaunchKernelGGL((k_decode<S, T, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); } while (0)
+#define CRTHIP_LAUNCH_DECODE(TG, B3) \
+    do { if constexpr (S::CCS != 4 && TG == 2) break; /* no FIR build of the 5-sample system */ \
+         else if (wide) hipLaunchKernelGGL((k_decode<S, TG, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); \
+         else hipLaunchKernelGGL((k_decode<S, TG, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); } while (0)
             /* wide pictures in tiers 0 / 1: the 16-scanlines-per-wave kernel with 1 KB row runs (crt_decode4.hip); the groups
              * of the higher tiers stay with k_decode below */
             if (use_wide) {
                 const int rc = crt_run_decode_wide(c, p, n, d_inp, d_lines, d_out, ostride, min_tier, rank);
                 if (rc) return rc;
-                CRTHIP_LAUNCH_DECODE(2, false);
-                CRTHIP_LAUNCH_DECODE(3, false);
+                CRTHIP_LAUNCH_DECODE(1, false);
                 continue;
             }
-            /* every tier >= min_tier gets its pass; waves without lines of that tier leave at once */
+            /* one launch per tier GROUP that can be populated (0: tiers 0 / 1, 1: tiers 2 / 3, 2: the FIR tiers); waves of the
+             * other group leave at once */
             if (p->out_bpp == 3) {
-                if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, true);
-                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, true);
-                if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, true);
-                if (min_tier <= 3) CRTHIP_LAUNCH_DECODE(3, true);
-                if (min_tier == 4) CRTHIP_LAUNCH_DECODE(4, true);
-                if (min_tier >= 4) CRTHIP_LAUNCH_DECODE(5, true);
+                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(0, true);
+                if (min_tier <= 3) CRTHIP_LAUNCH_DECODE(1, true);
+                if (min_tier >= 4) CRTHIP_LAUNCH_DECODE(2, true);
             } else {
-                if (min_tier <= 0) CRTHIP_LAUNCH_DECODE(0, false);
-                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(1, false);
-                if (min_tier <= 2) CRTHIP_LAUNCH_DECODE(2, false);
-                if (min_tier <= 3) CRTHIP_LAUNCH_DECODE(3, false);
-                if (min_tier == 4) CRTHIP_LAUNCH_DECODE(4, false);
-                if (min_tier >= 4) CRTHIP_LAUNCH_DECODE(5, false);
+                if (min_tier <= 1) CRTHIP_LAUNCH_DECODE(0, false);
+                if (min_tier <= 3) CRTHIP_LAUNCH_DECODE(1, false);
+                if (min_tier >= 4) CRTHIP_LAUNCH_DECODE(2, false);
             }
 #undef CRTHIP_LAUNCH_DECODE
         }

@@ -150,19 +150,16 @@ int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, con
             const dim3 grid((unsigned) (slots / 64)), block(64);
             unsigned char *o = (unsigned char *) d_out;
             for (int rank = 0; rank < passes; rank++) {
-#define CRTHIP_LAUNCH_BLOOM(T, B3) \
-    do { if (wide) hipLaunchKernelGGL((k_decode<S, T, B3, 32, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm); \
-         else hipLaunchKernelGGL((k_decode<S, T, B3, 16, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm); } while (0)
+#define CRTHIP_LAUNCH_BLOOM(TG, B3) \
+    do { if (wide) hipLaunchKernelGGL((k_decode<S, TG, B3, 32, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm); \
+         else hipLaunchKernelGGL((k_decode<S, TG, B3, 16, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm); } while (0)
+                /* tier groups as in crt_run_decode: 0 = tiers 0 / 1 (tier 1 only ever holds lines of the 5-sample system here), 1 = 2 / 3 */
                 if (p->out_bpp == 3) {
-                    if (min_tier <= 0) CRTHIP_LAUNCH_BLOOM(0, true);
-                    if constexpr (S::CCS == 5) { if (min_tier <= 1) CRTHIP_LAUNCH_BLOOM(1, true); }
-                    if (min_tier <= 2) CRTHIP_LAUNCH_BLOOM(2, true);
-                    CRTHIP_LAUNCH_BLOOM(3, true);
+                    if (min_tier <= 1) CRTHIP_LAUNCH_BLOOM(0, true);
+                    CRTHIP_LAUNCH_BLOOM(1, true);
                 } else {
-                    if (min_tier <= 0) CRTHIP_LAUNCH_BLOOM(0, false);
-                    if constexpr (S::CCS == 5) { if (min_tier <= 1) CRTHIP_LAUNCH_BLOOM(1, false); }
-                    if (min_tier <= 2) CRTHIP_LAUNCH_BLOOM(2, false);
-                    CRTHIP_LAUNCH_BLOOM(3, false);
+                    if (min_tier <= 1) CRTHIP_LAUNCH_BLOOM(0, false);
+                    CRTHIP_LAUNCH_BLOOM(1, false);
                 }
 #undef CRTHIP_LAUNCH_BLOOM
             }

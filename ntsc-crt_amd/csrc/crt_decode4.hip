@@ -26,8 +26,9 @@
  * bit (tests/test_gpu_parity.py: every 1080p case runs through here).
  */
 #include "crt_decode_lane.h"
+#include <type_traits>
 
-#define WIDE_LPW   16                 /* scanlines per wave */
+#define WIDE_LPW   16                 /* scanlines per wave (throughput); small batches: 8, see k_decode_wide */
 #define WIDE_RING  128                /* samples per scanline in the y/i/q ring */
 #define WIDE_PXT   256                /* pixels per row run: 64 lanes x 4 */
 
@@ -37,7 +38,7 @@ __device__ __forceinline__ void lds_store16_lanes(unsigned addr, int v, unsigned
 {
     unsigned long long saved;
     asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tds_write_b16 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "v"(addr), "v"(v), "s"(lanes) : "memory");
+                 : "=&s"(saved) : "v"(addr), "v"(v), "s"(lanes) : "memory", "scc");      /* s_and_b64 writes SCC */
 }
 
 /* v_mad_i64_i32 with a per-lane multiplier */
@@ -48,14 +49,19 @@ __device__ __forceinline__ long mad64_vv(int d, int m, long acc)
     return r;
 }
 
-template <class S, int TIER>
+/* LPW = scanlines per wave.  16 fills the filter stage's 64 lanes (four cascades per scanline).  8 leaves half of them idle there
+ * but makes twice as many waves, each half as long: a batch of 64 fields of 1920x1080 is 960 waves of 16 scanlines on 1024 SIMDs --
+ * less than one wave per SIMD, each walking its 16 x 1920 pixels alone -- and 1920 waves of 8 (VERDICT round 4, item 3b;
+ * profiles/r05_experiments.txt section 6). */
+template <class S, int LPW>
 __global__ void __launch_bounds__(64)
 k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
               const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
               int want_rank, int n_px, unsigned ppos_end)
 {
-    static_assert(S::CCS == 4 && TIER <= 1, "tiers 0 / 1 of the 4-samples-per-cycle systems");
-    constexpr int LPW = WIDE_LPW, RING = WIDE_RING;
+    static_assert(S::CCS == 4, "tiers 0 / 1 of the 4-samples-per-cycle systems");
+    static_assert(LPW == 16 || LPW == 8, "scanlines per wave");
+    constexpr int RING = WIDE_RING;
     constexpr int IN_DW = 16, IN_STRIDE = IN_DW + 1;
     /* LDS, 13.5 KB (12 waves per CU): the { q, i } ring -- one dword per sample --, the luma ring -- 16-bit values, scanlines l and
      * l + 8 sharing a dword so that both rings are addressed by sample * 4 -- and the input tile (64 samples per scanline).
@@ -63,25 +69,29 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
      * stores sample x of all 16 scanlines with ONE instruction, and at a stride of 128 dwords its 32-lane halves met on a single bank
      * (SQ_LDS_BANK_CONFLICT: 80 % of all LDS cycles, the filter stage alone 1.35 ms at 1080p x 2048 -- profiles/r04_experiments.txt 10) */
     constexpr int RSTRIDE = RING + 1;
-    constexpr int OFF_IQ = 0, OFF_Y = LPW * RSTRIDE * 4, OFF_IN = OFF_Y + LPW / 2 * RSTRIDE * 4;
+    constexpr int OFF_IQ = 0, OFF_Y = LPW * RSTRIDE * 4 + (LPW == 8 ? 32 : 0), OFF_IN = OFF_Y + 8 * RSTRIDE * 4 + (LPW == 8 ? 32 : 0);
     static_assert((OFF_Y / 4) % 32 == 16 && OFF_IN % 16 == 0, "bank offset of the luma ring, alignment of the input tile");
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[OFF_IN + LPW * IN_STRIDE * 4];
     unsigned *const s_in = (unsigned *) (s_mem + OFF_IN);
 
     const int lane = threadIdx.x, l = lane >> 2, c = lane & 3; /* my scanline of the wave, my cascade */
+    const bool has_line = l < LPW;                             /* (LPW 8: the upper half-wave has no scanline of its own; it emits pixels) */
     const int total = n_fields * S::LINES;
+    int tier;
     {
-        /* the tier of the 64-scanline group my scanlines belong to: the decision of k_decode, flag for flag */
+        /* the tier of the 64-scanline group my scanlines belong to: the decision of k_decode, flag for flag; tiers 0 and 1 are
+         * both decoded here (they differ in ONE instruction of the filter stage, chosen per wave), the groups of tiers 2 / 3 are
+         * k_decode's */
         const int g = (int) (blockIdx.x * LPW) / 64 * 64 + lane;
         int fl = 0;
         if (g < total) fl = lines[g].nrows;
-        int tier = __ballot(fl & CRTHIP_LINE_EXACT) ? 3 : __ballot(fl & CRTHIP_LINE_NOT64) ? 2 : __ballot(fl & CRTHIP_LINE_WIDE) ? 1 : 0;
+        tier = __ballot(fl & CRTHIP_LINE_EXACT) ? 3 : __ballot(fl & CRTHIP_LINE_NOT64) ? 2 : __ballot(fl & CRTHIP_LINE_WIDE) ? 1 : 0;
         if (tier < 2 && __ballot(fl & (int) CRTHIP_LINE_KEEPLO) != 0ull) tier = 2;
         if (tier < min_tier) tier = min_tier;
-        if (tier != TIER) return;
+        if (tier > 1) return;
     }
     const int gl = blockIdx.x * LPW + l;
-    const bool live = gl < total;
+    const bool live = has_line && gl < total;
     crthip_line lp;
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0; lp.dx = 0; lp.scanl = 0;
     if (live) lp = lines[gl];
@@ -129,23 +139,27 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
         /* ---- filter: every sample the run's pixels need (taps idx and idx + 1, crt_core.c:555-558) ---- */
         const int pxl = px0 + WIDE_PXT - 1 < n_px - 1 ? px0 + WIDE_PXT - 1 : n_px - 1;
         const int x_need = (int) (((unsigned) pxl * dx) >> 12) + 2;
+        auto filter_run = [&](auto tier_tag) {
+        constexpr int TIER = decltype(tier_tag)::value;
         while (xq * 4 < x_need && xq < NQ) {
             const int t = xq >> 4;
             if (t != have_tile) {
                 wave_lds_fence();
-                unsigned *d = s_in + l * IN_STRIDE + c * 4;
-                d[0] = (unsigned) nxt.x; d[1] = (unsigned) nxt.y; d[2] = (unsigned) nxt.z; d[3] = (unsigned) nxt.w;
+                if (has_line) {
+                    unsigned *d = s_in + l * IN_STRIDE + c * 4;
+                    d[0] = (unsigned) nxt.x; d[1] = (unsigned) nxt.y; d[2] = (unsigned) nxt.z; d[3] = (unsigned) nxt.w;
+                }
                 wave_lds_fence();
                 have_tile = t;
                 if (t + 1 < NT) nxt = gload16u(src + (t + 1) * (IN_DW * 4) + c * 16);
             }
-            const int word = (int) s_in[l * IN_STRIDE + (xq & (IN_DW - 1))];
+            const int word = (int) s_in[(has_line ? l : 0) * IN_STRIDE + (xq & (IN_DW - 1))];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = xq * 4 + k;
                 const int s = (word << (24 - 8 * k)) >> 24;
                 /* my cascade's input: s + bright | (s * wave) >> 9, as the high word of the product with the pre-scaled multiplier */
-                const int ut = TIER == 0 ? __mul24(s, wk[k]) : mul_lo_mad64(s, wk[k]);
+                const int ut = TIER == 0 ? __mul24(s, wk[k]) : mul_lo_mad64(s, wk[k]);      /* tier 1: carriers << 7 beyond 24 bits */
                 const int u = add_hiword(bl, ut);
                 /* four stages, eq_step64: x' = hi32(M * (in - x) + {2^31, near1 ? in : x}) */
 #define WIDE_STAGE(X, IN) X = hi32(mad64_vv((IN) - X, M, pair_of(near1 ? (IN) : X)))
@@ -161,10 +175,12 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
                 const int nb = __builtin_amdgcn_mov_dpp(x3, 0xe0 /* quad_perm:[0,0,2,3] */, 0xf, 0xf, true);
                 const int tt = x3 - nb;
                 const int out = (r - tt + (tt >> 3)) >> sh;
-                lds_store16_lanes(wbase + (unsigned) (x & (RING - 1)) * 4u, out, 0xeeeeeeeeeeeeeeeeull);
+                lds_store16_lanes(wbase + (unsigned) (x & (RING - 1)) * 4u, out, LPW == 16 ? 0xeeeeeeeeeeeeeeeeull : 0x00000000eeeeeeeeull);
             }
             xq++;
         }
+        };
+        if (tier == 0) filter_run(std::integral_constant<int, 0>{}); else filter_run(std::integral_constant<int, 1>{});
         wave_lds_fence();
         /* ---- pixels: scanline after scanline, lane = four consecutive pixels of the run ---- */
         const int px = px0 + 4 * lane;
@@ -248,17 +264,21 @@ int crt_run_decode_wide(crthip_ctx *c, const crthip_params *p, int n, const sign
         using S = decltype(tag);
         if constexpr (S::CCS == 4) {
             const int total = n * S::LINES;
-            const dim3 grid((total + WIDE_LPW - 1) / WIDE_LPW), block(64);
+            /* 8 scanlines per wave while 16 would leave SIMDs without a wave of their own twice over (see the kernel);
+             * CRTHIP_WIDE_LPW=8|16 pins it (A/B) */
+            const int lpw = c->wide_lpw_env ? c->wide_lpw_env : (total / WIDE_LPW < WIDE_LPW8_MAX_WAVES ? 8 : 16);
+            const dim3 grid((total + lpw - 1) / lpw), block(64);
             /* pixels the reference emits per scanline: px * dx < min(dx * outw, (AV_LEN - 1) << 12)  (crt_core.c:528-531, 555) */
             const unsigned long long all = (unsigned long long) (unsigned) p->dx * (unsigned) p->outw;
             const unsigned scan_r = (unsigned) (S::AV_LEN - 1) << 12;
             const unsigned ppos_end = all < scan_r ? (unsigned) all : scan_r;
             const int n_px = (int) ((ppos_end + (unsigned) p->dx - 1) / (unsigned) p->dx);
-            if (min_tier <= 0)
-                hipLaunchKernelGGL((k_decode_wide<S, 0>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
+            if (lpw == 8)
+                hipLaunchKernelGGL((k_decode_wide<S, 8>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
                                    min_tier, rank, n_px, ppos_end);
-            hipLaunchKernelGGL((k_decode_wide<S, 1>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
-                               min_tier, rank, n_px, ppos_end);
+            else
+                hipLaunchKernelGGL((k_decode_wide<S, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
+                                   min_tier, rank, n_px, ppos_end);
         }
         return CRTHIP_OK;
     });

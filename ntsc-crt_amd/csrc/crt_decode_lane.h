@@ -4,6 +4,7 @@
 #ifndef CRT_DECODE_LANE_H
 #define CRT_DECODE_LANE_H
 #include "crt_dev.h"
+#include <type_traits>
 
 /* ------------------------------------------------------------------------- */
 /* D8-D10: equalisers + resample + YIQ->RGB, one lane per CRT line              */
@@ -208,14 +209,16 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * width line_w alone.  The 64 lines of a wave are then not neighbours but lines of EQUAL line_w, gathered by `perm` (the
  * counting sort of crt_decode3.hip; -1 = padding), so the pixel schedule stays wave-uniform; the filters run over
  * [scanL >> 12, AV_LEN - 1) only and the entry AV_LEN - 1 of the reference's yiq buffer is never written (zero). */
-template <class S, int TIER, bool BPP3, int PXT, bool BLOOM = false>
+/* TG = tier GROUP of this launch: 0 -> tiers 0 / 1, 1 -> tiers 2 / 3, 2 -> tiers 4 / 5 (FIR).  A wave takes the loop compiled for
+ * its own tier -- two copies of the line loop in one kernel, chosen once per wave -- so that a field-pass launches two decoder
+ * kernels where it launched four, three of which usually had nothing to do (5 us each in a 230 us step). */
+template <class S, int TG, bool BPP3, int PXT, bool BLOOM = false>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
          int want_rank, const int *__restrict__ perm)
 {
-    constexpr bool FAST = TIER <= 2 || TIER == 4;   /* 24-bit multiplies outside the filter stages */
-    constexpr bool FIR = TIER >= 4;
+    constexpr int TLO = 2 * TG;
     constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
     __shared__ unsigned s_in[64 * IN_STRIDE];
     constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
@@ -240,7 +243,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     if (tier < 2 && __ballot(lp.nrows & (int) CRTHIP_LINE_KEEPLO) != 0ull) tier = 2;
     if (min_tier >= 4) tier = (min_tier == 5 || tier == 3) ? 5 : 4;     /* FIR build: 24-bit envelope as for tier 2 */
     else if (tier < min_tier) tier = min_tier;
-    if (tier != TIER) return;
+    if (tier != TLO && tier != TLO + 1) return;
     int nrows = lp.nrows & CRTHIP_LINE_NROWS_MASK;
     const int rank = (lp.nrows >> CRTHIP_LINE_RANK_SHIFT) & CRTHIP_LINE_RANK_MASK;
     if (!live || rank != want_rank) nrows = 0;
@@ -248,6 +251,13 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     /* Bloom: the sort hands every wave lines of ONE geometry (see crt_decode3.hip for why their width is bounded).  Should
      * a wave ever hold more than one -- a line table that did not come from k_bloom, through crthip_decode -- it is decoded
      * in rounds, one geometry at a time, the other lanes idling: correct for any table, free for the tables that occur. */
+    /* 5 samples per chroma cycle: the line's carrier pairs by sample phase, [lane][phase]{I, Q} at an odd row stride (below) */
+    constexpr int W5_STRIDE = 11;
+    __shared__ int s_w5[S::CCS == 5 ? 64 * W5_STRIDE : 1];
+  auto decode_lines = [&](auto tier_tag) {
+    constexpr int TIER = decltype(tier_tag)::value;
+    constexpr bool FAST = TIER <= 2 || TIER == 4;   /* 24-bit multiplies outside the filter stages */
+    constexpr bool FIR = TIER >= 4;
     int nrows_todo = nrows;
   do {
     int scanl_u = 0, dx_u = P.dx;
@@ -273,8 +283,6 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
      * of the five sample phases follow from them with the blob's cos / sin tables; the phase of a sample is wave-uniform */
     /* ... so the carrier pair of a sample is ONE LDS read at a scalar offset ([lane][phase]{I, Q}, odd row stride), where
      * selecting among five per-lane registers costs four v_cndmask per carrier (round 3: 3.35 -> 3.08 ms per 4096 fields) */
-    constexpr int W5_STRIDE = 11;
-    __shared__ int s_w5[S::CCS == 5 ? 64 * W5_STRIDE : 1];
     if constexpr (S::CCS == 5) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
@@ -478,6 +486,9 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                         const unsigned long long dd = d + (size_t) dup * pitch;
                                         if (have >= 4) {
                                             v4i o; o.x = (int) v[0]; o.y = (int) v[1]; o.z = (int) v[2]; o.w = (int) v[3];
+#if defined(DEC_DBG) && DEC_DBG == 1          /* measurement build: no picture stores (the alpha byte is never 0) */
+                                            if (o.x != 0) continue;
+#endif
                                             gstore16u_nt(dd, o);   /* nontemporal: plain stores measured 5 % slower here and slow the encoder down too (profiles/r03_1080p_experiments.txt) */
                                         } else {
                                             gstore32(dd, v[0]);
@@ -521,6 +532,9 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     }
     wave_lds_fence();
   } while (BLOOM && __ballot(nrows_todo > 0) != 0ull);
+  };
+    if (tier == TLO) decode_lines(std::integral_constant<int, TLO>{});
+    else decode_lines(std::integral_constant<int, TLO + 1>{});
 }
 
 

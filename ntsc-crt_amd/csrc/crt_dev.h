@@ -387,11 +387,12 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * 512 fields: 0.672 ms with the lane-shaped encoder, 0.734 with the row-shaped one) */
 #define ROWS_SHAPE_MAX_FIELDS 128          /* k_decode_row */
 #define ROWS_SHAPE_MAX_FIELDS_ENC 256      /* k_active_row */
-/* k_active's 256-byte signal pieces need 16.6 KB of LDS per wave (6 waves per CU beside the wide image tile, 7 beside the narrow
- * one): taken from this many waves on, i.e. four residency rounds of that occupancy (1080p: 1638 fields; profiles/r04_experiments.txt
- * section 19 has the cliff below it, profiles/r05_experiments.txt the A/B) */
-#define SIG_TILE64_MIN_WAVES_WIDE 6144
-#define SIG_TILE64_MIN_WAVES      7168
+/* k_active's larger signal pieces cost LDS, i.e. occupancy: taken from this many waves (64 destination rows each) on -- about four
+ * residency rounds at the occupancy they leave (1080p: 1638 fields; 640x480: 1792 fields).  Below: a second, half-empty round costs
+ * more than the pieces give (profiles/r04_experiments.txt section 19, profiles/r05_experiments.txt sections 2-4) */
+#define SIG_TILE64_MIN_WAVES_WIDE 6144     /* wide image tile (w >= 1280): 256-byte pieces */
+#define SIG_TILE32_MIN_WAVES      6720     /* narrow image tile: 128-byte pieces */
+#define WIDE_LPW8_MAX_WAVES 2048           /* k_decode_wide: 8 scanlines per wave while 16 per wave would make fewer waves than this (1080p: < 137 fields) */
 #define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
 
 #define CRTHIP_MAX_CHUNKS 64               /* crthip_set_overlap */
@@ -413,18 +414,6 @@ __host__ __device__ constexpr int vhs_tail_start(int input_size, int hres)
 /* ------------------------------------------------------------------------- */
 /* host side: context, dispatch by system, C ABI                               */
 /* ------------------------------------------------------------------------- */
-#define SYNC_FULL 0              /* crt_run_sync modes, see k_hsync_wave (crt_sync.hip) */
-#define SYNC_SPEC 1
-#define SYNC_VERIFY 2
-/* what the speculative sync pass (k_hsync_wave<SYNC_SPEC>) found for a field, for the verifying pass to commit or discard */
-struct crthip_spec {
-    int ok;                     /* no window of the chain reached into the encoder's active rectangle */
-    int vsync, odd_field;       /* the vertical sync it assumed (picture part of the candidate lines masked) */
-    int hsync;                  /* the field's final hsync */
-    int ccf[CRTHIP_MAX_VPER][CRTHIP_MAX_CCS];   /* ... and burst integrators */
-    int pad[3];
-};                              /* 128 bytes */
-
 struct crthip_ctx {
     int device;
     int system, pattern;
@@ -438,9 +427,6 @@ struct crthip_ctx {
     int cap_fields;
     signed char *d_analog, *d_inp;
     crthip_line *d_lines;
-    crthip_spec *d_spec;        /* per field: the speculative sync pass's record */
-    bool spec_ran;              /* the last crthip_fieldpass speculated (crthip_spec_sync_stats) */
-    int spec_sync;              /* CRTHIP_SPEC_SYNC: 1 (default) = the sync chain beside the encoder on the second stream, 0 = after it */
     /* profiling */
     bool force_exact;           /* debug/test: never use the 24-bit fast kernels */
     bool no_tier0;              /* debug/test: never use the 64-bit-mad decoder tiers */
@@ -457,8 +443,7 @@ struct crthip_ctx {
     int skel_yo;                /* ... and the first active line (NES timing: the burst is only on the active lines) */
     int shape;                  /* crthip_set_shape: 0 auto, 1 lane-per-scanline, 2 scanline-parallel */
     int row_tile;               /* CRTHIP_ROW_TILE: samples per tile of the scanline-parallel decoder, 32 (default) or 16 */
-    int sync_kernel;            /* CRTHIP_SYNC_KERNEL: 0 by batch size, 1 k_hsync (4 fields per wave), 2 k_hsync_wave (field per wave) */
-    bool legacy_sync;           /* CRTHIP_LEGACY_SYNC=1 in the environment: the 16-lanes-per-field sync kernel (A/B measurements) */
+    int sync_kernel;            /* CRTHIP_SYNC_KERNEL: 0 by batch size, 2 / 3 = k_hsync_wave with 1 / 4 fields per workgroup (A/B measurements) */
     uint2 *d_jump1;             /* LCG affine maps of 0..15 steps */
     int *d_bloom;               /* bloom build, lane-per-scanline decoder: line_w histogram, cursors, slot -> line (crt_decode3.hip) */
     size_t bloom_cap;
@@ -476,7 +461,8 @@ struct crthip_ctx {
     int px_tile;                /* 0 = by output width, else 16 / 32 (tuning / tests) */
     int ac_tile;                /* encoder tile, same convention, by input width */
     int ac_tile_env;            /* CRTHIP_AC_TILE: overrides both (A/B measurements) */
-    int sig_tile_env;           /* CRTHIP_SIG_TILE = 16 | 64: pins k_active's signal tile (A/B measurements); 0 = by batch size */
+    int wide_lpw_env;           /* CRTHIP_WIDE_LPW = 8 | 16: pins k_decode_wide's scanlines per wave (A/B measurements); 0 = by batch size */
+    int sig_tile_env;           /* CRTHIP_SIG_TILE = 16 | 32 | 64: pins k_active's small / large signal tile (A/B measurements); 0 = by batch size */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join, ev_chunk[CRTHIP_MAX_CHUNKS];
@@ -589,9 +575,6 @@ static inline int crt_ensure_aux(crthip_ctx *c)
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                     signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state);
 int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state);
-int crt_run_encoder_margins(crthip_ctx *c, const crthip_params *p, int n, signed char *dst, crthip_state *d_state);
-int crt_run_encoder_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                           signed char *dst, crthip_state *d_state);
 int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused);
 int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
                   crthip_state *d_state, bool advance_rn);
@@ -599,7 +582,7 @@ int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
 int crt_run_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration);
 int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthip_state *d_state);
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
-                 crthip_line *d_lines, int advance_rn, int mode = 0);
+                 crthip_line *d_lines, int advance_rn, int preset_ccf = 0);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
                    const crthip_line *d_lines, void *d_out, size_t ostride);
 bool crt_decode_wide_ok(const crthip_ctx *c, const crthip_params *p, int min_tier, bool wide);

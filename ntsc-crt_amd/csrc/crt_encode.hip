@@ -993,14 +993,21 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const bool wide_in = c->ac_tile_env ? c->ac_tile_env == 32 : c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
     /* signal pieces of 256 bytes where the batch keeps the chip full at the 6-7 waves per CU their tile leaves (fused throughput
      * path, 4-byte pixels, fast envelope); CRTHIP_SIG_TILE=16|64 pins the choice (A/B) */
-    if constexpr (FULL && FAST && !S::IS_NES) {
-        const int big = c->sig_tile_env ? c->sig_tile_env == 64 : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE64_MIN_WAVES);
+    /* Larger signal pieces where the batch keeps the chip full at the lower occupancy their tile leaves (fused throughput path,
+     * 4-byte pixels, fast envelope): 256-byte pieces beside the wide image tile (26 KB of LDS, 6 waves per CU), 128-byte pieces
+     * beside the narrow one (12.7 KB, 12 waves per CU).  Measured per batch size and system in profiles/r05_experiments.txt
+     * (sections 2-4): 1080p x 2048 k_active 0.86 -> 0.79 ms, 640x480 x 4096 1.05 -> 0.98, VHS / bloom / 720p -4..9 %; below the
+     * thresholds (and for the 5-sample system, whose carrier table shares the LDS) the 64-byte pieces stay the faster ones.
+     * CRTHIP_SIG_TILE=16 pins the small tile, =32 / =64 the large one whatever the batch (A/B). */
+    if constexpr (FULL && FAST && !S::IS_NES && S::CCS == 4) {
+        const bool big = c->sig_tile_env ? c->sig_tile_env != 16
+                                         : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
         if (in4 && big) {
-#define CRTHIP_LAUNCH_ACTIVE64(NZ) \
+#define CRTHIP_LAUNCH_ACTIVE_BIG(NZ) \
     do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
-         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 64>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
-            if (noise) CRTHIP_LAUNCH_ACTIVE64(true); else CRTHIP_LAUNCH_ACTIVE64(false);
-#undef CRTHIP_LAUNCH_ACTIVE64
+         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
+            if (noise) CRTHIP_LAUNCH_ACTIVE_BIG(true); else CRTHIP_LAUNCH_ACTIVE_BIG(false);
+#undef CRTHIP_LAUNCH_ACTIVE_BIG
             return;
         }
     }
@@ -1180,24 +1187,7 @@ int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_
     });
 }
 
-/* the two halves of the fused encoder on their own (the speculative sync chain is forked between them, crt_host.hip) */
-int crt_run_encoder_margins(crthip_ctx *c, const crthip_params *p, int n, signed char *dst, crthip_state *d_state)
-{
-    return dispatch_system(c->system, c->pattern, [&](auto tag) {
-        launch_margins<decltype(tag)>(c, p, n, dst, d_state);
-        return CRTHIP_OK;
-    });
-}
-
-int crt_run_encoder_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                           signed char *dst, crthip_state *d_state)
-{
-    return dispatch_system(c->system, c->pattern, [&](auto tag) {
-        launch_active_any<decltype(tag), true>(c, p, n, d_images, istride, dst, d_state);
-        return CRTHIP_OK;
-    });
-}
-
+/* the ccf preset as a launch of its own: sequence mode re-runs the sync chain from it (crt_host.hip) */
 int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {

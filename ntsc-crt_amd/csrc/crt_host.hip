@@ -186,15 +186,12 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     }
     c->stream = 0;              /* the device's default stream until crthip_set_stream() */
     c->overlap_chunks = 0;      /* automatic */
-    { const char *e = getenv("CRTHIP_LEGACY_SYNC"); c->legacy_sync = e && e[0] == '1'; }
     { const char *e = getenv("CRTHIP_SYNC_KERNEL"); c->sync_kernel = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_ROW_TILE"); c->row_tile = e ? atoi(e) : 0; }
-    /* the sync chain beside the encoder (k_hsync_wave SYNC_SPEC / SYNC_VERIFY): off unless asked for -- measured neutral to
-     * slightly negative except for mid-size wide batches (profiles/r04_spec_sync.txt) */
-    { const char *e = getenv("CRTHIP_SPEC_SYNC"); c->spec_sync = e ? atoi(e) != 0 : 0; }
     { const char *e = getenv("CRTHIP_WIDE_DECODE"); c->wide_decode = e ? atoi(e) != 0 : 1; }     /* A/B switch, crt_decode4.hip */
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
-    { const char *e = getenv("CRTHIP_SIG_TILE"); c->sig_tile_env = e && (atoi(e) == 16 || atoi(e) == 64) ? atoi(e) : 0; }   /* A/B switch, k_active */
+    { const char *e = getenv("CRTHIP_WIDE_LPW"); c->wide_lpw_env = e && (atoi(e) == 8 || atoi(e) == 16) ? atoi(e) : 0; }   /* A/B switch, k_decode_wide */
+    { const char *e = getenv("CRTHIP_SIG_TILE"); c->sig_tile_env = e && (atoi(e) == 16 || atoi(e) == 32 || atoi(e) == 64) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
     const int nq = sd.input_size / 16 + 2;
@@ -304,7 +301,6 @@ void crthip_destroy(crthip_ctx *c)
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
-    if (c->d_spec) hipFree(c->d_spec);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -337,8 +333,7 @@ int crthip_reserve(crthip_ctx *c, int n)
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
     if (c->d_vhs_next) hipFree(c->d_vhs_next);
-    if (c->d_spec) hipFree(c->d_spec);
-    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->d_vhs_next = 0; c->d_spec = 0; c->cap_fields = 0;
+    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->d_vhs_next = 0; c->cap_fields = 0;
     const size_t bytes = c->fstride * (size_t) n + 4096;
     if (hipMalloc((void **) &c->d_inp, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc inp", hipSuccess);
     if (hipMalloc((void **) &c->d_analog, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc analog", hipSuccess);
@@ -347,13 +342,10 @@ int crthip_reserve(crthip_ctx *c, int n)
     if (c->system == CRTHIP_SYSTEM_NTSCVHS &&
         hipMalloc((void **) &c->d_vhs_next, sizeof(unsigned) * 32 * (size_t) n) != hipSuccess)
         return set_err(c, CRTHIP_E_NOMEM, "hipMalloc VHS histories", hipSuccess);
-    if (hipMalloc((void **) &c->d_spec, sizeof(crthip_spec) * (size_t) n) != hipSuccess)
-        return set_err(c, CRTHIP_E_NOMEM, "hipMalloc sync records", hipSuccess);
-    /* the second stream of the speculative sync pass exists from here on: a field-pass creates nothing (graph capture) */
+    /* the internal second stream (VHS noise pair, overlap chunks) exists from here on: a field-pass creates nothing (graph capture) */
     if (crt_ensure_aux(c) != CRTHIP_OK) return set_err(c, CRTHIP_E_HIP, "internal stream", hipGetLastError());
     HIPCHK(c, hipMemsetAsync(c->d_inp, 0, bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_analog, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_spec, 0, sizeof(crthip_spec) * (size_t) n, c->stream));
     if (!c->sd.nes_timing) {                    /* bloom builds (none with the NES timing): the decoder's sort scratch, 4 bytes per scanline */
         const int rc = crt_reserve_bloom(c, n);
         if (rc) return rc;
@@ -470,6 +462,7 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     signed char *analog = c->d_analog + (size_t) first * c->fstride;
     crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
     int rc = CRTHIP_OK;
+    bool preset = false;
     if (part & 1) {
         const bool vhs_rand = c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
         if (vhs_rand || (p->flags & CRTHIP_F_NO_VSYNC)) {
@@ -495,38 +488,11 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
             part &= ~4;
         } else {
             if (enc == 0) {
-                /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised */
-                const bool legacy = c->legacy_sync || c->sync_kernel == 1;
-                if (part == 7 && c->spec_sync && !legacy && p->out_bpp != 0 && c->d_spec && c->aux_stream) {
-                    /* The sync chain BESIDE the encoder (k_hsync_wave, SYNC_SPEC / SYNC_VERIFY): it reads the margins, which
-                     * are complete after k_margin; what it assumes about the picture part is checked afterwards.
-                     *   caller's stream : ccf preset, margins, [fork] active video ............ [join] verify (+ bloom), decoder
-                     *   second stream   :                      [fork] speculative sync chain  [join]
-                     * The ccf preset (M6) moves to the front: it is image independent and the chain starts from it. */
-                    const crthip_params q = with_signal_envelope(p);
-                    hipStream_t main_stream = c->stream;
-                    c->spec_ran = true;
-                    rc = crt_run_encoder_state(c, p, n, st);
-                    if (rc) return rc;
-                    rc = crt_run_encoder_margins(c, p, n, inp, st);
-                    if (rc) return rc;
-                    HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
-                    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-                    c->stream = c->aux_stream;
-                    rc = crt_run_sync(c, &q, n, inp, st, ln, 0, SYNC_SPEC);
-                    c->stream = main_stream;
-                    if (rc) return rc;
-                    HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
-                    rc = crt_run_encoder_active(c, p, n, img, istride, inp, st);
-                    if (rc) return rc;
-                    HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-                    rc = crt_run_sync(c, &q, n, inp, st, ln, 1, SYNC_VERIFY);
-                    if (rc) return rc;
-                    part &= ~4;
-                } else {
-                    c->spec_ran = false;
-                    rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, true);
-                }
+                /* the encoder writes the noisy field straight into inp[]; analog[] is never materialised.  What crt_modulate
+                 * leaves in the state (ccf preset, M6) is applied by the sync chain's own waves when it follows at once
+                 * (k_hsync_wave, preset_ccf): one launch less per field-pass */
+                preset = (part & 4) && p->out_bpp != 0 && c->system != CRTHIP_SYSTEM_NTSCVHS;   /* (VHS also resets hsync there) */
+                rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, !preset);
             } else {
                 /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise
                  * (rn is advanced by k_vsync below) */
@@ -538,7 +504,7 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     }
     if ((part & 4) && p->out_bpp != 0) {
         const crthip_params q = enc == 0 ? with_signal_envelope(p) : *p;
-        rc = crt_run_sync(c, &q, n, inp, st, ln, 1);
+        rc = crt_run_sync(c, &q, n, inp, st, ln, 1, preset ? 1 : 0);
         if (rc) return rc;
     }
     if ((part & 2) && p->out_bpp != 0) rc = crt_run_decode(c, p, n, inp, ln, out, ostride);
@@ -610,6 +576,13 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     }
     if (rc) return rc;
     HIPCHK(c, hipGetLastError());
+    return CRTHIP_OK;
+}
+
+int crthip_set_signal_tile(crthip_ctx *c, int dwords)
+{
+    if (!c || (dwords != 0 && dwords != 16 && dwords != 32 && dwords != 64)) return CRTHIP_E_ARG;
+    c->sig_tile_env = dwords;
     return CRTHIP_OK;
 }
 
@@ -850,37 +823,6 @@ int crthip_set_shape(crthip_ctx *c, int shape)
 {
     if (!c || shape < 0 || shape > 2) return CRTHIP_E_ARG;
     c->shape = shape;
-    return CRTHIP_OK;
-}
-
-int crthip_set_spec_sync(crthip_ctx *c, int on)
-{
-    if (!c) return CRTHIP_E_ARG;
-    c->spec_sync = on != 0;
-    return CRTHIP_OK;
-}
-
-int crthip_spec_sync_stats(crthip_ctx *c, int n, const crthip_state *d_state, int *n_committed, int *n_redone)
-{
-    if (!c || n <= 0 || !d_state) return CRTHIP_E_ARG;
-    if (n_committed) *n_committed = 0;
-    if (n_redone) *n_redone = 0;
-    if (!c->spec_ran || !c->d_spec || n > c->cap_fields) return CRTHIP_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    crthip_spec *sp = (crthip_spec *) malloc(sizeof(crthip_spec) * (size_t) n);
-    crthip_state *st = (crthip_state *) malloc(sizeof(crthip_state) * (size_t) n);
-    if (!sp || !st) { free(sp); free(st); return CRTHIP_E_NOMEM; }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(sp, c->d_spec, sizeof(crthip_spec) * (size_t) n, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(st, d_state, sizeof(crthip_state) * (size_t) n, hipMemcpyDeviceToHost);
-    int ok = 0;
-    /* (the verifying pass's criterion, evaluated on what it left in the state; fields of a 4-field workgroup that were redone
-     * along with a failing neighbour count as committed here: their record was right) */
-    for (int k = 0; e == hipSuccess && k < n; k++) ok += sp[k].ok && sp[k].vsync == st[k].vsync && sp[k].odd_field == st[k].odd_field;
-    free(sp); free(st);
-    HIPCHK(c, e);
-    if (n_committed) *n_committed = ok;
-    if (n_redone) *n_redone = n - ok;
     return CRTHIP_OK;
 }
 

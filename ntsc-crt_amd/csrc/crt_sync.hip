@@ -4,18 +4,11 @@
 /* ------------------------------------------------------------------------- */
 /* D2-D7: the serial sync chain                                                */
 /* ------------------------------------------------------------------------- */
-/* The chain is serial in the line index (hsync and the burst integrators carry over,
- * crt_core.c:447,456-467).  Two kernels:
- *   k_vsync  D2      one wave per field: all 2*VWIN candidate lines are fetched up front, then
- *                    scanned with a wave-wide prefix sum; runs once per field.
- *   k_hsync  D4-D7   ONE DPP ROW (16 lanes) PER FIELD, four fields per wave: the hsync window is
- *                    16 samples (= one row, prefix sum by DPP row shifts), the burst integrators
- *                    are 4 chains (= one quad).  Row-uniform values live redundantly in the 16 lanes.
- * Latency: the bytes a line needs lie in [ln+hsync+SYNC_BEG-HWIN, ln+(hsync'&~3)+CB_BEG+40) with
- * |hsync'-hsync| <= HWIN; a 256-byte window [ln+hsync-40, ln+hsync+216) of line L+2 is fetched
- * while line L is processed (speculating that hsync moves by at most 3*HWIN until then) and parked
- * in a 3-slot LDS ring one iteration later, so a fetch has a whole iteration to land.  Whenever the bytes actually needed are not inside the parked window (hsync
- * wrapped around, ...) they are loaded directly -- same result, only slower. */
+/* The chain is serial in the line index (hsync and the burst integrators carry over, crt_core.c:447,456-467).  One kernel,
+ * k_hsync_wave: a wave per field, the vertical search (D2) included; k_vsync is the same search as a kernel of its own for the
+ * CRT_DO_VSYNC 0 variant, which looks at the CLEAN signal before the noise stage.  (Rounds 1-4 also carried a 16-lanes-per-field
+ * kernel and a speculative variant of the chain that ran beside the encoder: measured slower / neutral, removed in round 5 --
+ * profiles/r02_shape_sweep.txt, profiles/r04_spec_sync.txt.) */
 #define DPP_ROW_SHR(n)   (0x110 + (n))
 #define DPP_ROW_BCAST15  0x142
 #define DPP_ROW_BCAST31  0x143
@@ -42,12 +35,8 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 /* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR.  Wave-wide: all 2 * VWIN candidate lines
  * are fetched up front, then searched in order with a prefix sum across the wave.  Returns the line found (the last
  * candidate if none) and j (HRES if none), the same in every lane. */
-/* MASKED (the speculative sync pass, see k_hsync_wave): the samples of the encoder's active rectangle -- flat index S0 + y * HRES
- * + x, y < desth, x < destw, exactly like crt_ntsc.c:322 -- are not written yet; they count as 0, i.e. the search assumes that
- * no candidate line crosses the threshold inside its picture part.  The verifying pass repeats the search on the complete field. */
-template <class S, bool MASKED = false>
-__device__ __forceinline__ void vsync_search(const signed char *__restrict__ in, const int vsync, const int lane, int &vline, int &vj,
-                                             const int m_xo = 0, const int m_yo = 0, const int m_destw = 0, const int m_desth = 0)
+template <class S>
+__device__ __forceinline__ void vsync_search(const signed char *__restrict__ in, const int vsync, const int lane, int &vline, int &vj)
 {
     vline = 0; vj = S::HRES;
     constexpr int PIECES = (S::HRES + 1023) / 1024;      /* 64 lanes x 16 samples per piece; 2 pieces for the PV-1000's 1920 */
@@ -79,20 +68,12 @@ __device__ __forceinline__ void vsync_search(const signed char *__restrict__ in,
                     vline = posmod(vsync + g0 + i - S::VWIN, S::VRES);
                     const int wds[4] = { cand[i][pc].x, cand[i][pc].y, cand[i][pc].z, cand[i][pc].w };
                     const int s0 = pc * 1024 + lane * 16;
-                    /* MASKED: columns of this line inside the rectangle: [a_lo, a_hi) of its own row, [0, b_hi) of the row above
-                     * running over the line end (wave-uniform) */
-                    int a_lo = 0, a_hi = 0, b_hi = 0;
-                    if (MASKED) {
-                        if (vline >= m_yo && vline < m_yo + m_desth) { a_lo = m_xo; a_hi = m_xo + m_destw; }
-                        if (vline - 1 >= m_yo && vline - 1 < m_yo + m_desth && m_xo + m_destw > S::HRES) b_hi = m_xo + m_destw - S::HRES;
-                    }
                     int pre[16];
                     int run = 0;
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         int s = (wds[k >> 2] << (24 - 8 * (k & 3))) >> 24;
                         if (s0 + k >= S::HRES) s = 0;
-                        if (MASKED && ((s0 + k >= a_lo && s0 + k < a_hi) || s0 + k < b_hi)) s = 0;
                         run += s;
                         pre[k] = run;
                     }
@@ -136,248 +117,12 @@ k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthi
     }
 }
 
-#define SYNC_WIN_BACK 40       /* a line's parked window starts this far before ln + hsync */
-
-/* D4-D7, crt_core.c:428-510.  Needs state.vsync / state.odd_field from k_vsync. */
-template <class S>
-__global__ void __launch_bounds__(64)
-k_hsync(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
-        crthip_state *__restrict__ state, crthip_line *__restrict__ lines)
-{
-    constexpr int WIN = S::SYNC_WIN;                     /* bytes of a line's parked sync/burst window (16 lanes x WP x 16 bytes) */
-    constexpr int WP = WIN / 256;                        /* 16-byte pieces per lane */
-    constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS; /* burst samples per carrier phase */
-    constexpr int LW = 8;                                /* ints per line table entry */
-    static_assert(sizeof(crthip_line) == LW * 4, "line table entry");
-    __shared__ int s_win[4][3][WIN / 4];
-    __shared__ int s_fb[4][(16 + S::CB_LEN + 3) / 4 + 1]; /* fallback scratch: 16 hsync + CB_LEN burst bytes per row */
-    __shared__ int s_cc[4][8];                            /* 5-sample systems: the row's five integrators */
-    __shared__ int s_lines[4][S::LINES * LW];             /* the rows' line tables; written to memory after the loop so
-                                                             that no store sits between the window prefetches */
-    const int lane = threadIdx.x;
-    const int row = lane >> 4, j = lane & 15;            /* field slot in the wave, lane in the row */
-    const int f = blockIdx.x * 4 + row;
-    const bool live = f < n_fields;
-    const int fc = live ? f : n_fields - 1;              /* dead rows shadow the last field, never store */
-    const signed char *in = inp + (size_t) fc * fstride;
-    crthip_state *st = state + fc;
-    int hsync = st->hsync;
-    const int vsync = st->vsync;
-    const int field_rows = st->odd_field * (P.ratio / 2);             /* crt_core.c:407 */
-    const int phase = CCS == 4 ? (j & 3) : j % CCS;      /* the carrier phase this lane integrates */
-    int ccr[S::VPER];                                    /* lane holds ccf[r][phase] */
-#pragma unroll
-    for (int r = 0; r < S::VPER; r++) ccr[r] = st->ccf[r][phase];
-    crthip_line *out_lines = lines + (size_t) fc * S::LINES;
-
-    /* flat base of the window of line `line` assuming hsync h (row-uniform) */
-    auto window_base = [&](int line, int h) {
-        int l = line + vsync;                          /* < 2*VRES: BOT + 1 + VRES - 1 */
-        if (l >= S::VRES) l -= S::VRES;
-        const int b = l * S::HRES + h - SYNC_WIN_BACK;
-        return b < 0 ? 0 : b;
-    };
-    /* each of the 16 lanes of a row moves WP x 16 bytes of its field's window */
-    int base_cur = window_base(S::TOP, hsync);           /* window parked for the current line */
-#pragma unroll
-    for (int q = 0; q < WP; q++) {
-        const v4i w = load16u(in + base_cur + q * 256 + j * 16);
-        int *d = s_win[row][S::TOP % 3] + q * 64 + j * 4;
-        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-    }
-    int base_p = window_base(S::TOP + 1, hsync);         /* window in flight for line + 1 */
-    v4i wp[WP];
-#pragma unroll
-    for (int q = 0; q < WP; q++) wp[q] = load16u(in + base_p + q * 256 + j * 16);
-    __syncthreads();
-
-    const unsigned span = (unsigned) P.outh + P.v_fac;
-    int prev_beg = -1, rank = 0;                          /* row collisions when outh + v_fac < LINES */
-    for (int line = S::TOP; line < S::BOT; line++) {
-        /* speculative fetch of the window of line + 2 (see the comment above) */
-        const int base_n = window_base(line + 2, hsync);
-        v4i wn[WP];
-#pragma unroll
-        for (int q = 0; q < WP; q++) wn[q] = wp[q];
-        if (line + 2 < S::BOT) {
-#pragma unroll
-            for (int q = 0; q < WP; q++) wn[q] = load16u(in + base_n + q * 256 + j * 16);
-        }
-        const signed char *win = (const signed char *) s_win[row][line % 3];
-
-        /* D4, crt_core.c:428-432 (unsigned arithmetic: v_fac is unsigned) */
-        int beg = (int) ((unsigned) (line - S::TOP + 0) * span / (unsigned) S::LINES + (unsigned) field_rows);
-        int end = (int) ((unsigned) (line - S::TOP + 1) * span / (unsigned) S::LINES + (unsigned) field_rows);
-        const bool skip = beg >= P.outh;                               /* :431, row-uniform */
-        if (end > P.outh) end = P.outh;
-        if (!skip) {
-            /* several lines can start on the same output row (outh + v_fac < LINES); the reference
-             * handles them one after the other, so they are decoded in rank order by separate passes */
-            rank = beg == prev_beg ? rank + 1 : 0;
-            prev_beg = beg;
-        }
-
-        /* D5 hsync, crt_core.c:437-450.  0 <= vsync < VRES (k_vsync), so one conditional subtract wraps */
-        int lidx = line + vsync;
-        if (lidx >= S::VRES) lidx -= S::VRES;
-        const int ln = lidx * S::HRES;
-        const int a_off = ln + hsync + S::SYNC_BEG - S::HWIN - base_cur;          /* window-relative */
-        /* the fast path reads LDS only; if the bytes are not in the parked window (rare) the fallback fetches
-         * them into an LDS scratch row INSIDE its own branch, so no memory wait leaks into the common path */
-        signed char *fb = (signed char *) s_fb[row];
-        const bool a_in = a_off >= 0 && a_off + 2 * S::HWIN <= WIN;
-        if (!a_in) {
-            if (j < 2 * S::HWIN) fb[j] = in[ln + hsync + S::SYNC_BEG - S::HWIN + j];
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-        int sv = 0;
-        if (j < 2 * S::HWIN) sv = a_in ? win[a_off + j] : fb[j];
-        const int pref = row_incl_scan(sv);
-        const unsigned long long hm = __ballot(j < 2 * S::HWIN && pref <= S::HTHR);
-        const unsigned m16 = (unsigned) (hm >> (row * 16)) & 0xffffu;
-        const int hi = m16 ? (__ffs((int) m16) - 1 - S::HWIN) : S::HWIN;
-        int hsync_new = hi + hsync;                                      /* POSMOD(i + hsync, HRES), :447 */
-        if (hsync >= 0 && hsync < S::HRES) {                             /* |hi| <= HWIN: one wrap either way */
-            if (hsync_new < 0) hsync_new += S::HRES;
-            if (hsync_new >= S::HRES) hsync_new -= S::HRES;
-        } else {
-            hsync_new = posmod(hsync_new, S::HRES);                      /* caller-supplied out-of-range hsync */
-        }
-        if (!skip) hsync = (P.flags & CRTHIP_F_NO_HSYNC) ? 0 : hsync_new;              /* CRT_DO_HSYNC 0: crt_core.c:448-450 */
-
-        int xpos, ypos;                                                  /* :452-454 */
-        if (hsync >= 0 && hsync < S::HRES) {
-            xpos = S::AV_BEG + hsync - 3;
-            if (xpos >= S::HRES) xpos -= S::HRES;
-        } else {
-            xpos = posmod(S::AV_BEG + hsync - 3, S::HRES);
-        }
-        ypos = lidx + 3;
-        if (ypos >= S::VRES) ypos -= S::VRES;
-        const int pos = xpos + ypos * S::HRES;
-
-        /* D6 burst lock, crt_core.c:456-467.  The lane of carrier phase p integrates the burst bytes CB_BEG + k0,
-         * CB_BEG + k0 + CCS, ... with (CB_BEG + k0) % CCS == p; the burst is read from the sample grid aligned to
-         * the chroma cycle (hsync & ~3, :459; hsync - hsync % 5, :461) */
-        const int halign = CCS == 4 ? (hsync & ~3) : hsync - hsync % CCS;
-        const int b_off = ln + halign + S::CB_BEG - base_cur;
-        const bool b_in = b_off >= 0 && b_off + S::CB_LEN <= WIN;
-        const int k0 = CCS == 4 ? ((phase - S::CB_BEG) & 3) : ((phase - S::CB_BEG) % CCS + CCS) % CCS;
-        if (!b_in) {
-            const signed char *g = in + ln + halign + S::CB_BEG;
-            for (int k = j; k < S::CB_LEN; k += 16) fb[16 + k] = g[k];
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-        const signed char *bsrc = b_in ? win + b_off : fb + 16;
-        int smp[NB];
-#pragma unroll
-        for (int q = 0; q < NB; q++) smp[q] = bsrc[k0 + CCS * q];
-        const int r = S::VPER == 1 ? 0 : ypos % S::VPER;
-        int acc = ccr[0];
-#pragma unroll
-        for (int k = 1; k < S::VPER; k++) if (r == k) acc = ccr[k];
-#pragma unroll
-        for (int q = 0; q < NB; q++) {
-            const int t127 = (int) (((unsigned) acc << 7) - (unsigned) acc);   /* acc * 127 with wrap, no slow multiply */
-            acc = ((t127 + ((t127 >> 31) & 127)) >> 7) + smp[q];          /* C's truncating /128 */
-        }
-        if (!skip) {
-#pragma unroll
-            for (int k = 0; k < S::VPER; k++) if (r == k) ccr[k] = acc;
-        }
-
-        /* D7 carrier table */
-        int dci, dcq;
-        if constexpr (CCS == 4) {
-            /* crt_core.c:469-479: quad lanes 0..3 hold ccr[0..3] */
-            const int q0 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(0), 0xf, 0xf, false);
-            const int q1 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(1), 0xf, 0xf, false);
-            const int q2 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(2), 0xf, 0xf, false);
-            const int q3 = __builtin_amdgcn_update_dpp(0, acc, DPP_QUAD_BCAST(3), 0xf, 0xf, false);
-            const int pa = hsync & 3;
-            const int c0 = pa == 0 ? q0 : pa == 1 ? q1 : pa == 2 ? q2 : q3;
-            const int c1 = pa == 0 ? q1 : pa == 1 ? q2 : pa == 2 ? q3 : q0;
-            const int c2 = pa == 0 ? q2 : pa == 1 ? q3 : pa == 2 ? q0 : q1;
-            const int c3 = pa == 0 ? q3 : pa == 1 ? q0 : pa == 2 ? q1 : q2;
-            dci = c1 - c3;
-            dcq = c2 - c0;
-        } else {
-            /* crt_core.c:480-494: lanes 0..4 of the row hold ccr[0..4]; exchanged through LDS */
-            if (j < CCS) s_cc[row][j] = acc;
-            wave_lds_fence();
-            const int pa = posmod(hsync, CCS);
-            const int peak_a = pa + CCS / 4, peak_b = pa;
-            const int dci_a = s_cc[row][peak_a % CCS];
-            const int dci_b = (s_cc[row][(peak_a + CCS / 2) % CCS] + s_cc[row][(peak_a + CCS / 2 + 1) % CCS]) / 2;
-            const int dcq_a = s_cc[row][(peak_b + CCS / 2) % CCS];
-            const int dcq_b = s_cc[row][peak_b % CCS];
-            dci = dci_a - dci_b;
-            dcq = dcq_a - dcq_b;
-            wave_lds_fence();
-        }
-        if (j == 0 && live) {
-            crthip_line lp;
-            lp.dx = P.dx; lp.scanl = 0;                                    /* :528-529; k_bloom rewrites them per line */
-            if (skip) {
-                lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = hsync;
-            } else {
-                lp.pos = pos;
-                if constexpr (CCS == 4) {
-                    lp.wave0 = ((dci * P.huecs - dcq * P.huesn) >> 4) * P.saturation;
-                    lp.wave1 = ((dcq * P.huecs + dci * P.huesn) >> 4) * P.saturation;
-                } else {
-                    lp.wave0 = dci;                                        /* the decoder builds waveI / waveQ (:497-505) */
-                    lp.wave1 = dcq;
-                }
-                lp.beg = beg;
-                int nrows = end - P.scanlines - beg;                        /* rows beg .. end-scanlines-1, :662 */
-                nrows = nrows < 1 ? 1 : nrows;
-                /* carrier amplitude outside the 24-bit-multiply envelope of the fast decoder? */
-                if (nrows > CRTHIP_LINE_NROWS_MASK) nrows = CRTHIP_LINE_NROWS_MASK;
-                nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
-                nrows |= line_tier_flags<CCS>(lp.wave0, lp.wave1, P.saturation, P.loskip_wave_max, lp.pos + S::AV_LEN + 8 > S::INPUT_SIZE);
-                lp.nrows = nrows;
-                lp.hsync = hsync;
-            }
-            int *d = s_lines[row] + (line - S::TOP) * LW;
-            d[0] = lp.pos; d[1] = lp.wave0; d[2] = lp.wave1; d[3] = lp.beg; d[4] = lp.nrows; d[5] = lp.hsync;
-            d[6] = lp.dx; d[7] = lp.scanl;
-        }
-        /* park the window of line + 1 (fetched one iteration ago), keep line + 2's in flight */
-        if (line + 1 < S::BOT) {
-#pragma unroll
-            for (int q = 0; q < WP; q++) {
-                int *d = s_win[row][(line + 1) % 3] + q * 64 + j * 4;
-                d[0] = wp[q].x; d[1] = wp[q].y; d[2] = wp[q].z; d[3] = wp[q].w;
-            }
-        }
-        base_cur = base_p;
-        base_p = base_n;
-#pragma unroll
-        for (int q = 0; q < WP; q++) wp[q] = wn[q];
-        __syncthreads();
-    }
-    /* line tables: LINES * 32 bytes per row, copied out 16 bytes per lane and pass */
-    if (live) {
-        int *dst = (int *) out_lines;
-        for (int i = j * 4; i < S::LINES * LW; i += 64) {
-            v4i v; v.x = s_lines[row][i]; v.y = s_lines[row][i + 1]; v.z = s_lines[row][i + 2]; v.w = s_lines[row][i + 3];
-            store16u(dst + i, v);
-        }
-    }
-    if (j < CCS && live) {
-#pragma unroll
-        for (int r = 0; r < S::VPER; r++) st->ccf[r][j] = ccr[r];
-    }
-    if (j == 0 && live) st->hsync = hsync;
-}
-
 /* ------------------------------------------------------------------------------------------------------------ */
-/* D4-D7, second implementation: ONE WAVE PER FIELD, scalar control                                               */
+/* D2, D4-D7 (crt_core.c:379-396, 428-510): ONE WAVE PER FIELD, scalar control                                     */
 /* ------------------------------------------------------------------------------------------------------------ */
-/* k_hsync (above) walks a field's 240 lines with everything -- sync search, burst integrators, carrier table, row
- * bookkeeping -- inside one serial iteration of ~1800 cycles, four fields per wave: 0.18 ms however small the batch,
- * one wave per SIMD however large.  Here the two serial recurrences are separated and stripped to their cores:
+/* A serial walk over a field's 240 lines with everything -- sync search, burst integrators, carrier table, row
+ * bookkeeping -- inside one iteration costs ~1800 cycles per line (round 1's kernel: 0.18 ms however small the batch).
+ * Here the two serial recurrences are separated and stripped to their cores:
  *   pass 1   hsync chain: per line 16 LDS bytes -> DPP row scan -> ballot -> scalar update           (~200 cycles)
  *   pass 2   burst integrators (crt_core.c:462-467): 10 steps per line and carrier phase of
  *            acc' = acc + s - ((acc >> 7) + (acc > 0 && (acc & 127) != 0))   [== acc * 127 / 128 + s in C]
@@ -414,22 +159,14 @@ __device__ __forceinline__ int burst_step(int acc, int s)
  * burst integrators of the workgroup's 4 fields are stepped by ONE wave, 4 fields x CC_VPER x CC_SAMPLES lanes at a
  * time, while the other three wait at a barrier -- the chain is the only part that keeps the vector unit busy for long,
  * and with 4 of 64 lanes working per field it costs a quarter this way. */
-/* MODE -- taking the chain off the critical path of a fused field-pass.  Everything the chain reads
- * lies OUTSIDE the encoder's active rectangle -- sync pulses, bursts, blanking: the margins, complete after k_margin -- with
- * two exceptions: the vertical sync search integrates whole candidate lines, some of which carry picture (crt_core.c:379-396),
- * and a sync state far from lock moves the hsync / burst windows into the picture.  So:
- *   SYNC_SPEC    runs BESIDE the encoder (k_active) on the context's second stream, on a field whose picture part is not
- *                written yet: vertical search with the picture part masked, the whole chain, the line table; the field's state
- *                is not touched -- results go to a crthip_spec record; `ok` = no window ever reached into the rectangle;
- *   SYNC_VERIFY  runs where the chain used to: repeats ONLY the vertical search, on the complete field; same answer and ok
- *                => commit the record to the state (and advance rn), done; anything else => the full chain, as if nothing
- *                had been speculated (the state is still the incoming one).
- * Exact by construction: the speculative result is used only if the one assumption it rests on was checked on final data. */
-template <class S, int FPB, int MODE = SYNC_FULL>
+/* preset_ccf (the fused field-pass): the burst integrators do not start from the state's ccf but from what crt_modulate leaves
+ * there (crt_ntsc.c:325-329 and siblings: the burst level of the line class, << 7) -- k_encoder_state's work, done by the lanes
+ * that are about to read it, which saves the fused path a launch; field / frame are masked like there. */
+template <class S, int FPB>
 __global__ void __launch_bounds__(64 * FPB, 4)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
              crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn,
-             crthip_spec *__restrict__ spec)
+             int preset_ccf)
 {
     constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS, VPER = S::VPER;
     constexpr int WOFF = S::SYNC_BEG - S::HWIN;          /* first byte of the search window relative to ln + hsync */
@@ -448,11 +185,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     __shared__ int s_cnt_[FPB][VPER], s_off_[FPB][VPER];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    /* SYNC_SPEC runs as a PERSISTENT grid (crt_run_sync): a few waves per CU walk the fields one after the other, so that the
-     * chain -- latency bound, 10 KB of LDS per field -- occupies a fixed small share of every CU beside the encoder instead of
-     * flooding the chip with one workgroup per field (measured: 1024 workgroups of 48 KB LDS starve k_active of LDS and the
-     * field-pass gets slower, profiles/r04_spec_sync.txt).  The other modes: one workgroup per FPB fields, one trip. */
-  for (int vblock = blockIdx.x; vblock * FPB < n_fields; vblock += (int) gridDim.x) {        /* (the other modes' grids cover every field: one trip) */
+    const int vblock = blockIdx.x;
     const int f_raw = vblock * FPB + wv;
     const bool live = f_raw < n_fields;                  /* a wave without a field shadows the last one and stores nothing */
     const int f = live ? f_raw : n_fields - 1;
@@ -471,45 +204,16 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
         vsync = __builtin_amdgcn_readfirstlane(st->vsync);
         odd_field = __builtin_amdgcn_readfirstlane(st->odd_field);
     } else {
-        if (MODE == SYNC_SPEC) vsync_search<S, true>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_, P.xo, P.yo, P.destw, P.desth);
-        else vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
+        vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
         vsync = __builtin_amdgcn_readfirstlane(vsync);
         odd_field = __builtin_amdgcn_readfirstlane(vj_) > S::HRES / 2;
     }
-    crthip_spec *const sp = spec + f;
-    if (MODE == SYNC_VERIFY) {
-        /* the speculative pass's answer stands iff it rested on the right vertical sync and never looked into the picture */
-        const bool mine_ok = sp->ok != 0 && sp->vsync == vsync && sp->odd_field == odd_field;
-        /* a workgroup's fields share the chain wave and its barriers: all of them redo, or none (redoing a good one is harmless) */
-        const bool redo = FPB > 1 ? __syncthreads_or(live && !mine_ok) != 0 : !mine_ok;
-        if (!redo) {
-            if (live) {
-                if (lane == 0) {
-                    st->vsync = vsync;
-                    st->odd_field = odd_field;
-                    st->hsync = sp->hsync;
-                    if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
-                }
-                if (lane < S::VPER * S::CCS) st->ccf[lane / S::CCS][lane % S::CCS] = sp->ccf[lane / S::CCS][lane % S::CCS];
-            }
-            return;
-        }
-    }
-    if (MODE != SYNC_SPEC && live && lane == 0) {
+    if (live && lane == 0) {
         st->vsync = vsync;
         st->odd_field = odd_field;
         if (advance_rn) st->rn = (int) (whole_field.x * (unsigned) st->rn + whole_field.y);
+        if (preset_ccf && (!S::LINE_ROWS || !S::NES_TIMING)) { st->field &= 1; st->frame &= 1; }      /* k_encoder_state */
     }
-    bool touched = false;                                /* SYNC_SPEC: some window of this field reached into the active rectangle */
-    /* does the flat range [a, a + len) (len <= HRES) meet the encoder's rectangle?  (rows S0 + y * HRES + [0, destw), y < desth) */
-    auto hits_active = [&](long a, int len) {
-        long r0 = a - ((long) P.yo * S::HRES + P.xo);
-        if (r0 + len <= 0) return false;
-        if (r0 < 0) { len += (int) r0; r0 = 0; }
-        const int row0 = (int) (r0 / S::HRES), c0 = (int) (r0 - (long) row0 * S::HRES);
-        if (row0 >= P.desth) return false;
-        return c0 < P.destw || (c0 + len > S::HRES && row0 + 1 < P.desth);
-    };
     const int field_rows = odd_field * (P.ratio / 2);                                          /* crt_core.c:407 */
     const unsigned span = (unsigned) P.outh + P.v_fac;
     crthip_line *out_lines = lines + (size_t) f * S::LINES;
@@ -522,6 +226,15 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     const bool chain_lane = wv == 0 && my_slot < FPB && vblock * FPB + my_slot < n_fields;
     crthip_state *st_chain = state + (chain_lane ? vblock * FPB + my_slot : 0);
     int acc = chain_lane ? st_chain->ccf[my_r][my_p] : 0;
+    if constexpr (!S::IS_VHS) {                          /* (the rand()-noise VHS build runs k_encoder_state itself: it also resets hsync) */
+        if (preset_ccf && chain_lane && (S::LINE_ROWS || my_r == 0)) {
+            /* what crt_modulate leaves in ccf (k_encoder_state, crt_encode.hip): entry [(cls + CCF_SHIFT) % VPER][p] = the burst
+             * level of line class cls at carrier phase p, << 7; the systems without line classes preset row 0 from class 0 */
+            const int cls = S::LINE_ROWS ? (my_r + S::VPER - S::CCF_SHIFT % S::VPER) % S::VPER : 0;
+            const int row = carrier_row<S>(cls, st_chain->field, st_chain->frame, st_chain->aux);
+            acc = ((int) (signed char) ((S::BLANK + P.burst[row][my_p] * S::BURST) >> 5)) << 7;
+        }
+    }
     const bool big = chain_lane && (acc >= (1 << 23) || acc <= -(1 << 23));
     const bool exact_mul = __ballot(big) != 0ull;        /* caller-supplied garbage in ccf: keep the wrapping multiply (wave 0 only) */
     const int k0 = CCS == 4 ? ((my_p - S::CB_BEG) & 3) : ((my_p - S::CB_BEG) % CCS + CCS) % CCS;
@@ -588,7 +301,6 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                 if (!new_skip) {
                     /* the 2*HWIN bytes from ln + h_in + SYNC_BEG - HWIN: from my parked window, the next line's (wrapped
                      * hsync), or -- rarely -- from memory */
-                    if (MODE == SYNC_SPEC && hits_active((long) my_lidx * S::HRES + h_in + WOFF, 2 * S::HWIN)) touched = true;
                     int a = -1;
                     if (h_in >= 0 && h_in <= WLEN - 2 * S::HWIN - WBACK && own_ok) a = lane * (WSTR * 4) + h_in + WBACK;
                     else if (h_in >= S::HRES - WBACK && h_in < S::HRES && next_ok) a = (lane + 1) * (WSTR * 4) + h_in - S::HRES + WBACK;
@@ -803,7 +515,6 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             /* burst samples: CB_LEN bytes from ln + halign + CB_BEG (:459-461) */
             const int halign = CCS == 4 ? (rec_hs & ~3) : rec_hs - rec_hs % CCS;
             const int baddr = lidx * S::HRES + halign + S::CB_BEG;
-            if (MODE == SYNC_SPEC && !rec_skip && hits_active((long) baddr, S::CB_LEN)) touched = true;
 #pragma unroll
             for (int q = 0; q < BPIECES; q++) {
                 breg[q] = !rec_skip ? load16u(in + baddr + q * 16) : v4i{0, 0, 0, 0};
@@ -811,16 +522,8 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             wave_lds_fence();
         }
     }
-    if (MODE == SYNC_SPEC) {
-        if (chain_lane) spec[vblock * FPB + my_slot].ccf[my_r][my_p] = acc;
-        const bool any_touched = __ballot(touched) != 0ull;
-        if (lane == 0 && live) { sp->ok = any_touched ? 0 : 1; sp->vsync = vsync; sp->odd_field = odd_field; sp->hsync = hsync; }
-    } else {
-        if (chain_lane) st_chain->ccf[my_r][my_p] = acc;
-        if (lane == 0 && live) st->hsync = hsync;
-    }
-    HSW_SYNC();                                          /* (the next field of a persistent wave reuses the LDS rows) */
-  }
+    if (chain_lane) st_chain->ccf[my_r][my_p] = acc;
+    if (lane == 0 && live) st->hsync = hsync;
 #undef HSW_SYNC
 }
 
@@ -938,54 +641,29 @@ int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthi
     });
 }
 
-/* workgroups of the speculative pass: at most CRTHIP_SPEC_WAVES (default 4: the chain of 4096 fields then finishes under the
- * encoder; 2 do not, profiles/r04_spec_sync.txt) per CU, each walking several fields */
-static unsigned spec_grid(crthip_ctx *c, unsigned blocks)
-{
-    static int per_cu = -1;
-    if (per_cu < 0) { const char *e = getenv("CRTHIP_SPEC_WAVES"); per_cu = e && atoi(e) > 0 ? atoi(e) : 4; }
-    hipDeviceProp_t prop;
-    static int cus = 0;
-    if (!cus) cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const unsigned cap = (unsigned) (per_cu * cus);
-    return blocks < cap ? blocks : cap;
-}
-
-/* mode: SYNC_FULL, or the two halves of the speculative scheme (see k_hsync_wave): SYNC_SPEC -- on whatever stream c->stream is
- * at the moment, the line table and c->d_spec only -- and SYNC_VERIFY (+ the bloom pass, which reads the picture part) */
+/* the sync chain of n fields on the context's stream: vertical search, hsync fixed point, burst integrators, line table (+ the
+ * bloom pass).  preset_ccf: see k_hsync_wave. */
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
-                 crthip_line *d_lines, int advance_rn, int mode)
+                 crthip_line *d_lines, int advance_rn, int preset_ccf)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
-        const bool legacy = c->legacy_sync || c->sync_kernel == 1;
-        if (mode != SYNC_FULL && (legacy || !c->d_spec)) return set_err(c, CRTHIP_E_ARG, "speculative sync without its scratch", hipSuccess);
-        if (legacy)
-            if (!(p->flags & CRTHIP_F_NO_VSYNC))
-                hipLaunchKernelGGL((k_vsync<S>), dim3(n), dim3(64), 0, c->stream, n, d_inp, c->fstride, d_state, c->whole_field, advance_rn, 0);
-        /* k_hsync (16 lanes per field) is kept for A/B measurements (CRTHIP_SYNC_KERNEL=1): the wave-per-field kernel
-         * is faster at every batch size measured (profiles/r02_shape_sweep.txt, rows L against A).
-         * CRTHIP_SYNC_KERNEL=2 / 3 force 1 / 4 fields per workgroup */
+        /* 4 fields per workgroup share one wave for their burst chains (large batches); CRTHIP_SYNC_KERNEL=2 / 3 force 1 / 4
+         * fields per workgroup (A/B) */
         constexpr bool FPB4_OK = 64 / (S::VPER * S::CCS) >= 4;
-        if (legacy)
-            hipLaunchKernelGGL((k_hsync<S>), dim3((n + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines);
-        else {
-            bool done = false;
-#define CRT_LAUNCH_HSW(FPB, GRID, BLOCK) do { \
-            if (mode == SYNC_SPEC) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_SPEC>), dim3(spec_grid(c, (GRID).x)), BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
-            else if (mode == SYNC_VERIFY) hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_VERIFY>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); \
-            else hipLaunchKernelGGL((k_hsync_wave<S, FPB, SYNC_FULL>), GRID, BLOCK, 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines, c->whole_field, advance_rn, c->d_spec); } while (0)
-            if constexpr (FPB4_OK) {                     /* 4 fields per workgroup share one wave for their burst chains */
-                if (mode != SYNC_SPEC && c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {    /* (the speculative pass: a wave per field, persistent) */
-                    CRT_LAUNCH_HSW(4, dim3((n + 3) / 4), dim3(256));
-                    done = true;
-                }
+        bool done = false;
+        if constexpr (FPB4_OK) {
+            if (c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {
+                hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                                   c->whole_field, advance_rn, preset_ccf);
+                done = true;
             }
-            if (!done) CRT_LAUNCH_HSW(1, dim3(n), dim3(64));
-#undef CRT_LAUNCH_HSW
         }
-        if (p->bloom && mode != SYNC_SPEC)
+        if (!done)
+            hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
+                               c->whole_field, advance_rn, preset_ccf);
+        if (p->bloom)
             hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
         return CRTHIP_OK;
     });

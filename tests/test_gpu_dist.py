@@ -191,8 +191,9 @@ def test_node_bench_runs_batches_in_flight_through_the_c_abi():
 
 @pytest.mark.gpu
 def test_bench_tunes_the_batches_in_flight_and_reports_every_candidate():
-    """bench.py: the same K steps timed with 1, 2 and 3 independent batches in flight; `value` is the best one, all are in
-    the JSON, the one-batch figure separately"""
+    """bench.py: the same K steps timed with 1, 2 and 3 independent batches in flight, five times each; S is chosen on the medians
+    (all of them in the JSON, the one-batch figure separately), then the chosen S is timed five more times and
+    `value` is the median of THOSE, with min / median / max as `value_spread`"""
     import tempfile
     full = os.path.join(tempfile.mkdtemp(prefix="benchfull_"), "full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "96", "--steps", "6", "--warmup", "1", "--no-cpu", "--no-extra",
@@ -204,8 +205,13 @@ def test_bench_tunes_the_batches_in_flight_and_reports_every_candidate():
     j = json.load(open(full))                                 # ... and the complete one in the file
     tuning = j["config"]["batches_in_flight_tuning"]
     assert sorted(tuning) == ["1", "2", "3"] and j["config"]["batches_in_flight"] in (1, 2, 3)
-    best = max(tuning.values(), key=lambda t: t["value"])
-    assert abs(j["value"] - best["value"]) < 1e-6 * best["value"] and abs(j["ms_per_step"] - best["ms_per_step"]) < 1e-9 + 1e-6 * best["ms_per_step"]
+    best = max(tuning, key=lambda s_: tuning[s_]["value"])
+    assert j["config"]["batches_in_flight"] == int(best), "S is chosen on the medians of the candidates' samples"
+    assert all(len(t_["samples_ms_per_step"]) == 5 for t_ in tuning.values())
+    sp = j["value_spread"]
+    assert sp["reps"] == 5 and sp["min"] <= sp["median"] <= sp["max"] and abs(j["value"] - sp["median"]) < 1e-6 * sp["median"]
+    assert abs(j["ms_per_step"] * j["value"] - 96 * 1e3) < 1e-3 * 96 * 1e3          # ms per step x frames per second = frames per step
+    assert c["value_spread"]["reps"] == 5 and abs(c["value_spread"]["median"] - j["value"]) < 1e-5 * j["value"]
     assert abs(j["one_batch_in_flight"]["value"] - tuning["1"]["value"]) < 1e-6 * tuning["1"]["value"]
     assert j["steps"] == 6 and j["roofline"]["kernel_ms"]["decode"] > 0
     # the compact line says the same at its precision

@@ -82,7 +82,7 @@ CASES = [
 ]
 
 
-def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1):
+def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=0):
     """shape: 1 = lane-per-scanline kernels (the throughput shape; forced, because small batches would otherwise
     pick the other one), 2 = scanline-parallel kernels, 0 = the library's own choice"""
     name, outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = case
@@ -94,6 +94,7 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1):
     g.eq_fir = R.EQ_KERNEL.get(name, 0)              # "ntscfir7": the FIR decoder of a USE_CONVOLUTION build
     g.set_exact(exact)
     g.set_shape(shape)
+    g.set_signal_tile(sig_tile)
     for k, v in knobs.items():
         setattr(g, k, v)
     fields = [k & 1 for k in range(n)]
@@ -265,6 +266,14 @@ def test_wide_pictures_leave_the_scanline_parallel_decoder_early(crtlib):
         assert torch.equal(outs[0][0], outs[k][0]), "picture: shape 0 vs shape %d" % k
         assert torch.equal(outs[0][1], outs[k][1]), "state: shape 0 vs shape %d" % k
     assert int(outs[0][0].to(torch.int64).sum().item()) > 0
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_large_signal_tiles_parity(crtlib, case):
+    """the fused encoder with its LARGE signal tile (128-byte pieces beside the narrow image tile, 256-byte pieces beside the wide
+    one: what batches of thousands of fields take, crt_encode.hip launch_active) forced onto every case of the table, against the
+    oracle; the library's own choice at these batch sizes is the 64-byte tile of every other test"""
+    _run_case(crtlib, CASES[case], fused=True, steps=2, sig_tile=64)
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
@@ -1204,14 +1213,13 @@ def test_full_size_batch_properties_vhs_nes(crtlib, name, n, noise):
 
 @pytest.mark.parametrize("name,n,noise", [("ntsc", 24, 0), ("ntsc", 24, 150), ("ntsc", 520, 60), ("snes", 24, 100), ("pv1k", 12, 90),
                                           ("nes", 24, 80), ("ntscbloom", 24, 40)])
-def test_speculative_sync_commit_and_redo(crtlib, name, n, noise):
-    """The sync chain of a fused field-pass runs BESIDE the encoder, on a field whose picture part is not written yet, and is
-    verified afterwards (k_hsync_wave SYNC_SPEC / SYNC_VERIFY).  Fields are started from sync states
-    that make the speculation fail in each of its ways -- vertical sync candidates in the middle of the picture under heavy
-    noise (a candidate line crosses the threshold INSIDE its picture part), hsync values that put the search window or the
-    burst window into the picture, values near the line end (windows that wrap) -- next to ordinary ones, in one batch (520
-    fields: four fields per workgroup, which redo together).  Every field, three consecutive field-passes, against the
-    oracle; and the same bytes with the chain in its old place."""
+def test_wild_sync_states_against_the_oracle(crtlib, name, n, noise):
+    """Fields started from sync states far from lock -- vertical sync candidates in the middle of the picture under heavy noise,
+    hsync values that put the search window or the burst window into the picture, values near the line end (windows that wrap)
+    -- next to ordinary ones, in one batch (520 fields: four fields per workgroup of the sync kernel).  Every field, three
+    consecutive field-passes, against the oracle: hsync, vsync, rn, the burst integrators the chain starts from (the ccf preset
+    of crt_modulate is applied by the sync kernel's own lanes in a fused pass, k_hsync_wave preset_ccf) and every picture byte.
+    (Rounds 4's speculative sync chain was tested with these inputs; the chain is gone, the inputs stayed.)"""
     import torch
     nes = name == "nes"
     w, h = (256, 240) if nes else (640, 480)
@@ -1230,10 +1238,9 @@ def test_speculative_sync_commit_and_redo(crtlib, name, n, noise):
     vs = [vs0[(k // uniq * 5 + k) % len(vs0)] for k in range(n)]
     fields = [k & 1 for k in range(n)]
     outs = {}
-    for spec in (1, 0):
+    for spec in (1,):
         g = crtlib.CRT(n, 640, 480, crtlib.FMT_BGRA, name, device=0)
         g.scanlines = 1
-        g.set_spec_sync(spec)
         g.state[:, crtlib.ST_HSYNC] = torch.tensor(hs, dtype=torch.int32, device="cuda:0")
         g.state[:, crtlib.ST_VSYNC] = torch.tensor(vs, dtype=torch.int32, device="cuda:0")
         if nes:
@@ -1246,19 +1253,9 @@ def test_speculative_sync_commit_and_redo(crtlib, name, n, noise):
         for step in range(3):
             g.fieldpass(s, noise)
             g.synchronize()
-            per.append((g.out.cpu().numpy().copy(), g.state.cpu().numpy().copy(), g.spec_sync_stats()))
+            per.append((g.out.cpu().numpy().copy(), g.state.cpu().numpy().copy()))
         outs[spec] = per
         g.close()
-    for step in range(3):
-        assert np.array_equal(outs[1][step][0], outs[0][step][0]), "step %d: pictures differ between the two placements of the chain" % step
-        assert np.array_equal(outs[1][step][1], outs[0][step][1]), "step %d: states differ" % step
-        assert outs[0][step][2] == (0, 0)
-        com, red = outs[1][step][2]
-        assert com + red == n
-    # the wild starting states make some chains fail (that is what this test is for), locked sets let them stand
-    assert outs[1][0][2][1] > 0, "no field was redone: the test does not reach the verify-and-redo path"
-    if noise == 0:
-        assert outs[1][2][2][0] >= n * 3 // 4, "steady pictures: the speculative chains should stand (%r)" % (outs[1][2][2],)
     orc = R.Oracle(name)
     check = range(n) if n <= 64 else list(range(0, n, 7)) + [n - 1]
     checked = 0

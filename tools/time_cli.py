@@ -19,6 +19,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "ntsc_cli")
 HIP = os.path.join(ROOT, "ntsc-crt_amd", "lib", "ntsc_cli_hip")
+FLOOR = os.path.join(ROOT, "ntsc-crt_amd", "lib", "hip_floor")        # tools/hip_floor.hip: hipInit, hipMalloc, one trivial kernel, exit
+PROBE = os.path.join(ROOT, "ntsc-crt_amd", "lib", "startup_probe")    # tools/startup_probe.c: the drop-in API, wall clock around every call
 
 
 def config1_ppm(path, w=640, h=480, seed=1):
@@ -62,6 +64,15 @@ def measure(runs=5, flags="-op", noise=0):
         ts = sorted(ts[1:])
         res[tag + "_ms"] = [round(ts[0], 1), round(ts[len(ts) // 2], 1)]
         outs[tag] = open(out, "rb").read()
+    if os.path.exists(FLOOR):
+        # what ANY one-shot HIP process pays on this box before its first kernel has run: the runtime's share of hip_ms
+        ts = []
+        for _ in range(runs + 1):
+            t0 = time.perf_counter()
+            subprocess.run([FLOOR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            ts.append(1e3 * (time.perf_counter() - t0))
+        ts = sorted(ts[1:])
+        res["hip_floor_ms"] = [round(ts[0], 1), round(ts[len(ts) // 2], 1)]
     res["identical"] = outs["ref"] == outs["hip"] == outs["hip_lazy"]
     res["runs"] = runs
     res["cmd"] = "ntsc %s 640 480 %d 0 in.ppm out.ppm" % (flags, noise)
@@ -76,4 +87,11 @@ if __name__ == "__main__":
     print("reference binary (unmodified sources, gcc -O3, 1 core)      %8.1f / %8.1f" % tuple(r["ref_ms"]))
     print("same crt_main.c + libntsccrt_hip_ntsc.so (strict mirror)     %8.1f / %8.1f" % tuple(r["hip_ms"]))
     print("same, CRTHIP_LAZY_MIRROR=1                                   %8.1f / %8.1f" % tuple(r["hip_lazy_ms"]))
+    if "hip_floor_ms" in r:
+        print("a one-shot HIP process that launches ONE trivial kernel       %8.1f / %8.1f   <- the runtime's floor on this box" % tuple(r["hip_floor_ms"]))
     print("output images byte-identical: %s" % r["identical"])
+    if os.path.exists(PROBE):
+        print("# the drop-in API called like crt_main.c does (tools/startup_probe.c), wall clock around every call:")
+        print(subprocess.run([PROBE], capture_output=True, text=True).stdout.rstrip())
+        print("# the same with the HIP runtime initialised by hand first (what of crt_modulate #1 is hipInit):")
+        print(subprocess.run([PROBE, "hipinit"], capture_output=True, text=True).stdout.rstrip())

@@ -20,13 +20,26 @@ __device__ __forceinline__ void st16n(unsigned long long a, v4i v) { __builtin_n
 __device__ __forceinline__ v4i ld16nt(unsigned long long a) { return __builtin_nontemporal_load((const g_v4i *) a); }
 __device__ __forceinline__ unsigned ld32nt(unsigned long long a) { return __builtin_nontemporal_load((const g_u32 *) a); }
 __device__ __forceinline__ unsigned ld32(unsigned long long a) { return *(const g_u32 *) a; }
+__device__ __forceinline__ v4i ld16(unsigned long long a) { return ((const g_u16 *) a)->v; }
 
 #define ROWS 240
+#ifdef GEO640                     /* 640x480: 2560-byte image rows, every second row, 753 samples from 640 pixels */
+#define IPITCH 2560
+#define SRC_ROW(y) ((y) * 2)
+#define IMG_ROWS 481
+#define PIXELS 640
+#else
 #define IPITCH 7680
+#define SRC_ROW(y) ((y) * 9 / 2)
+#define IMG_ROWS 1081
+#define PIXELS 1920
+#endif
 static __device__ __constant__ int c_lpitch = 910, c_line0 = 21 * 910 + 152, c_nt = 0;
 #define LPITCH c_lpitch
 #define LINE0 c_line0
 #define DESTW 753
+#define XSTR2(x) #x
+#define XSTR(x) XSTR2(x)
 
 __device__ __forceinline__ int filler(int acc, int n)
 {
@@ -36,7 +49,7 @@ __device__ __forceinline__ int filler(int acc, int n)
 
 // today's shape: a wave owns 64 rows; per tile 8 load instructions cover 64 rows x 128 bytes; the signal leaves in
 // PIECE-byte runs per row (64: every 5.1 tiles; 256: every 20.4)
-template <int PIECE>
+template <int PIECE, int IPIECE = 128>
 __global__ void __launch_bounds__(64)
 k_rows64(const unsigned char *img, size_t istride, unsigned char *dst, size_t fstride, int total, int do_load, int do_store, int valu, int *sink)
 {
@@ -44,24 +57,28 @@ k_rows64(const unsigned char *img, size_t istride, unsigned char *dst, size_t fs
     __shared__ unsigned long long s_src[64], s_dst[64];
     const int lane = threadIdx.x, gid = blockIdx.x * 64 + lane;
     const int f = gid < total ? gid / ROWS : 0, y = gid < total ? gid % ROWS : 0;
-    s_src[lane] = (unsigned long long) (img + (size_t) f * istride + (size_t) (y * 9 / 2) * IPITCH);
+    s_src[lane] = (unsigned long long) (img + (size_t) f * istride + (size_t) SRC_ROW(y) * IPITCH);
     s_dst[lane] = gid < total ? (unsigned long long) (dst + (size_t) f * fstride + LINE0 + y * LPITCH) : 0ull;
     __syncthreads();
     int acc = lane;
     constexpr int PPR = PIECE / 16, RPI = 64 / PPR;       // pieces per row, rows per store instruction
     int stored = 0;
-    for (int tile = 0; tile < 60; tile++) {
+    constexpr int NTILES = IPITCH / IPIECE, IPPR = IPIECE / 16, IRPI = 64 / IPPR;      // image pieces per row, rows per load instruction
+    for (int tile = 0; tile < NTILES; tile++) {
         if (do_load) {
-            v4i v[8];
+            v4i v[IPPR];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = ld16nt(s_src[i * 8 + (lane >> 3)] + tile * 128 + (lane & 7) * 16);
+            for (int i = 0; i < IPPR; i++) {
+                const unsigned long long a = s_src[i * IRPI + lane / IPPR] + tile * IPIECE + (lane % IPPR) * 16;
+                v[i] = IPIECE == 128 ? ld16nt(a) : ld16(a);               // (narrow tiles: plain loads, the line's other half comes later)
+            }
 #pragma unroll
-            for (int i = 0; i < 8; i++) acc ^= v[i].x + v[i].y + v[i].z + v[i].w;
+            for (int i = 0; i < IPPR; i++) acc ^= v[i].x + v[i].y + v[i].z + v[i].w;
         }
         acc = filler(acc, valu);
-        // samples produced so far: (tile + 1) * 32 pixels * 753 / 1920
-        const int have = (tile + 1) * 32 * DESTW / 1920;
-        while (do_store && (have - stored >= PIECE || (tile == 59 && stored + PIECE <= DESTW))) {
+        // samples produced so far
+        const int have = (tile + 1) * (IPIECE / 4) * DESTW / PIXELS;
+        while (do_store && (have - stored >= PIECE || (tile == NTILES - 1 && stored + PIECE <= DESTW))) {
 #pragma unroll 2
             for (int i = 0; i < 64 / RPI; i++) {
                 const unsigned long long d = s_dst[i * RPI + lane / PPR];
@@ -87,7 +104,7 @@ k_rows16(const unsigned char *img, size_t istride, unsigned char *dst, size_t fs
     if (lane < 16) {
         const int gid = blockIdx.x * 16 + lane;
         const int f = gid < total ? gid / ROWS : 0, y = gid < total ? gid % ROWS : 0;
-        s_src[lane] = (unsigned long long) (img + (size_t) f * istride + (size_t) (y * 9 / 2) * IPITCH);
+        s_src[lane] = (unsigned long long) (img + (size_t) f * istride + (size_t) SRC_ROW(y) * IPITCH);
         s_dst[lane] = gid < total ? (unsigned long long) (dst + (size_t) f * fstride + LINE0 + y * LPITCH) : 0ull;
     }
     __syncthreads();
@@ -96,7 +113,7 @@ k_rows16(const unsigned char *img, size_t istride, unsigned char *dst, size_t fs
         for (int t = 0; t < 12; t++) {
             int x = t * 64 + lane;
             if (x > DESTW - 1) x = DESTW - 1;
-            const int col = x * 1920 / DESTW;
+            const int col = x * PIXELS / DESTW;
             if (do_load) {
                 unsigned v[16];
 #pragma unroll
@@ -107,7 +124,7 @@ k_rows16(const unsigned char *img, size_t istride, unsigned char *dst, size_t fs
             acc = filler(acc, valu);
         }
     } else {
-        for (int t = 0; t < 15; t++) {
+        for (int t = 0; t < IPITCH / 512; t++) {
             if (do_load) {
                 v4i v[8];
 #pragma unroll
@@ -146,14 +163,14 @@ int main(int argc, char **argv)
 {
     const int fields = argc > 1 ? atoi(argv[1]) : 2048;
     const int uniq = fields;                                      // every field its own image (8.3 MB each)
-    const size_t istride = (size_t) 1081 * IPITCH, fstride = 270336;
+    const size_t istride = (size_t) IMG_ROWS * IPITCH, fstride = 270336;
     unsigned char *img, *dst; int *sink;
     if (hipMalloc(&img, istride * uniq) != hipSuccess || hipMalloc(&dst, fstride * fields + 4096) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(img, 3, istride * uniq); hipMemset(dst, 0, fstride * fields);
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int total = fields * ROWS;
     const double gb_in = (double) total * IPITCH / 1e9, gb_out = (double) total * 752 / 1e9;
-    printf("# tools/ubench_enc.hip: %d fields of 1920x1080 -> %d rows; image rows %.2f GB, signal %.2f GB; ms (best of 4)\n", fields, total, gb_in, gb_out);
+    printf("# tools/ubench_enc.hip: %d fields of " XSTR(PIXELS) " pixels per row -> %d rows; image rows %.2f GB, signal %.2f GB; ms (best of 4)\n", fields, total, gb_in, gb_out);
     printf("# %-52s %9s %9s %9s\n", "shape (LDS pad -> waves per CU)", "loads", "stores", "both");
     // (the same istride for fields beyond `uniq`: f % uniq through a smaller stride would change the pattern; instead cap)
     const int f_eff = fields <= uniq ? fields : uniq;
@@ -174,6 +191,10 @@ int main(int argc, char **argv)
             const int v64 = pass ? 565 / 3 : 0, v16p = pass ? 610 / 3 : 0;
             printf("# %s\n", pass ? "with the kernels' dependent vector work per tile (565 / 610 instructions)" : "memory only");
             char nm[96];
+            snprintf(nm, sizeof nm, "64 rows/wave, 64 B image, 64 B signal pieces, LDS 9700");
+            row(nm, [&](int l, int s) { hipLaunchKernelGGL((k_rows64<64, 64>), dim3((total_eff + 63) / 64), dim3(64), 9700, 0, img, istride, dst, fstride, total_eff, l, s, v64 / 2, sink); });
+            snprintf(nm, sizeof nm, "64 rows/wave, 64 B image, 128 B signal pieces, LDS 13800");
+            row(nm, [&](int l, int s) { hipLaunchKernelGGL((k_rows64<128, 64>), dim3((total_eff + 63) / 64), dim3(64), 13800, 0, img, istride, dst, fstride, total_eff, l, s, v64 / 2, sink); });
             snprintf(nm, sizeof nm, "64 rows/wave, 128 B image, 64 B signal pieces, LDS 13800");
             row(nm, [&](int l, int s) { hipLaunchKernelGGL((k_rows64<64>), dim3((total_eff + 63) / 64), dim3(64), 13800, 0, img, istride, dst, fstride, total_eff, l, s, v64, sink); });
             snprintf(nm, sizeof nm, "64 rows/wave, 128 B image, 128 B signal pieces, LDS 18000");
