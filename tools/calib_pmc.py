@@ -3,6 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir>/F -- tools/ubench_hbm.bin calib
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d <dir>/W -- tools/ubench_hbm.bin calib
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir>/E -- tools/ubench_enc640.bin 4096 calib
     tools/calib_pmc.py <dir>  > profiles/r03_pmc_calibration.json
 
 Every calibration kernel moves a known number of useful bytes (tools/ubench_hbm.hip, `calib`); the factor is
@@ -18,6 +19,11 @@ KNOWN = {  # kernel name prefix -> (counter, useful bytes, pattern)
     "void k_fill<0, 4>": ("WRITE_SIZE", GIB, "16 B/lane contiguous, plain stores"),
     "k_write_pieces64(": ("WRITE_SIZE", GIB, "64-byte aligned pieces, one per 256 B"),
     "k_write_pieces64_unaligned": ("WRITE_SIZE", GIB, "64-byte pieces at byte offset 28, one per 256 B"),
+    # the encoder's image reads as the encoder issues them (tools/ubench_enc.hip -DGEO640, `<fields> calib`, 4096 fields of
+    # 640x480: 240 rows x 2560 B each).  VERDICT round 4, weak #4: isolated 64-byte pieces count in full, but k_active's
+    # pieces are HALF LINES whose other half follows a tile later -- what the memory side is asked for is the line
+    "void k_rows64<64, 64>": ("FETCH_SIZE", 4096 * 240 * 2560, "k_active, narrow image tile: 64-byte half lines, the other half a tile later"),
+    "void k_rows64<64, 128>": ("FETCH_SIZE", 4096 * 240 * 2560, "k_active, wide image tile: whole 128-byte lines, nontemporal"),
 }
 vals = collections.defaultdict(dict)
 for f in glob.glob(sys.argv[1] + "/*/**/*counter_collection.csv", recursive=True):

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) unaligned16 { v4i v; };
 typedef __attribute__((address_space(1))) unaligned16 g_u16;
@@ -182,6 +183,17 @@ int main(int argc, char **argv)
         for (int m = 0; m < 3; m++) t[m] = best_ms([&] { launch(modes[m][0], modes[m][1]); }) * scale;
         printf("  %-52s %9.3f %9.3f %9.3f\n", name, t[0], t[1], t[2]);
     };
+    if (argc > 2 && !strcmp(argv[2], "calib")) {
+        // one loads-only launch of the encoder's two image-read patterns (run under rocprofv3 --pmc FETCH_SIZE; tools/calib_pmc.py
+        // divides the useful bytes printed here by the counter): 64-byte pieces whose other half-line follows a tile later
+        // (k_active with the narrow image tile) and whole 128-byte lines (wide tile)
+        hipLaunchKernelGGL((k_rows64<64, 64>), dim3((total_eff + 63) / 64), dim3(64), 9700, 0, img, istride, dst, fstride, total_eff, 1, 0, 0, sink);
+        hipLaunchKernelGGL((k_rows64<64, 128>), dim3((total_eff + 63) / 64), dim3(64), 13800, 0, img, istride, dst, fstride, total_eff, 1, 0, 0, sink);
+        hipDeviceSynchronize();
+        printf("calib: k_rows64<64, 64> %.0f B | k_rows64<64, 128> %.0f B (image rows of %d fields, " XSTR(PIXELS) " pixels per row)\n",
+               (double) total_eff * IPITCH, (double) total_eff * IPITCH, fields);
+        return 0;
+    }
     const int geo[3][2] = { { 910, 21 * 910 + 152 }, { 912, 21 * 912 + 160 }, { 1024, 21 * 1024 + 128 } };
     const char *geo_name[3] = { "reference pitch 910, odd start", "pitch 912, lines 16-byte aligned", "pitch 1024, lines 128-byte aligned" };
     for (int g = 0; g < 3; g++) for (int nt = 0; nt < 2; nt++) {
