@@ -344,6 +344,12 @@ int  crthip_set_overlap(crthip_ctx *ctx, int chunks);
 int  crthip_set_shape(crthip_ctx *ctx, int shape);
 
 
+/* HIP graphs: the encoder's cached tables (blanking / sync / burst skeleton, NES sample table) are rebuilt when the settings they
+ * derive from change; this counts the rebuilds.  A graph captured at generation g keeps replaying with generation g's tables --
+ * they stay allocated until crthip_destroy and are never written again -- i.e. with the settings it was captured with; compare
+ * the value at capture with the current one to know whether a kept graph still matches the context's latest settings. */
+unsigned crthip_table_generation(const crthip_ctx *ctx);
+
 /* Decoder output tile: 16 or 32 pixels per row and flush (0 = choose by output width, default). */
 int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
 /* Encoder signal tile of the fused path: how many bytes of a scanline leave the encoder per store piece.  0 (default) = by

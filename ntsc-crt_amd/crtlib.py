@@ -122,6 +122,8 @@ def load_library():
     L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_set_shape.argtypes = [vp, ci]
     L.crthip_set_signal_tile.argtypes = [vp, ci]
+    L.crthip_table_generation.argtypes = [vp]
+    L.crthip_table_generation.restype = C.c_uint
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
     L.crthip_vhs_chain.argtypes = [vp, ci, vp, ci]
     L.crthip_seq_vhs_prechained.argtypes = [vp, ci]
@@ -430,6 +432,10 @@ class CRT:
     def set_overlap(self, chunks):
         """fieldpass(): split the batch into `chunks` pieces alternating between two streams."""
         self._check(self.L.crthip_set_overlap(self.ctx, int(chunks)), "crthip_set_overlap")
+
+    def table_generation(self):
+        """rebuilds of the encoder's cached tables so far (a HIP graph captured at generation g replays with g's tables)"""
+        return int(self.L.crthip_table_generation(self.ctx))
 
     def set_signal_tile(self, dwords):
         """fieldpass(): the encoder's signal tile -- 0 by batch size (default), 16 = 64-byte store pieces, 32 / 64 = the large ones"""

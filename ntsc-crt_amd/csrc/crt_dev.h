@@ -414,6 +414,7 @@ __host__ __device__ constexpr int vhs_tail_start(int input_size, int hres)
 /* ------------------------------------------------------------------------- */
 /* host side: context, dispatch by system, C ABI                               */
 /* ------------------------------------------------------------------------- */
+#define CRTHIP_MAX_RETIRED 64
 struct crthip_ctx {
     int device;
     int system, pattern;
@@ -437,6 +438,10 @@ struct crthip_ctx {
     signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields (cached: the burst table they were built from) */
     signed char *d_skel_alt, *d_nes_tab_alt;   /* second set: where the tables are built when the context's stream is being captured */
     hipStream_t table_stream;   /* ... and the (never captured) stream they are built on then; created on first use */
+    bool tables_captured;       /* a captured graph may be reading the current table set: it is never written again (crt_run_encoder_prepare) */
+    unsigned table_gen;         /* incremented by every table rebuild (crthip_table_generation) */
+    signed char *retired[CRTHIP_MAX_RETIRED];   /* table sets that graphs may still read: freed by crthip_destroy */
+    int n_retired;
     bool skel_valid;
     int skel_burst[CRTHIP_CARRIER_ROWS][CRTHIP_MAX_CCS];
     int skel_border[4];         /* ... NES_BORDER: flag, colour, black point, white point */

@@ -1106,8 +1106,25 @@ __global__ void k_encoder_state(const crthip_params P, int n_fields, crthip_stat
  * HIP graph) a launch on the capturing stream would only be recorded: the tables would not exist when the capture ends,
  * the cache would call them valid, and every replay would rebuild them.  So under capture the tables are built FOR REAL,
  * now, on a private stream that is not being captured (the thread's capture mode relaxed for the duration, as allocators
- * do), into the context's second set of buffers -- kernels enqueued before the capture began may still be reading the
- * first -- and the sets are swapped.  The graph then holds only the per-call kernels, reading tables that exist. */
+ * do).  The graph then holds only the per-call kernels, reading tables that exist.
+ *
+ * Which buffer: a set of tables that a captured graph may be reading is NEVER written again.  Every capture
+ * marks the current set as referenced; a rebuild that finds the current set referenced (or happens under capture, where
+ * kernels enqueued before may still be reading it) goes into a set of its own -- the spare allocated with the context first,
+ * fresh allocations after that -- and the old set is retired, alive until crthip_destroy.  A graph captured with generation
+ * g (crthip_table_generation) therefore replays with generation g's tables whatever the context was asked to do since; it
+ * encodes with ITS settings, as a graph does.  Plain eager use (no capture ever) rebuilds in place as before. */
+static signed char *table_target(crthip_ctx *c, signed char **cur, signed char **spare, size_t bytes, bool fresh_needed)
+{
+    if (!fresh_needed) return *cur;
+    signed char *t = *spare;
+    *spare = nullptr;
+    if (!t && hipMalloc((void **) &t, bytes) != hipSuccess) return nullptr;
+    if (c->n_retired < CRTHIP_MAX_RETIRED) c->retired[c->n_retired++] = *cur;      /* (beyond: leaked until the process ends; 64 settings changes under graphs) */
+    *cur = t;
+    return t;
+}
+
 int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
@@ -1120,11 +1137,14 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
         const bool need_skel = fused && (!c->skel_valid || memcmp(c->skel_burst, p->burst, sizeof(p->burst)) != 0 || c->skel_yo != p->yo || !border_same);
         bool need_nes = false;
         if constexpr (S::IS_NES) need_nes = !c->nes_tab_valid || c->nes_tab_black != p->black_point || c->nes_tab_white != p->white_point;
-        if (!need_skel && !need_nes) return CRTHIP_OK;
 
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { (void) hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         const bool capturing = cap == hipStreamCaptureStatusActive;
+        if (!need_skel && !need_nes) {
+            if (capturing) c->tables_captured = true;          /* the graph being recorded reads the current set */
+            return CRTHIP_OK;
+        }
         hipStream_t st = c->stream;
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
         if (capturing) {
@@ -1136,42 +1156,51 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
             }
             st = c->table_stream;
         }
+        const bool fresh = capturing || c->tables_captured;
+        int rc = CRTHIP_OK;
         if (need_skel) {
             constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
-            signed char *dst = capturing ? c->d_skel_alt : c->d_skel;
-            if (!capturing) {
-                ProfScope ps(c, CRTHIP_K_TEMPLATE);
-                hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, st, *p, dst, c->fstride);
-            } else {
-                hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, st, *p, dst, c->fstride);
+            signed char *dst = table_target(c, &c->d_skel, &c->d_skel_alt, (size_t) SKEL_VARIANTS * c->fstride, fresh);
+            if (!dst) rc = set_err(c, CRTHIP_E_NOMEM, "hipMalloc skeleton tables", hipSuccess);
+            else {
+                if (!capturing) {
+                    ProfScope ps(c, CRTHIP_K_TEMPLATE);
+                    hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, st, *p, dst, c->fstride);
+                } else {
+                    hipLaunchKernelGGL((k_skeleton<S>), dim3((SK_LANES + 255) / 256), dim3(256), 0, st, *p, dst, c->fstride);
+                }
+                memcpy(c->skel_burst, p->burst, sizeof(p->burst));
+                c->skel_yo = p->yo;
+                memcpy(c->skel_border, border_key, sizeof(border_key));
+                c->skel_valid = true;
             }
-            memcpy(c->skel_burst, p->burst, sizeof(p->burst));
-            c->skel_yo = p->yo;
-            memcpy(c->skel_border, border_key, sizeof(border_key));
-            c->skel_valid = true;
         }
         if constexpr (S::IS_NES) {
-            if (need_nes) {
-                signed char *dst = capturing ? c->d_nes_tab_alt : c->d_nes_tab;
-                if (!capturing) {
-                    ProfScope ps(c, CRTHIP_K_ACTIVE);
-                    hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, st, *p, dst);
-                } else {
-                    hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, st, *p, dst);
+            if (need_nes && rc == CRTHIP_OK) {
+                signed char *dst = table_target(c, &c->d_nes_tab, &c->d_nes_tab_alt, NES_TAB_SIZE, fresh);
+                if (!dst) rc = set_err(c, CRTHIP_E_NOMEM, "hipMalloc NES sample table", hipSuccess);
+                else {
+                    if (!capturing) {
+                        ProfScope ps(c, CRTHIP_K_ACTIVE);
+                        hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, st, *p, dst);
+                    } else {
+                        hipLaunchKernelGGL((k_nes_table<S>), dim3((NES_TAB_SIZE + 255) / 256), dim3(256), 0, st, *p, dst);
+                    }
+                    c->nes_tab_black = p->black_point;
+                    c->nes_tab_white = p->white_point;
+                    c->nes_tab_valid = true;
                 }
-                c->nes_tab_black = p->black_point;
-                c->nes_tab_white = p->white_point;
-                c->nes_tab_valid = true;
             }
         }
+        c->table_gen++;
+        c->tables_captured = capturing;                        /* the new set: referenced iff this very call is being recorded */
         if (capturing) {
             const hipError_t e = hipStreamSynchronize(st);
             (void) hipThreadExchangeStreamCaptureMode(&mode);
             if (e != hipSuccess) { c->skel_valid = false; c->nes_tab_valid = false; return set_err(c, CRTHIP_E_HIP, "table build under capture", e); }
-            if (need_skel) { signed char *t = c->d_skel; c->d_skel = c->d_skel_alt; c->d_skel_alt = t; }
-            if (need_nes) { signed char *t = c->d_nes_tab; c->d_nes_tab = c->d_nes_tab_alt; c->d_nes_tab_alt = t; }
         }
-        return CRTHIP_OK;
+        if (rc != CRTHIP_OK) { c->skel_valid = false; c->nes_tab_valid = false; }
+        return rc;
     });
 }
 

@@ -297,6 +297,7 @@ void crthip_destroy(crthip_ctx *c)
     if (c->d_nes_tab_alt) hipFree(c->d_nes_tab_alt);
     if (c->d_skel) hipFree(c->d_skel);
     if (c->d_skel_alt) hipFree(c->d_skel_alt);
+    for (int i = 0; i < c->n_retired; i++) if (c->retired[i]) hipFree(c->retired[i]);
     if (c->d_jump1) hipFree(c->d_jump1);
     if (c->d_analog) hipFree(c->d_analog);
     if (c->d_inp) hipFree(c->d_inp);
@@ -578,6 +579,8 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     HIPCHK(c, hipGetLastError());
     return CRTHIP_OK;
 }
+
+unsigned crthip_table_generation(const crthip_ctx *c) { return c ? c->table_gen : 0u; }
 
 int crthip_set_signal_tile(crthip_ctx *c, int dwords)
 {

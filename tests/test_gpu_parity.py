@@ -1211,6 +1211,65 @@ def test_full_size_batch_properties_vhs_nes(crtlib, name, n, noise):
                (c.get("hsync"), c.get("vsync"), c.get("rn")), "%s: state of field %d" % (name, k)
 
 
+def test_a_kept_graph_keeps_its_tables(crtlib):
+    """the encoder's cached tables (skeleton fields: a function of the burst table, i.e. of the hue) used to swap
+    between two buffer sets, so a later capture or an eager call with other settings rewrote the set an EARLIER graph was reading
+    and that graph silently encoded with the wrong burst.  Now a set a graph may be reading is never written again: graph A
+    (hue 0), an eager pass with hue 40, graph B (hue 80), another eager pass with hue 120 -- then A and B are replayed and must
+    give what eager passes with THEIR settings give; crthip_table_generation counts the rebuilds."""
+    import torch
+    n, w, h = 4, 640, 480
+    imgs = _padded(np.stack([R.synth_image(w, h, 4, 60 + k) for k in range(n)]))
+
+    def settings(hue):
+        return crtlib.Settings(imgs, format=crtlib.FMT_BGRA, field=[k & 1 for k in range(n)], frame=0, hue=hue)
+
+    def eager_result(hue):
+        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+        g.scanlines = 1
+        s = settings(hue)
+        g.fieldpass(s, 24)
+        g.synchronize()
+        out = g.out.clone()
+        g.close()
+        return out
+    want = {hue: eager_result(hue) for hue in (0, 80)}
+    assert not torch.equal(want[0], want[80])
+    g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, "ntsc", device=0)
+    g.scanlines = 1
+    g.reserve(n)
+    side = torch.cuda.Stream()
+    g.use_stream(side)
+    s0 = settings(0)
+    g._load_field_state(s0)
+    torch.cuda.synchronize()
+    state0 = g.state.clone()
+    graphs, gens = {}, {}
+    for hue in (0, 40, 80, 120):
+        s = settings(hue)
+        p = g.params(s, 24)
+        g.state.copy_(state0)
+        torch.cuda.synchronize()
+        if hue in (0, 80):
+            graphs[hue] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[hue], stream=side):
+                g.fieldpass(s, 24, params=p)
+            gens[hue] = g.table_generation()
+        else:
+            g.fieldpass(s, 24, params=p)
+            g.synchronize()
+    assert gens[80] > gens[0] and g.table_generation() > gens[80]
+    for hue in (0, 80, 0):
+        g.state.copy_(state0)
+        g.out.zero_()
+        torch.cuda.synchronize()
+        graphs[hue].replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g.out, want[hue]), "the graph captured with hue %d no longer encodes with its own tables" % hue
+    del graphs
+    g.close()
+
+
 @pytest.mark.parametrize("name,n,noise", [("ntsc", 24, 0), ("ntsc", 24, 150), ("ntsc", 520, 60), ("snes", 24, 100), ("pv1k", 12, 90),
                                           ("nes", 24, 80), ("ntscbloom", 24, 40)])
 def test_wild_sync_states_against_the_oracle(crtlib, name, n, noise):
