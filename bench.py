@@ -643,6 +643,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time a replayed HIP graph of two steps instead of eager launches (measured: no difference)")
     ap.add_argument("--full-json", default="", help="also write the complete record (every workload's own objects) to this file")
     ap.add_argument("--dry-run", action="store_true", help="(tests) exercise launch / collectives / JSON without a GPU")
+    ap.add_argument("--multi-gpu-workloads", action="store_true",
+                    help="(tests) run what a --gpus N run adds to the headline -- 1080p weak, BASELINE configs[2] sharded over the ranks -- "
+                         "with the ranks there are (with --force-dist: through RCCL on a 1-GPU box)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run every collective of the multi-GPU path (settings broadcast, "
                          "CRC all_gather, MAX all-reduce, barriers) even with ONE rank -- exercises RCCL on a 1-GPU box")
@@ -733,7 +736,7 @@ def main():
             extras.append(r)
 
     mg = {}
-    if world > 1 and headline and not args.no_extra:
+    if headline and ((world > 1 and not args.no_extra) or args.multi_gpu_workloads):
         # `bench.py --gpus N` is the command the driver's scaling run issues -- it must report the 1080p
         # numbers of the north star too, not only the weak 640x480 headline
         for e in multi_gpu_workloads(world, rank, shard):

@@ -40,6 +40,18 @@ def test_bench_force_dist_runs_every_collective_over_rccl(launcher):
     assert j["value"] > 1e5
 
 
+def test_bench_multi_gpu_workloads_over_rccl():
+    """what `bench.py --gpus N` adds to the headline on every rank -- 1080p weak and BASELINE configs[2] sharded over the ranks -- run
+    here with the one rank there is, every collective through RCCL: the final line carries the north star's row"""
+    j = _bench([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--multi-gpu-workloads", "--no-cpu", "--no-extra", "--steps", "4",
+                "--warmup", "1"])
+    ns = j["north_star"]
+    assert ns["n_gpus"] == 1 and j["world_size_seen_by_rccl"] == 1
+    assert ns["fps_640"] > 1e5 and ns["fps_1080p_weak"] > 1e5 and 0.3 < ns["frac_1080p_weak"] < 1.0
+    assert ns["configs2_frames"] == 512 and ns["configs2_frames_per_gpu"] == 512 and 0.3 < ns["configs2_ms"] < 5.0
+    assert abs(ns["configs2_fps"] - 512e3 / ns["configs2_ms"]) < 1e-2 * ns["configs2_fps"]
+
+
 @pytest.mark.parametrize("n_fields", [11, 4])
 def test_node_entry_matches_the_single_context_path(n_fields):
     """include/crt_hip_node.h through its C test program (tests/node_probe.c, built by ntsc-crt_amd/Makefile):
