@@ -207,7 +207,7 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
     constexpr int DW = VHS_CHUNK / 4;                            /* dwords per chunk */
     constexpr int DWS = DW | 1;                                  /* odd LDS stride: conflict-free lane-per-chunk access */
     static_assert((2 * VHS_CHUNK) % 31 == 0 && VHS_CHUNK % 4 == 0, "static ring index / dword packing");
-    __shared__ unsigned s_t[64 * DWS];
+    __shared__ __attribute__((aligned(16))) unsigned s_t[64 * DWS];
     __shared__ unsigned long long s_off[64];
     const int lane = threadIdx.x;
     const int gid = blockIdx.x * 64 + lane;
@@ -262,6 +262,23 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
      * (Several tiles per jump -- 37 % fewer vector instructions, but a loop the register allocator answers with 162
      * VGPRs -- measured 0.824 ms, the field-pass the same: not kept.) */
     static_assert(DWS == DW, "tile rows are packed: LDS dword index == request * 64 + lane");
+    /* (r5) A wave whose 64 chunks are ONE contiguous run of one field (26 waves in 27) moves its tile in 16-byte pieces -- 8 requests
+     * of 1 KB (global_load_lds_dwordx4, gfx950: lane l's 16 bytes land at LDS base + 16 l, tools/probe_lds128.hip) instead of 31
+     * of 256 bytes, and 8 stores instead of 31 on the way out; the waves that straddle a field boundary or the batch's end keep
+     * the dword path */
+    static_assert((64 * DW) % 4 == 0, "the tile is a whole number of 16-byte pieces");
+    constexpr int P16 = (64 * DW / 4 + 63) / 64;                 /* 16-byte requests per tile */
+    const bool one_run = f_first == f_last && gid_first + 63 < total;
+    const unsigned long long run_base = (unsigned long long) f_first * fstride + (unsigned long long) (gid_first - f_first * chunks_a) * VHS_CHUNK;
+    if (one_run) {
+#pragma unroll
+        for (int it = 0; it < P16; it++) {
+            const int n = (it * 64 + lane) * 4;                  /* first dword of my piece */
+            if (n < 64 * DW)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *) (analog + run_base + 4 * (size_t) n),
+                                                 (void __attribute__((address_space(3))) *) (s_t + it * 256), 16, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int it = 0; it < DW; it++) {
         const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
@@ -269,6 +286,7 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
         if (off != ~0ull)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *) (analog + off + 4 * d),
                                              (void __attribute__((address_space(3))) *) (s_t + it * 64), 4, 0, 0);
+    }
     }
     /* history of call K = 1 + 2 * VHS_CHUNK * q */
     unsigned w[31];
@@ -313,6 +331,17 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
         }
     }
     __syncthreads();
+    if (one_run) {
+#pragma unroll
+        for (int it = 0; it < P16; it++) {
+            const int n = (it * 64 + lane) * 4;
+            if (n < 64 * DW) {
+                const v4i o = *(const v4i *) (s_t + n);
+                gstore16u((unsigned long long) (inp + run_base + 4 * (size_t) n), o);
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int it = 0; it < DW; it++) {
         const int n = it * 64 + lane, owner = n / DW, d = n - owner * DW;
@@ -337,6 +366,8 @@ k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__
 /* (three waves per SIMD: 168 registers and a few spilled dwords instead of 242.  The kernel runs BESIDE k_vhs_noise, and two of its
  * waves per SIMD at 242 registers left that kernel none: the two ran one after the other -- 0.41 + 0.46 ms -- whatever the
  * streams said; at 168 one wave of k_vhs_noise fits next to them: 0.845 -> 0.785 ms for the pair, profiles/r04_experiments.txt) */
+#define VHS_COS_TAB 24                                         /* >= (HRES * 17) / HRES + 2 distinct values of (i * line) / HRES per segment */
+#define VHS_DIV_MAGIC(h) ((unsigned long long) ((((1ull << 40) + (h) - 1) / (h))))
 template <class S, bool MFMA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ analog,
@@ -352,6 +383,7 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
     __shared__ unsigned s_h[64];                                   /* 31-value history in front of the window; base sequence */
     __shared__ unsigned s_misc[2];
     __shared__ signed char s_a[NB * 64], s_o[NB * 64];
+    __shared__ int s_cos[VHS_COS_TAB];                             /* the band's noise amplitudes of the current segment, by (i * line) / HRES */
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     if (f >= n_fields) return;
@@ -475,6 +507,16 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
         __syncthreads();
 
         /* 4. samples (crt_core.c:347-365) */
+        /* (r5) The amplitude inside the aberration band, nn = cos14(((i * line) / HRES) * 8192 / 180) >> 8 (crt_core.c:353-355),
+         * used to be evaluated per sample inside the walk below -- two divisions and the sine polynomial behind a branch that some
+         * lane of the wave nearly always takes: two thirds of the walk's instructions, on the one chain that bounds the VHS noise
+         * pair (25 segments x 19 us per field).  (i * line) / HRES takes at most 18 consecutive values
+         * over a segment of <= HRES samples (line <= 17): one lane per value evaluates the cosine ONCE per segment into a table,
+         * the walk divides by HRES with an exact multiply-shift and looks it up.  The per-sample `r2 % 20 > kseg - 6` is the flag
+         * bit the speculative walks already use (G), not a second modulo. */
+        const int ln_first = (seg_start * vhs_line) / H;
+        if (lane < VHS_COS_TAB) s_cos[lane] = dev_cos14((ln_first + lane) * 8192 / 180) >> 8;
+        __syncthreads();
         {
             int pos = e_in;
             for (int k = 0; k < (B + 1) / 2; k++) {
@@ -483,17 +525,15 @@ k_vhs_tail(const crthip_params P, int n_fields, const signed char *__restrict__ 
                 if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break;
                 if (valid) {
                     const unsigned *yp = s_y + lane * B + pos;
-                    const unsigned rnv = yp[0] >> 1, r2 = yp[1] >> 1;
+                    const unsigned rnv = yp[0] >> 1;
                     const int i = seg_start + s;
-                    const int c1 = 6 + (int) (r2 % 20u) > kseg ? 1 : 0;
-                    int nn = noise;
-                    if (c1) {
-                        const unsigned r3 = yp[2] >> 1;
-                        if (i < N - H * (5 + ((int) (r3 & 7u) - 4))) {
-                            const int ln = (i * vhs_line) / H;
-                            nn = dev_cos14(ln * 8192 / 180) >> 8;
-                        }
-                    }
+                    const int c1 = (int) ((G >> (pos + 1)) & 1ull);                       /* 6 + r2 % 20 > kseg, crt_core.c:350 */
+                    const unsigned r3 = yp[2] >> 1;                                       /* (read whether or not it is a call: in bounds) */
+                    /* (i * line) / HRES: i * line < 2^23, HRES < 2^11: exact as (x * ceil(2^40 / HRES)) >> 40 */
+                    const unsigned x = (unsigned) (i * vhs_line);
+                    const int ln = (int) (((unsigned long long) x * VHS_DIV_MAGIC(H)) >> 40);
+                    const bool band = c1 && i < N - H * (5 + ((int) (r3 & 7u) - 4));      /* crt_core.c:351 */
+                    const int nn = band ? s_cos[ln - ln_first] : noise;
                     const int sv = (int) s_a[s] + (mul_lo_mad64((int) ((rnv >> 16) & 0xffu) - 0x7f, nn) >> 8);
                     s_o[s] = (signed char) clampi(sv, -127, 127);
                     pos += 2 + c1;
