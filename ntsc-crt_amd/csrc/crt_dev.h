@@ -392,6 +392,7 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * more than the pieces give (profiles/r04_experiments.txt section 19, profiles/r05_experiments.txt sections 2-4) */
 #define SIG_TILE64_MIN_WAVES_WIDE 6144     /* wide image tile (w >= 1280): 256-byte pieces */
 #define SIG_TILE32_MIN_WAVES      6720     /* narrow image tile: 128-byte pieces */
+#define SYNC_FPB4_MIN_FIELDS 768            /* k_hsync_wave: four fields per workgroup from here on, one below (crt_sync.hip) */
 #define WIDE_LPW8_MAX_WAVES 1440           /* k_decode_wide: 8 scanlines per wave while 16 per wave would make fewer waves than this (1080p: < 96 fields; measured: 32 fields -10 %, 64 -4 %, 128 +4 %) */
 #define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
 

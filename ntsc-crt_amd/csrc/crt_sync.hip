@@ -650,11 +650,12 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         using S = decltype(tag);
         ProfScope ps(c, CRTHIP_K_SYNC);
         /* 4 fields per workgroup share one wave for their burst chains (large batches); CRTHIP_SYNC_KERNEL=2 / 3 force 1 / 4
-         * fields per workgroup (A/B) */
+         * fields per workgroup (A/B).  (r5) threshold re-measured, session r5s23: 512 fields 0.078 (one) / 0.085 ms (four) and the
+         * field-pass 0.566 / 0.606; 1024 fields 0.097 / 0.090; 4096 fields 0.188 / 0.165; 1080p x 2048 0.140 / 0.119 */
         constexpr bool FPB4_OK = 64 / (S::VPER * S::CCS) >= 4;
         bool done = false;
         if constexpr (FPB4_OK) {
-            if (c->sync_kernel != 2 && (n >= 512 || c->sync_kernel == 3)) {
+            if (c->sync_kernel != 2 && (n >= SYNC_FPB4_MIN_FIELDS || c->sync_kernel == 3)) {
                 hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
                                    c->whole_field, advance_rn, preset_ccf);
                 done = true;
