@@ -866,21 +866,29 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
     int q = gid - f * per_field;
     const int s0 = P.yo * S::HRES + P.xo;
     const int gap_len = S::HRES - P.destw;
-    int idx0, len;
+    int idx0, len, region0;
     if (q < head_chunks) {
         idx0 = q * 16;
         len = s0 - idx0;
+        region0 = 0;
     } else if (q < head_chunks + (P.desth - 1) * gap_chunks) {
         q -= head_chunks;
         const int yy = q / gap_chunks, c = q - yy * gap_chunks;
-        idx0 = s0 + yy * S::HRES + P.destw + c * 16;
+        region0 = s0 + yy * S::HRES + P.destw;
+        idx0 = region0 + c * 16;
         len = gap_len - c * 16;
     } else {
         q -= head_chunks + (P.desth - 1) * gap_chunks;
-        idx0 = s0 + (P.desth - 1) * S::HRES + P.destw + q * 16;
+        region0 = s0 + (P.desth - 1) * S::HRES + P.destw;
+        idx0 = region0 + q * 16;
         len = S::INPUT_SIZE - idx0;
     }
     if (len > 16) len = 16;
+    /* (r5) a region's last, partial chunk is moved BACK so that it ends with the region and is a whole chunk too (it overlaps its
+     * neighbour, which writes the same bytes: skeleton and noise are functions of the sample index).  As 1-15 byte stores it made
+     * EVERY wave of the kernel issue up to 15 store instructions beside its one 16-byte store -- a gap is 157 samples, every tenth
+     * lane was partial: k_margin 0.116 -> see profiles/r05_experiments.txt section 14 */
+    if (len < 16 && idx0 - (16 - len) >= region0) { idx0 -= 16 - len; len = 16; }
     const crthip_state *st = state + f;
     const int aux = st->aux;
     const int var = skeleton_variant<S>(st->field, st->frame, aux);
