@@ -857,13 +857,15 @@ template <class S, bool NOISE>
 __global__ void __launch_bounds__(256)
 k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride,
          const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1,
-         const signed char *__restrict__ skel, int head_chunks, int gap_chunks, int tail_chunks)
+         const signed char *__restrict__ skel, int head_chunks, int gap_chunks, int tail_chunks, unsigned gap_magic)
 {
+    /* (r5) the field is the grid's y index and the row of a gap chunk comes from a multiply-high by ceil(2^32 / gap_chunks)
+     * (exact for the < 2^16 chunks of a field): two runtime integer divisions per lane were a third of a noise-free lane's work */
     const int per_field = head_chunks + (P.desth - 1) * gap_chunks + tail_chunks;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= n_fields * per_field) return;
-    const int f = gid / per_field;
-    int q = gid - f * per_field;
+    const int q0 = blockIdx.x * 256 + threadIdx.x;
+    if (q0 >= per_field) return;
+  for (int f = blockIdx.y; f < n_fields; f += (int) gridDim.y) {
+    int q = q0;
     const int s0 = P.yo * S::HRES + P.xo;
     const int gap_len = S::HRES - P.destw;
     int idx0, len, region0;
@@ -873,7 +875,7 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
         region0 = 0;
     } else if (q < head_chunks + (P.desth - 1) * gap_chunks) {
         q -= head_chunks;
-        const int yy = q / gap_chunks, c = q - yy * gap_chunks;
+        const int yy = gap_chunks == 1 ? q : (int) __umulhi((unsigned) q, gap_magic), c = q - yy * gap_chunks;     /* (ceil(2^32 / 1) does not fit) */
         region0 = s0 + yy * S::HRES + P.destw;
         idx0 = region0 + c * 16;
         len = gap_len - c * 16;
@@ -945,11 +947,12 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
             if (k < len) out[idx0 + k] = (signed char) (o4[k >> 2] >> (8 * (k & 3)));
         }
     }
-    if (gid - f * per_field == 0) {
+    if (q0 == 0) {
         /* mirror of the struct members behind inp[] (see CRTHIP_TAIL) */
         signed char *tail = out + S::INPUT_SIZE;
         store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
     }
+  }
 }
 
 template <class S>
@@ -1037,13 +1040,15 @@ static void launch_margins(crthip_ctx *c, const crthip_params *p, int n, signed 
     const int gap = (S::HRES - p->destw + 15) / 16;
     const int tail_len = S::INPUT_SIZE - (s0 + (p->desth - 1) * S::HRES + p->destw);
     const int tail = (tail_len + 15) / 16;
-    const int total = n * (head + (p->desth - 1) * gap + tail);
+    const int per_field = head + (p->desth - 1) * gap + tail;
+    const unsigned gap_magic = gap > 0 ? (unsigned) ((0x100000000ull + (unsigned) gap - 1) / (unsigned) gap) : 0u;
+    const dim3 grid((per_field + 255) / 256, n < 65535 ? n : 65535);          /* (fields beyond the grid's y limit: the kernel loops) */
     if (p->noise != 0)
-        hipLaunchKernelGGL((k_margin<S, true>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                           *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+        hipLaunchKernelGGL((k_margin<S, true>), grid, dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail, gap_magic);
     else
-        hipLaunchKernelGGL((k_margin<S, false>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
-                           *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail);
+        hipLaunchKernelGGL((k_margin<S, false>), grid, dim3(256), 0, c->stream,
+                           *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail, gap_magic);
 }
 
 template <class S, bool FULL>
