@@ -203,7 +203,7 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * 2 = 24-bit mads, all cascades (also every line flagged CRTHIP_LINE_KEEPLO),
  * 3 = exact 32-bit multiplies; 4 / 5 = the FIR kernels of a USE_CONVOLUTION build (P.eq_kernel taps; the whole
  * batch) with 24-bit / exact 32-bit multiplies around them; a wave of 64 lines is decoded by the kernel
- * of its tier = max(tier flagged by k_hsync from its carrier amplitude, min_tier of the batch);
+ * of its tier = max(tier flagged by k_hsync_wave from its carrier amplitude, min_tier of the batch);
  * want_rank: only lines of this collision rank (always 0 unless outh + v_fac < LINES).
  * BLOOM (CRT_DO_BLOOM build, crt_core.c:512-526): every scanline has its own resampler step and start, a function of its
  * width line_w alone.  The 64 lines of a wave are then not neighbours but lines of EQUAL line_w, gathered by `perm` (the

@@ -17,7 +17,7 @@
  * Translation units (stage names M0-M6 / D0-D10 as in DESIGN.md):
  *   crt_encode.hip  M4-M6   k_template / k_skeleton + k_margin (skeleton), k_active, k_nes_table + k_active_nes
  *   crt_noise.hip   D1      k_noise (LCG, jump-ahead tables), k_vhs_noise + k_vhs_tail (libc rand() model)
- *   crt_sync.hip    D2-D7   k_vsync, k_hsync (serial chain over the lines of a field)
+ *   crt_sync.hip    D2-D7   k_hsync_wave (a wave per field: vertical search, hsync fixed point, burst chains, line table), k_vsync, k_bloom
  *   crt_decode.hip  D8-D10  k_decode (3x 3-band IIR equaliser, resample, YIQ->RGB, row duplication)
  *   crt_host.hip            context, the crthip_* C ABI, sequence mode
  * Integer-only; signed overflow wraps (-fwrapv), >> of negatives is arithmetic, / truncates --
@@ -58,7 +58,7 @@ struct SysCommon {
     static constexpr int VS_LO = 4, VS_HI = 6;          /* crt_ntsc.c:217 */
     static constexpr bool VS_BY_FIELD = true;
     static constexpr int CCF_SHIFT = 0;                 /* ccf preset row = (line + CCF_SHIFT) % VPER */
-    static constexpr int SYNC_WIN = 256;                /* bytes of a line's parked sync/burst window (k_hsync) */
+    static constexpr int SYNC_WIN = 256;                /* (bytes of a line's parked sync/burst window in round 1's 16-lanes-per-field kernel; unused since round 5) */
 };
 template <int CC_LINE>
 struct RgbTiming : SysCommon {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h / crt_template.h */

@@ -9,7 +9,7 @@
  *   rn      : closed form, rn_k = J^k(rn_0), J = INPUT_SIZE steps of the LCG;
  *   encoder : independent per field (fused, writes the noisy field);
  *   sync    : field k starts from field k-1's final (hsync, vsync).  Solved as a fixed point: every
- *             pass runs k_vsync/k_hsync for ALL fields in parallel with init_k = final_{k-1} of the
+ *             pass runs k_hsync_wave for ALL fields in parallel with init_k = final_{k-1} of the
  *             previous pass; after pass j fields 0..j-1 are final for good, and because a field's final
  *             state hardly ever depends on its initial one the iteration normally stops after 2-3 passes;
  *   decoder : independent per field given its line table (blend must be 0: with blend the output is a

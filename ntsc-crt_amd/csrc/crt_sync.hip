@@ -98,7 +98,7 @@ __device__ __forceinline__ void vsync_search(const signed char *__restrict__ in,
     if (!found) vj = S::HRES;
 }
 
-/* D2 as a kernel of its own (the 16-lanes-per-field k_hsync needs it; k_hsync_wave searches for itself) */
+/* D2 as a kernel of its own: the CRT_DO_VSYNC 0 variant searches the CLEAN field before the noise stage (k_hsync_wave searches for itself) */
 template <class S>
 __global__ void __launch_bounds__(64)
 k_vsync(int n_fields, const signed char *__restrict__ inp, size_t fstride, crthip_state *__restrict__ state,

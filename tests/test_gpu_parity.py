@@ -1297,7 +1297,7 @@ def test_wild_sync_states_against_the_oracle(crtlib, name, n, noise):
     vs = [vs0[(k // uniq * 5 + k) % len(vs0)] for k in range(n)]
     fields = [k & 1 for k in range(n)]
     outs = {}
-    for spec in (1,):
+    for spec in (1,):      # (one pass; the dict keeps the shape the comparisons below were written for)
         g = crtlib.CRT(n, 640, 480, crtlib.FMT_BGRA, name, device=0)
         g.scanlines = 1
         g.state[:, crtlib.ST_HSYNC] = torch.tensor(hs, dtype=torch.int32, device="cuda:0")
