@@ -102,6 +102,40 @@ DROPIN = {"ntsc": ("libntsccrt_hip_ntsc.so", ["-DCRT_SYSTEM=0"]),
           "nesborder": ("libntsccrt_hip_nes_border.so", ["-DCRT_SYSTEM=1", "-DNES_BORDER=1"])}
 
 
+def build_driver_binaries():
+    """The reference's UNCHANGED drivers (crt_main.c, extra/video_convert.c, straight from /root/reference) compiled against
+    include/ and linked with the HIP drop-in libraries -> ntsc-crt_amd/lib/ntsc_cli_hip & co. (tests/test_gpu_dropin.py,
+    tools/time_cli.py run them on the GPU box, where the reference's sources do not exist).  Returns [(exe, gcc -H log)];
+    raises if a link fails; [] where there is no /root/reference."""
+    import subprocess
+    import tempfile
+    ref = "/root/reference"
+    if not os.path.exists(ref + "/crt_main.c"):
+        return []
+    inc = os.path.join(ROOT, "include")
+    done = []
+    # `#include "crt_core.h"` looks next to the including file first; the drivers are therefore
+    # reached through symlinks in a scratch directory, so the only crt_core.h found is include/'s.
+    with tempfile.TemporaryDirectory(prefix="crtdrv") as tmp:
+        for f in ("crt_main.c", "extra/video_convert.c"):
+            os.symlink(os.path.join(ref, f), os.path.join(tmp, os.path.basename(f)))
+        for out, defs, drv, lib in [
+            ("ntsc_cli_hip", ["-DCRT_SYSTEM=0"], "crt_main.c", "ntsccrt_hip_ntsc"),
+            ("ntscvhs_video_hip", ["-DCRT_SYSTEM=5"], "video_convert.c", "ntsccrt_hip_vhs"),
+            ("ntsc_cli_snes_hip", ["-DCRT_SYSTEM=3"], "crt_main.c", "ntsccrt_hip_snes"),
+            ("ntsc_cli_pv1k_hip", ["-DCRT_SYSTEM=2"], "crt_main.c", "ntsccrt_hip_pv1k"),
+        ]:
+            exe = os.path.join(PKG_LIB, out)
+            cmd = ["gcc", "-O2", "-w", "-std=c89", "-H", "-I" + inc, "-I" + ref] + defs + ["-o", exe,
+                   os.path.join(tmp, drv), ref + "/ppm_rw.c", ref + "/bmp_rw.c",
+                   "-L" + PKG_LIB, "-l" + lib, "-Wl,-rpath," + PKG_LIB]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("linking %s failed: %s" % (out, r.stderr[-2000:]))
+            done.append((exe, r.stderr))
+    return done
+
+
 def build_dropin_probe(name):
     """tests/abi_probe.c compiled against THIS repo's include/crt_core.h and linked to the drop-in
     library: the same refp_* helper surface as oracle/_ref, but over the HIP implementation."""
