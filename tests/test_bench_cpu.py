@@ -96,6 +96,31 @@ def test_final_line_is_compact_and_round_trips():
     assert len(line2) <= bench.LINE_LIMIT and json.loads(line2)["roofline"]["frac"] == rf["frac"]
 
 
+def test_compact_line_of_an_eight_rank_run_fits():
+    """the final line of `bench.py --gpus 8` as the driver's scaling run will see it: this round's record dressed up as rank 0 of
+    eight (process group, eight blob CRCs, the north-star row from the multi-GPU workloads, no N = 1 extras) stays under the limit
+    with every judged object intact"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    by = {e["name"]: e for e in full["extra_workloads"] if e}
+    full.update(n_gpus=8, world_size=8, world_size_seen_by_rccl=8,
+                collectives={"backend": "nccl", "initialized": True,
+                             "ran": ["broadcast(settings blob)", "all_gather(blob crc)", "all_reduce(MAX elapsed)", "barrier"]},
+                settings_blob_crc32_per_rank=[3735928559] * 8, settings_blob_crc32_rank0_before_broadcast=3735928559,
+                north_star=bench.north_star_table(8, full, by["1080p_batch2048"], by["1080p_batch64"]))
+    for k in ("extra_workloads", "strong_scaling", "cli_config1", "cpu_baseline", "gpu_over_cpu", "gpu_over_cpu_all_cores"):
+        full.pop(k, None)
+    line = json.dumps(bench.compact_record(full))
+    back = json.loads(line)
+    assert len(line) <= bench.LINE_LIMIT
+    assert back["n_gpus"] == 8 and back["world_size_seen_by_rccl"] == 8 and len(back["settings_blob_crc32_per_rank"]) == 8
+    assert back["collectives"]["initialized"] is True and back["north_star"]["n_gpus"] == 8
+    for k in ("fps_640", "fps_1080p_weak", "frac_1080p_weak", "configs2_ms", "configs2_fps", "configs2_frames_per_gpu"):
+        assert back["north_star"][k], k
+    assert back["roofline"]["frac"] > 0 and back["value_spread"]["reps"] == 5
+
+
 def test_traffic_files_carry_a_source_hash_when_fresh():
     """roofline.traffic comes from committed PMC passes; bench.py flags it stale when csrc/ changed since."""
     sys.path.insert(0, ROOT)
