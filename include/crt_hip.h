@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CRTHIP_ABI_VERSION 5
+#define CRTHIP_ABI_VERSION 6
 
 /* CRT_SYSTEM_* of crt_core.h:30-36 */
 #define CRTHIP_SYSTEM_NTSC    0
@@ -357,6 +357,10 @@ int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
  * leaves), 16 = always the 64-byte pieces, 32 or 64 = always the large ones.  Same bytes either way (tests, A/B measurements).
  * Environment: CRTHIP_SIG_TILE sets the default of new contexts. */
 int  crthip_set_signal_tile(crthip_ctx *ctx, int dwords);
+/* Wide-run decoder (wide pictures, crt_decode4.hip): scanlines per wavefront.  0 (default) = by batch size (8 below 96 fields of
+ * 1920x1080, 16 from there on), 8 / 16 = always that instantiation.  Same pictures either way (tests pin each instantiation to the
+ * oracle, A/B measurements).  Environment: CRTHIP_WIDE_LPW sets the default of new contexts. */
+int  crthip_set_wide_lpw(crthip_ctx *ctx, int scanlines_per_wave);
 
 /* The decoder and encoder normally run kernels whose multiplies are the full-rate 24-bit
  * instructions; they are dispatched only where every operand is proven to fit (DESIGN.md,

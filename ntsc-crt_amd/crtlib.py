@@ -122,6 +122,7 @@ def load_library():
     L.crthip_set_overlap.argtypes = [vp, ci]
     L.crthip_set_shape.argtypes = [vp, ci]
     L.crthip_set_signal_tile.argtypes = [vp, ci]
+    L.crthip_set_wide_lpw.argtypes = [vp, ci]
     L.crthip_table_generation.argtypes = [vp]
     L.crthip_table_generation.restype = C.c_uint
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
@@ -440,6 +441,10 @@ class CRT:
     def set_signal_tile(self, dwords):
         """fieldpass(): the encoder's signal tile -- 0 by batch size (default), 16 = 64-byte store pieces, 32 / 64 = the large ones"""
         self._check(self.L.crthip_set_signal_tile(self.ctx, int(dwords)), "crthip_set_signal_tile")
+
+    def set_wide_lpw(self, lpw):
+        """the wide-run decoder's scanlines per wavefront: 0 by batch size (default), 8 or 16 = always that instantiation"""
+        self._check(self.L.crthip_set_wide_lpw(self.ctx, int(lpw)), "crthip_set_wide_lpw")
 
     def set_pixel_tile(self, px):
         self._check(self.L.crthip_set_pixel_tile(self.ctx, int(px)), "crthip_set_pixel_tile")

@@ -35,8 +35,11 @@ static int decoder_min_tier(const crthip_ctx *c, const crthip_params *p)
 }
 
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
-                   const crthip_line *d_lines, void *d_out, size_t ostride)
+                   const crthip_line *d_lines, void *d_out, size_t ostride, size_t fstride)
 {
+    /* fstride: bytes between the fields of d_inp -- the flat layout's (0) or the padded one's of the fused path (crt_dev.h, sig_layout);
+     * crthip_line.pos is an offset into the field either way, the kernels do not know the difference */
+    if (!fstride) fstride = c->fstride;
     if (p->dx <= 0)     /* more than 4096 output pixels per sample: the resampler's step (crt_core.c:528) rounds to 0 */
         return set_err(c, CRTHIP_E_ARG, "outw too large for the 12-bit resampler (dx == 0)", hipSuccess);
     /* kernel shape (crthip_set_shape): the FIR build only exists in the lane-per-scanline shape; a bloom build has a
@@ -59,8 +62,8 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
     const bool wide_px = c->px_tile ? c->px_tile >= 32 : p->outw >= 1280;
     const bool rows_shape = !p->eq_kernel && (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS &&
                             !(n >= WIDE_SHAPE_MIN_FIELDS && !p->bloom && crt_decode_wide_ok(c, p, decoder_min_tier(c, p), wide_px))));
-    if (rows_shape) return crt_run_decode_rows(c, p, n, d_inp, d_lines, d_out, ostride);
-    if (p->bloom) return crt_run_decode_bloom_lanes(c, p, n, d_inp, d_lines, d_out, ostride, decoder_min_tier(c, p));
+    if (rows_shape) return crt_run_decode_rows(c, p, n, d_inp, d_lines, d_out, ostride, fstride);
+    if (p->bloom) return crt_run_decode_bloom_lanes(c, p, n, d_inp, d_lines, d_out, ostride, decoder_min_tier(c, p), fstride);
     /* FIR build: the filters only add, their outputs stay inside the hull of the inputs, so the 24-bit envelope
      * of tier 2 carries over (tier 4); beyond it the exact instantiation (tier 5) */
     const int min_tier = p->eq_kernel ? (decoder_min_tier(c, p) == 3 ? 5 : 4) : decoder_min_tier(c, p);
@@ -73,18 +76,19 @@ int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed ch
         using S = decltype(tag);
         {
         const int total = n * S::LINES;
-        const dim3 grid((total + 63) / 64), block(64);
+        const block_order bo = make_block_order((total + 63) / 64, c->dec_order_env == -1 ? n : c->dec_order_env);
+        const dim3 grid(bo.grid), block(64);
         unsigned char *o = (unsigned char *) d_out;
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_DECODE(TG, B3) \
     do { if constexpr (S::CCS != 4 && TG == 2) break; /* no FIR build of the 5-sample system */ \
-         else if (wide) hipLaunchKernelGGL((k_decode<S, TG, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); \
-         else hipLaunchKernelGGL((k_decode<S, TG, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr); } while (0)
+         else if (wide) hipLaunchKernelGGL((k_decode<S, TG, B3, 32>), grid, block, 0, c->stream, *p, n, d_inp, fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr, bo.K, bo.per); \
+         else hipLaunchKernelGGL((k_decode<S, TG, B3, 16>), grid, block, 0, c->stream, *p, n, d_inp, fstride, d_lines, o, ostride, min_tier, rank, (const int *) nullptr, bo.K, bo.per); } while (0)
             /* wide pictures in tiers 0 / 1: the 16-scanlines-per-wave kernel with 1 KB row runs (crt_decode4.hip); the groups
              * of the higher tiers stay with k_decode below */
             if (use_wide) {
-                const int rc = crt_run_decode_wide(c, p, n, d_inp, d_lines, d_out, ostride, min_tier, rank);
+                const int rc = crt_run_decode_wide(c, p, n, d_inp, d_lines, d_out, ostride, min_tier, rank, fstride);
                 if (rc) return rc;
                 CRTHIP_LAUNCH_DECODE(1, false);
                 continue;

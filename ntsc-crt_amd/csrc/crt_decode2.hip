@@ -272,7 +272,7 @@ k_decode_row(const crthip_params P, int n_fields, const signed char *__restrict_
 
 /* Launch the scanline-parallel decoder: both instantiations (groups of 4 scanlines pick theirs), one pass per rank. */
 int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
-                        const crthip_line *d_lines, void *d_out, size_t ostride)
+                        const crthip_line *d_lines, void *d_out, size_t ostride, size_t fstride)
 {
     if (p->eq_kernel)
         return set_err(c, CRTHIP_E_ARG, "the FIR decoder (USE_CONVOLUTION build) has no scanline-parallel kernel", hipSuccess);
@@ -299,8 +299,8 @@ int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const sign
         ProfScope ps(c, CRTHIP_K_DECODE);
         for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_ROWS_T(B3, TSV) \
-    do { if (narrow_ok) hipLaunchKernelGGL((k_decode_row<S, true, B3, TSV>), dim3((total + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, 0); \
-         hipLaunchKernelGGL((k_decode_row<S, false, B3, TSV>), dim3((total + 1) / 2), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, rank, narrow_ok ? 0 : 1); } while (0)
+    do { if (narrow_ok) hipLaunchKernelGGL((k_decode_row<S, true, B3, TSV>), dim3((total + 3) / 4), dim3(64), 0, c->stream, *p, n, d_inp, fstride, d_lines, o, ostride, rank, 0); \
+         hipLaunchKernelGGL((k_decode_row<S, false, B3, TSV>), dim3((total + 1) / 2), dim3(64), 0, c->stream, *p, n, d_inp, fstride, d_lines, o, ostride, rank, narrow_ok ? 0 : 1); } while (0)
             /* tile of 16 samples: 9 KB of LDS per wave instead of 14 (4 waves per SIMD instead of 2.75) but twice the
              * per-tile overheads: better once the launch has a few waves per SIMD (measured: batch 64
              * -22 %, batch 16 and batch 1 +10 %, profiles/r02_shape_sweep.txt); CRTHIP_ROW_TILE=16|32 overrides */

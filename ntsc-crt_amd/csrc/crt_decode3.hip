@@ -119,7 +119,7 @@ int crt_reserve_bloom(crthip_ctx *c, int n)
 }
 
 int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
-                               const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier)
+                               const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier, size_t fstride)
 {
     const int total = n * c->sd.lines;
     const size_t slots = bloom_slots(c, n);
@@ -151,8 +151,8 @@ int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, con
             unsigned char *o = (unsigned char *) d_out;
             for (int rank = 0; rank < passes; rank++) {
 #define CRTHIP_LAUNCH_BLOOM(TG, B3) \
-    do { if (wide) hipLaunchKernelGGL((k_decode<S, TG, B3, 32, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm); \
-         else hipLaunchKernelGGL((k_decode<S, TG, B3, 16, true>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm); } while (0)
+    do { if (wide) hipLaunchKernelGGL((k_decode<S, TG, B3, 32, true>), grid, block, 0, c->stream, *p, n, d_inp, fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm, 0, 0); \
+         else hipLaunchKernelGGL((k_decode<S, TG, B3, 16, true>), grid, block, 0, c->stream, *p, n, d_inp, fstride, d_lines, o, ostride, min_tier, rank, (const int *) perm, 0, 0); } while (0)
                 /* tier groups as in crt_run_decode: 0 = tiers 0 / 1 (tier 1 only ever holds lines of the 5-sample system here), 1 = 2 / 3 */
                 if (p->out_bpp == 3) {
                     if (min_tier <= 1) CRTHIP_LAUNCH_BLOOM(0, true);

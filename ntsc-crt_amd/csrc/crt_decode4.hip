@@ -57,7 +57,7 @@ template <class S, int LPW>
 __global__ void __launch_bounds__(64)
 k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
               const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
-              int want_rank, int n_px, unsigned ppos_end)
+              int want_rank, int n_px, unsigned ppos_end, int order_k, int order_per)
 {
     static_assert(S::CCS == 4, "tiers 0 / 1 of the 4-samples-per-cycle systems");
     static_assert(LPW == 16 || LPW == 8, "scanlines per wave");
@@ -75,6 +75,11 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
     unsigned *const s_in = (unsigned *) (s_mem + OFF_IN);
 
     const int lane = threadIdx.x, l = lane >> 2, c = lane & 3; /* my scanline of the wave, my cascade */
+    /* which LPW scanlines: crt_dev.h, block_item (field-interleaved by default: the waves resident together then write rows of
+     * different pictures -- 1080p x 2048: 2.70 -> 2.35 ms, profiles/r06_1080p_placement.txt) */
+    static_assert(S::LINES % LPW == 0, "scanline groups do not straddle fields");
+    const int bid = block_item(blockIdx.x, order_k, order_per);
+    if (bid * LPW >= n_fields * S::LINES) return;
     const bool has_line = l < LPW;                             /* (LPW 8: the upper half-wave has no scanline of its own; it emits pixels) */
     const int total = n_fields * S::LINES;
     int tier;
@@ -82,7 +87,7 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
         /* the tier of the 64-scanline group my scanlines belong to: the decision of k_decode, flag for flag; tiers 0 and 1 are
          * both decoded here (they differ in ONE instruction of the filter stage, chosen per wave), the groups of tiers 2 / 3 are
          * k_decode's */
-        const int g = (int) (blockIdx.x * LPW) / 64 * 64 + lane;
+        const int g = (bid * LPW) / 64 * 64 + lane;
         int fl = 0;
         if (g < total) fl = lines[g].nrows;
         tier = __ballot(fl & CRTHIP_LINE_EXACT) ? 3 : __ballot(fl & CRTHIP_LINE_NOT64) ? 2 : __ballot(fl & CRTHIP_LINE_WIDE) ? 1 : 0;
@@ -90,7 +95,7 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
         if (tier < min_tier) tier = min_tier;
         if (tier > 1) return;
     }
-    const int gl = blockIdx.x * LPW + l;
+    const int gl = bid * LPW + l;
     const bool live = has_line && gl < total;
     crthip_line lp;
     lp.pos = 0; lp.wave0 = 0; lp.wave1 = 0; lp.beg = 0; lp.nrows = 0; lp.hsync = 0; lp.dx = 0; lp.scanl = 0;
@@ -258,7 +263,7 @@ bool crt_decode_wide_ok(const crthip_ctx *c, const crthip_params *p, int min_tie
 }
 
 int crt_run_decode_wide(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, const crthip_line *d_lines,
-                        void *d_out, size_t ostride, int min_tier, int rank)
+                        void *d_out, size_t ostride, int min_tier, int rank, size_t fstride)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
@@ -267,18 +272,22 @@ int crt_run_decode_wide(crthip_ctx *c, const crthip_params *p, int n, const sign
             /* 8 scanlines per wave while 16 would leave SIMDs without a wave of their own twice over (see the kernel);
              * CRTHIP_WIDE_LPW=8|16 pins it (A/B) */
             const int lpw = c->wide_lpw_env ? c->wide_lpw_env : (total / WIDE_LPW < WIDE_LPW8_MAX_WAVES ? 8 : 16);
-            const dim3 grid((total + lpw - 1) / lpw), block(64);
+            const dim3 block(64);
             /* pixels the reference emits per scanline: px * dx < min(dx * outw, (AV_LEN - 1) << 12)  (crt_core.c:528-531, 555) */
             const unsigned long long all = (unsigned long long) (unsigned) p->dx * (unsigned) p->outw;
             const unsigned scan_r = (unsigned) (S::AV_LEN - 1) << 12;
             const unsigned ppos_end = all < scan_r ? (unsigned) all : scan_r;
             const int n_px = (int) ((ppos_end + (unsigned) p->dx - 1) / (unsigned) p->dx);
+            /* workgroup order: one stride per field unless CRTHIP_WIDE_ORDER says otherwise (1 = in order, K = that many strides) */
+            const int nblk = (total + lpw - 1) / lpw;
+            const block_order bo = make_block_order(nblk, c->wide_order_env == 0 || c->wide_order_env == -1 ? n : c->wide_order_env);
+            const dim3 ogrid(bo.grid);
             if (lpw == 8)
-                hipLaunchKernelGGL((k_decode_wide<S, 8>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
-                                   min_tier, rank, n_px, ppos_end);
+                hipLaunchKernelGGL((k_decode_wide<S, 8>), ogrid, block, 0, c->stream, *p, n, d_inp, fstride, d_lines, (unsigned char *) d_out, ostride,
+                                   min_tier, rank, n_px, ppos_end, bo.K, bo.per);
             else
-                hipLaunchKernelGGL((k_decode_wide<S, 16>), grid, block, 0, c->stream, *p, n, d_inp, c->fstride, d_lines, (unsigned char *) d_out, ostride,
-                                   min_tier, rank, n_px, ppos_end);
+                hipLaunchKernelGGL((k_decode_wide<S, 16>), ogrid, block, 0, c->stream, *p, n, d_inp, fstride, d_lines, (unsigned char *) d_out, ostride,
+                                   min_tier, rank, n_px, ppos_end, bo.K, bo.per);
         }
         return CRTHIP_OK;
     });

@@ -216,7 +216,7 @@ template <class S, int TG, bool BPP3, int PXT, bool BLOOM = false>
 __global__ void __launch_bounds__(64)
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
-         int want_rank, const int *__restrict__ perm)
+         int want_rank, const int *__restrict__ perm, int order_k, int order_per)
 {
     constexpr int TLO = 2 * TG;
     constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
@@ -227,7 +227,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     __shared__ int s_nrows[64];
 
     const int lane = threadIdx.x;
-    int gid = blockIdx.x * 64 + lane;
+    int gid = block_item(blockIdx.x, order_k, order_per) * 64 + lane;     /* workgroup order: crt_dev.h */
     if (BLOOM) gid = perm[gid];
     const bool live = BLOOM ? gid >= 0 : gid < n_fields * S::LINES;
     crthip_line lp;

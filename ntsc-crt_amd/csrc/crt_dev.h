@@ -58,7 +58,6 @@ struct SysCommon {
     static constexpr int VS_LO = 4, VS_HI = 6;          /* crt_ntsc.c:217 */
     static constexpr bool VS_BY_FIELD = true;
     static constexpr int CCF_SHIFT = 0;                 /* ccf preset row = (line + CCF_SHIFT) % VPER */
-    static constexpr int SYNC_WIN = 256;                /* (bytes of a line's parked sync/burst window in round 1's 16-lanes-per-field kernel; unused since round 5) */
 };
 template <int CC_LINE>
 struct RgbTiming : SysCommon {   /* crt_ntsc.h:25-109 / crt_ntscvhs.h / crt_template.h */
@@ -143,14 +142,13 @@ struct SysPV1K : SysCommon {
     static constexpr int EQU_A_HI = -1;                 /* crt_pv1k.c:197: only lines 7..9 */
     static constexpr int VS_LO = 258, VS_HI = 260;      /* crt_pv1k.c:204 */
     static constexpr int CCF_SHIFT = 3;
-    static constexpr int SYNC_WIN = 512;                /* the burst ends 266 samples into the line */
 };
 
 static_assert(SysNTSC::HRES == 910 && SysNTSC::AV_BEG == 156 && SysNTSC::AV_LEN == 753 &&
               SysNTSC::SYNC_BEG == 21 && SysNTSC::CB_BEG == 97, "NTSC timing (SURVEY.md section 8)");
 static_assert(SysNES2::HRES == 909 && SysNES2::AV_LEN == 682 && SysNES0::HRES == 912 &&
               SysNES0::AV_LEN == 684, "NES timing (SURVEY.md section 8)");
-static_assert(SysPV1K::HRES == 1920 && SysPV1K::CB_BEG + SysPV1K::CB_LEN + 48 <= SysPV1K::SYNC_WIN, "PV-1000 timing");
+static_assert(SysPV1K::HRES == 1920 && SysPV1K::AV_LEN == 1487, "PV-1000 timing");
 
 /* carrier-table row of analog line n of a field (crthip_params.burst / modI / modQ):
  * line class + dot_crawl_offset (kept unreduced inside 0..CRTHIP_DCO_MAX, else reduced mod VPER), or the
@@ -164,6 +162,43 @@ template <class S> __device__ __forceinline__ int carrier_row(int n, int field, 
     } else {
         return (field & 1) == (frame & 1);
     }
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* (r6) The fused path's own signal layout.  The reference addresses analog[] / inp[] FLAT: line n starts at n * HRES (910:   */
+/* no line of a field starts on a cache line, and the encoder's 753-byte row stores straddle the memory's sectors at both     */
+/* ends -- a third of k_active's time, profiles/r05_experiments.txt section 1).  That layout is a property of `struct CRT`,   */
+/* i.e. of the stage-level entry points and the drop-in mirrors; the signal crthip_fieldpass keeps in its own workspace       */
+/* between its encoder and its decoder is nobody's business, and lives in PADDED lines:                                        */
+/*     sample (line n, column c) of the field  ->  shift + n * PITCH + c            PITCH = 1024 (1920-sample lines: 2048)    */
+/*     and the first `padv` samples of line n + 1 a SECOND time behind line n (columns HRES .. HRES + padv)                   */
+/* `shift` puts the active rows on 128-byte boundaries.  Because of the copies, every window of the flat signal that starts in */
+/* line n at column c and is no longer than HRES + padv - c bytes is contiguous here too, at shift + n * PITCH + c -- that is   */
+/* every sync / burst window (80 / 48 bytes) wherever it starts, and every decoder window (DECWIN bytes from crthip_line.pos)  */
+/* unless the line's hsync is far from lock (xpos > HRES + padv - DECWIN: hsync beyond about +88 for NTSC).  Those few lines   */
+/* are copied by the sync kernel into a scratch row of their own behind the field (lines VRES + 1 ...), and their table entry  */
+/* points there: the decoders never know.  Line VRES holds the mirrored struct tail (CRTHIP_TAIL) like the flat layout does.   */
+/* ------------------------------------------------------------------------------------------------------------ */
+template <class S> struct PadGeom {
+    static constexpr int PITCH = (S::HRES + 64 + 127) / 128 * 128;
+    static constexpr int PADW = PITCH - S::HRES;                       /* bytes behind a line (114 for NTSC) */
+    static constexpr int DECWIN = (((S::AV_LEN + 3) / 4 + 15) / 16) * 64;   /* bytes every decoder shape reads from crthip_line.pos at most */
+    static constexpr int SCR_LINE0 = S::VRES + 1;                      /* first scratch row (one per decoded line) */
+    static constexpr size_t FSTRIDE = (size_t) (S::VRES + 1 + S::LINES) * PITCH;
+    static_assert(DECWIN + 16 <= PITCH && PADW >= 96, "a decoder window fits a scratch row; the pad holds the sync windows");
+};
+/* what the host decides per field-pass (crt_fused_layout, crt_host.hip) */
+struct sig_layout {
+    int pitch;        /* bytes between line starts: HRES = the reference's flat layout, PadGeom::PITCH = padded */
+    int shift;        /* padded: bytes in front of line 0 */
+    int padv;         /* padded: valid copy bytes behind every line */
+    int wrap;         /* samples of an active row beyond its line's end: xo + destw - HRES, >= 0 */
+    size_t fstride;   /* bytes between fields */
+};
+/* offset of flat sample index `flat` (>= 0) in a padded field, without the shift */
+template <class S> __device__ __forceinline__ int sig_phys(int flat)
+{
+    return flat + (int) ((unsigned) flat / (unsigned) S::HRES) * PadGeom<S>::PADW;
 }
 
 #define CRTHIP_LINE_EXACT 0x40000000      /* bit in crthip_line.nrows: outside the 24-bit envelope */
@@ -396,6 +431,26 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
 #define WIDE_LPW8_MAX_WAVES 1440           /* k_decode_wide: 8 scanlines per wave while 16 per wave would make fewer waves than this (1080p: < 96 fields; measured: 32 fields -10 %, 64 -4 %, 128 +4 %) */
 #define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
 
+/* (r6) Workgroup order.  Workgroup b of a launch takes work item block_item(b): itself (K = 0: consecutive workgroups -- which
+ * the dispatcher deals round robin over the 8 XCDs and which are resident together -- work on neighbouring scanlines of the same
+ * pictures), or the launch's `total` items dealt out in K strides of per = ceil(total / K): consecutive workgroups are then `per`
+ * items apart, i.e. with K = the batch's fields on the SAME scanline group of consecutive pictures.  grid = K * per; items beyond
+ * `total` leave at once.  Measured: profiles/r06_1080p_placement.txt, r06_block_order.txt */
+__device__ __forceinline__ int block_item(unsigned b, int K, int per)
+{
+    return K ? (int) (b % (unsigned) K) * per + (int) (b / (unsigned) K) : (int) b;
+}
+struct block_order { int K, per; unsigned grid; };
+static inline block_order make_block_order(int total, int K)
+{
+    block_order o;
+    if (K <= 1 || K >= total) K = 0;
+    o.K = K;
+    o.per = K ? (total + K - 1) / K : 0;
+    o.grid = K ? (unsigned) K * (unsigned) o.per : (unsigned) total;
+    return o;
+}
+
 #define CRTHIP_MAX_CHUNKS 64               /* crthip_set_overlap */
 
 /* sizes shared between kernels and the context */
@@ -439,7 +494,8 @@ struct crthip_ctx {
     signed char *d_skel;        /* SKEL_VARIANTS clean skeleton fields (cached: the burst table they were built from) */
     signed char *d_skel_alt, *d_nes_tab_alt;   /* second set: where the tables are built when the context's stream is being captured */
     hipStream_t table_stream;   /* ... and the (never captured) stream they are built on then; created on first use */
-    bool tables_captured;       /* a captured graph may be reading the current table set: it is never written again (crt_run_encoder_prepare) */
+    bool skel_captured, nes_captured;   /* a captured graph may be reading the current skeleton set / NES table: that buffer is never written again
+                                           (crt_run_encoder_prepare; tracked per table -- they are rebuilt independently of each other) */
     unsigned table_gen;         /* incremented by every table rebuild (crthip_table_generation) */
     signed char *retired[CRTHIP_MAX_RETIRED];   /* table sets that graphs may still read: freed by crthip_destroy */
     int n_retired;
@@ -468,6 +524,12 @@ struct crthip_ctx {
     int ac_tile;                /* encoder tile, same convention, by input width */
     int ac_tile_env;            /* CRTHIP_AC_TILE: overrides both (A/B measurements) */
     int wide_lpw_env;           /* CRTHIP_WIDE_LPW = 8 | 16: pins k_decode_wide's scanlines per wave (A/B measurements); 0 = by batch size */
+    int sig_pad;                /* CRTHIP_SIG_PAD / crthip_set_signal_layout: 1 (default) = the fused path keeps its signal in padded lines, 0 = flat */
+    size_t fstride_pad;         /* PadGeom::FSTRIDE of the context's system: d_inp is sized for it */
+    sig_layout last_lay;        /* the layout of d_inp's current contents (crthip_fieldpass_signal) */
+    int last_n;
+    int wide_order_env, dec_order_env, act_order_env;   /* CRTHIP_WIDE_ORDER / _DEC_ORDER / _ACT_ORDER: workgroup order of k_decode_wide / k_decode / k_active
+                                                           (block_item above): 0 = the default, K > 1 = that many strides, -1 = one stride per field, 1 = in order */
     int sig_tile_env;           /* CRTHIP_SIG_TILE = 16 | 32 | 64: pins k_active's small / large signal tile (A/B measurements); 0 = by batch size */
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
@@ -579,7 +641,9 @@ static inline int crt_ensure_aux(crthip_ctx *c)
 
 /* launch entry points of the other translation units (enqueue on c->stream; no synchronisation) */
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                    signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state);
+                    signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state, const sig_layout *lay = nullptr);
+bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, sig_layout *lay);
+int crt_run_unpad(crthip_ctx *c, int n, const sig_layout *lay, const signed char *d_src, signed char *d_dst);
 int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state);
 int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused);
 int crt_run_noise(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_analog, signed char *d_inp,
@@ -588,16 +652,16 @@ int crt_run_advance_rn(crthip_ctx *c, int n, crthip_state *d_state);
 int crt_run_vhs_chain(crthip_ctx *c, int n, crthip_state *d_state, int draw_aberration);
 int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthip_state *d_state);
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
-                 crthip_line *d_lines, int advance_rn, int preset_ccf = 0);
+                 crthip_line *d_lines, int advance_rn, int preset_ccf = 0, const sig_layout *lay = nullptr);
 int crt_run_decode(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
-                   const crthip_line *d_lines, void *d_out, size_t ostride);
+                   const crthip_line *d_lines, void *d_out, size_t ostride, size_t fstride = 0);   /* fstride 0: the flat layout's */
 bool crt_decode_wide_ok(const crthip_ctx *c, const crthip_params *p, int min_tier, bool wide);
 int crt_run_decode_wide(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, const crthip_line *d_lines,
-                        void *d_out, size_t ostride, int min_tier, int rank);
+                        void *d_out, size_t ostride, int min_tier, int rank, size_t fstride);
 int crt_reserve_bloom(crthip_ctx *c, int n);
 int crt_run_decode_bloom_lanes(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
-                               const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier);
+                               const crthip_line *d_lines, void *d_out, size_t ostride, int min_tier, size_t fstride);
 int crt_run_decode_rows(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp,
-                        const crthip_line *d_lines, void *d_out, size_t ostride);
+                        const crthip_line *d_lines, void *d_out, size_t ostride, size_t fstride);
 
 #endif /* CRT_DEV_H */

@@ -339,7 +339,7 @@ template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT, int OT 
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
-         const uint2 *__restrict__ jump16)
+         const uint2 *__restrict__ jump16, int order_k, int order_per)
 {
     using T = RowTiles<ACT, OT>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
@@ -348,7 +348,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     __shared__ unsigned long long s_src[64], s_dst[64];
 
     const int lane = threadIdx.x;
-    const int gid = blockIdx.x * 64 + lane;
+    const int gid = block_item(blockIdx.x, order_k, order_per) * 64 + lane;     /* workgroup order: crt_dev.h */
     const int rows = P.desth;
     const bool live = gid < n_fields * rows;
     const int f = live ? gid / rows : 0;
@@ -1001,9 +1001,9 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
         }
     }
     const bool in4 = S::IS_NES || (p->in_bpp == 4 && p->w >= 4);
+    const block_order bo = make_block_order((int) grid.x, c->act_order_env == -1 ? n : c->act_order_env);
+    const dim3 ogrid(bo.grid);
     const bool wide_in = c->ac_tile_env ? c->ac_tile_env == 32 : c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
-    /* signal pieces of 256 bytes where the batch keeps the chip full at the 6-7 waves per CU their tile leaves (fused throughput
-     * path, 4-byte pixels, fast envelope); CRTHIP_SIG_TILE=16|64 pins the choice (A/B) */
     /* Larger signal pieces where the batch keeps the chip full at the lower occupancy their tile leaves (fused throughput path,
      * 4-byte pixels, fast envelope): 256-byte pieces beside the wide image tile (26 KB of LDS, 6 waves per CU), 128-byte pieces
      * beside the narrow one (12.7 KB, 12 waves per CU).  Measured per batch size and system in profiles/r05_experiments.txt
@@ -1015,16 +1015,16 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
                                          : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
         if (in4 && big) {
 #define CRTHIP_LAUNCH_ACTIVE_BIG(NZ) \
-    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
-         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); \
+         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); } while (0)
             if (noise) CRTHIP_LAUNCH_ACTIVE_BIG(true); else CRTHIP_LAUNCH_ACTIVE_BIG(false);
 #undef CRTHIP_LAUNCH_ACTIVE_BIG
             return;
         }
     }
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
-    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); \
-         else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16); } while (0)
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); \
+         else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); } while (0)
     if (noise) { if (in4) CRTHIP_LAUNCH_ACTIVE(true, true); else CRTHIP_LAUNCH_ACTIVE(true, false); }
     else       { if (in4) CRTHIP_LAUNCH_ACTIVE(false, true); else CRTHIP_LAUNCH_ACTIVE(false, false); }
 #undef CRTHIP_LAUNCH_ACTIVE
@@ -1154,10 +1154,13 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { (void) hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         const bool capturing = cap == hipStreamCaptureStatusActive;
-        if (!need_skel && !need_nes) {
-            if (capturing) c->tables_captured = true;          /* the graph being recorded reads the current set */
-            return CRTHIP_OK;
+        if (capturing) {
+            /* the graph being recorded reads the current buffer of every table that is NOT rebuilt below (a rebuilt one gets a fresh
+             * buffer and its own flag there) */
+            if (!need_skel) c->skel_captured = true;
+            if (!need_nes) c->nes_captured = true;
         }
+        if (!need_skel && !need_nes) return CRTHIP_OK;
         hipStream_t st = c->stream;
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
         if (capturing) {
@@ -1169,11 +1172,11 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
             }
             st = c->table_stream;
         }
-        const bool fresh = capturing || c->tables_captured;
+        /* per table: a buffer a graph may read (or, under capture, that kernels enqueued before may still be reading) is not written */
         int rc = CRTHIP_OK;
         if (need_skel) {
             constexpr int SK_LANES = SKEL_VARIANTS * ((S::INPUT_SIZE + 15) / 16);
-            signed char *dst = table_target(c, &c->d_skel, &c->d_skel_alt, (size_t) SKEL_VARIANTS * c->fstride, fresh);
+            signed char *dst = table_target(c, &c->d_skel, &c->d_skel_alt, (size_t) SKEL_VARIANTS * c->fstride, capturing || c->skel_captured);
             if (!dst) rc = set_err(c, CRTHIP_E_NOMEM, "hipMalloc skeleton tables", hipSuccess);
             else {
                 if (!capturing) {
@@ -1186,11 +1189,12 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
                 c->skel_yo = p->yo;
                 memcpy(c->skel_border, border_key, sizeof(border_key));
                 c->skel_valid = true;
+                c->skel_captured = capturing;                  /* the new buffer: referenced iff this very call is being recorded */
             }
         }
         if constexpr (S::IS_NES) {
             if (need_nes && rc == CRTHIP_OK) {
-                signed char *dst = table_target(c, &c->d_nes_tab, &c->d_nes_tab_alt, NES_TAB_SIZE, fresh);
+                signed char *dst = table_target(c, &c->d_nes_tab, &c->d_nes_tab_alt, NES_TAB_SIZE, capturing || c->nes_captured);
                 if (!dst) rc = set_err(c, CRTHIP_E_NOMEM, "hipMalloc NES sample table", hipSuccess);
                 else {
                     if (!capturing) {
@@ -1202,11 +1206,11 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
                     c->nes_tab_black = p->black_point;
                     c->nes_tab_white = p->white_point;
                     c->nes_tab_valid = true;
+                    c->nes_captured = capturing;
                 }
             }
         }
         c->table_gen++;
-        c->tables_captured = capturing;                        /* the new set: referenced iff this very call is being recorded */
         if (capturing) {
             const hipError_t e = hipStreamSynchronize(st);
             (void) hipThreadExchangeStreamCaptureMode(&mode);
@@ -1218,7 +1222,7 @@ int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused)
 }
 
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                    signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state)
+                    signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state, const sig_layout *lay)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);

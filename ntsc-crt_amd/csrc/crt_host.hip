@@ -191,6 +191,9 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     { const char *e = getenv("CRTHIP_WIDE_DECODE"); c->wide_decode = e ? atoi(e) != 0 : 1; }     /* A/B switch, crt_decode4.hip */
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     { const char *e = getenv("CRTHIP_WIDE_LPW"); c->wide_lpw_env = e && (atoi(e) == 8 || atoi(e) == 16) ? atoi(e) : 0; }   /* A/B switch, k_decode_wide */
+    { const char *e = getenv("CRTHIP_WIDE_ORDER"); c->wide_order_env = e ? atoi(e) : 0; }   /* A/B switches: workgroup order (crt_dev.h, block_item) */
+    { const char *e = getenv("CRTHIP_DEC_ORDER"); c->dec_order_env = e ? atoi(e) : 0; }
+    { const char *e = getenv("CRTHIP_ACT_ORDER"); c->act_order_env = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_SIG_TILE"); c->sig_tile_env = e && (atoi(e) == 16 || atoi(e) == 32 || atoi(e) == 64) ? atoi(e) : 0; }   /* A/B switch, k_active */
     c->own_stream = false;
     /* noise LCG jump tables: state after 16*q steps, q = 0 .. INPUT_SIZE/16 */
@@ -586,6 +589,13 @@ int crthip_set_signal_tile(crthip_ctx *c, int dwords)
 {
     if (!c || (dwords != 0 && dwords != 16 && dwords != 32 && dwords != 64)) return CRTHIP_E_ARG;
     c->sig_tile_env = dwords;
+    return CRTHIP_OK;
+}
+
+int crthip_set_wide_lpw(crthip_ctx *c, int lpw)
+{
+    if (!c || (lpw != 0 && lpw != 8 && lpw != 16)) return CRTHIP_E_ARG;
+    c->wide_lpw_env = lpw;
     return CRTHIP_OK;
 }
 

@@ -195,9 +195,9 @@ __device__ __forceinline__ void vhs_jump_mfma(const unsigned char *s_zd, const v
     }
 }
 
-/* Parallel region.  A wave's 64 chunks are (mostly) one contiguous 15872-byte run of the field: it is moved
- * through an LDS tile of 64 x 62 dwords with coalesced 256-byte requests (lane-per-chunk byte accesses cost
- * 12x the algorithmic HBM write traffic); the lane's own dwords sit at an odd stride = conflict-free. */
+/* Parallel region.  A wave's 64 chunks (VHS_CHUNK = 124 samples each) are (mostly) one contiguous 7936-byte run of the field: it
+ * is moved through an LDS tile of 64 x 31 dwords with coalesced requests (lane-per-chunk byte accesses cost 12x the algorithmic
+ * HBM write traffic); a chunk's 31 dwords are an odd stride already: the lane-per-chunk accesses are conflict-free. */
 template <class S, bool MFMA>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_vhs_noise(const crthip_params P, int n_fields, const signed char *__restrict__ analog,

@@ -231,7 +231,10 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             /* what crt_modulate leaves in ccf (k_encoder_state, crt_encode.hip): entry [(cls + CCF_SHIFT) % VPER][p] = the burst
              * level of line class cls at carrier phase p, << 7; the systems without line classes preset row 0 from class 0 */
             const int cls = S::LINE_ROWS ? (my_r + S::VPER - S::CCF_SHIFT % S::VPER) % S::VPER : 0;
-            const int row = carrier_row<S>(cls, st_chain->field, st_chain->frame, st_chain->aux);
+            /* field / frame are read here while lane 0 of the field's own wave may be masking them in place (above): harmless ONLY
+             * because carrier_row looks at bit 0 of each (or, with LINE_ROWS, at neither) -- masked locally so that this stays true
+             * whatever carrier_row becomes */
+            const int row = carrier_row<S>(cls, st_chain->field & 1, st_chain->frame & 1, st_chain->aux);
             acc = ((int) (signed char) ((S::BLANK + P.burst[row][my_p] * S::BURST) >> 5)) << 7;
         }
     }
@@ -644,7 +647,7 @@ int crt_run_clean_vsync(crthip_ctx *c, int n, const signed char *d_analog, crthi
 /* the sync chain of n fields on the context's stream: vertical search, hsync fixed point, burst integrators, line table (+ the
  * bloom pass).  preset_ccf: see k_hsync_wave. */
 int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char *d_inp, crthip_state *d_state,
-                 crthip_line *d_lines, int advance_rn, int preset_ccf)
+                 crthip_line *d_lines, int advance_rn, int preset_ccf, const sig_layout *lay)
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);

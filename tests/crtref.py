@@ -128,7 +128,7 @@ def build_driver_binaries():
             exe = os.path.join(PKG_LIB, out)
             cmd = ["gcc", "-O2", "-w", "-std=c89", "-H", "-I" + inc, "-I" + ref] + defs + ["-o", exe,
                    os.path.join(tmp, drv), ref + "/ppm_rw.c", ref + "/bmp_rw.c",
-                   "-L" + PKG_LIB, "-l" + lib, "-Wl,-rpath," + PKG_LIB]
+                   "-L" + PKG_LIB, "-l" + lib, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"]   # $ORIGIN like the Makefile: the snapshot may be unpacked anywhere
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("linking %s failed: %s" % (out, r.stderr[-2000:]))
@@ -144,7 +144,7 @@ def build_dropin_probe(name):
     src = os.path.join(ROOT, "tests", "abi_probe.c")
     if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(PKG_LIB, lib))):
         subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-w", "-I" + os.path.join(ROOT, "include")] + defs +
-                       ["-o", out, src, "-L" + PKG_LIB, "-l" + lib[3:-3], "-Wl,-rpath," + PKG_LIB], check=True)
+                       ["-o", out, src, "-L" + PKG_LIB, "-l" + lib[3:-3], "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
     return out
 
 

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(L, n), n
-    assert L.crthip_abi_version() == 5
+    assert L.crthip_abi_version() == 6
 
 
 def test_node_library_exports_its_header(lib):

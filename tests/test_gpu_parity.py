@@ -82,9 +82,10 @@ CASES = [
 ]
 
 
-def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=0):
+def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=0, wide_lpw=0):
     """shape: 1 = lane-per-scanline kernels (the throughput shape; forced, because small batches would otherwise
-    pick the other one), 2 = scanline-parallel kernels, 0 = the library's own choice"""
+    pick the other one), 2 = scanline-parallel kernels, 0 = the library's own choice;  wide_lpw: 8 / 16 pins the wide-run
+    decoder's scanlines per wavefront (0: by batch size, i.e. 8 for the small batches of these tests)"""
     name, outw, outh, ofmt, w, h, ifmt, noise, skw, knobs = case
     bpp = R.bpp4fmt(ifmt)
     imgs = np.stack([R.synth_image(w, h, bpp, 777 + 13 * k, "random" if k % 2 == 0 else "bars") for k in range(n)])
@@ -95,6 +96,7 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=
     g.set_exact(exact)
     g.set_shape(shape)
     g.set_signal_tile(sig_tile)
+    g.set_wide_lpw(wide_lpw)
     for k, v in knobs.items():
         setattr(g, k, v)
     fields = [k & 1 for k in range(n)]
@@ -202,20 +204,23 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("lpw", [8, 16])
 @pytest.mark.parametrize("case", range(len(WIDE_CASES)))
-def test_wide_decoder_parity(crtlib, case):
+def test_wide_decoder_parity(crtlib, case, lpw):
     """crt_decode4.hip (round 4): 16 scanlines per wave, a scanline's four filter cascades on four lanes, pixels lane-per-pixel in
-    1 KB row runs -- fused, three steps, every field against the oracle (out, state, ccf)"""
-    _run_case(crtlib, WIDE_CASES[case], fused=True, steps=3, n=5)
+    1 KB row runs -- fused, three steps, every field against the oracle (out, state, ccf).  Both instantiations pinned
+    (crthip_set_wide_lpw): k_decode_wide<S, 16> is what the 1080p bench batches run, <S, 8> what small batches pick by themselves."""
+    _run_case(crtlib, WIDE_CASES[case], fused=True, steps=3, n=5, wide_lpw=lpw)
 
 
+@pytest.mark.parametrize("lpw", [8, 16])
 @pytest.mark.parametrize("case", [0, 1, 7])
-def test_wide_decoder_stagewise_and_tiers(crtlib, case):
+def test_wide_decoder_stagewise_and_tiers(crtlib, case, lpw):
     """... stage by stage (line table compared too), and with the decoder tiers forced: tier 1 runs in the wide kernel,
     tiers 2 / 3 hand the whole batch back to the lane-per-scanline kernel"""
-    _run_case(crtlib, WIDE_CASES[case], fused=False, steps=2, n=3)
+    _run_case(crtlib, WIDE_CASES[case], fused=False, steps=2, n=3, wide_lpw=lpw)
     for mode in (1, 2, 3):
-        _run_case(crtlib, WIDE_CASES[case], fused=True, exact=mode, steps=1, n=2)
+        _run_case(crtlib, WIDE_CASES[case], fused=True, exact=mode, steps=1, n=2, wide_lpw=lpw)
 
 
 def test_wide_decoder_against_the_lane_per_scanline_decoder(crtlib):
@@ -1069,11 +1074,13 @@ def _random_wide_case(rng):
     return tuple(case)
 
 
+@pytest.mark.parametrize("lpw", [8, 16])
 @pytest.mark.parametrize("seed", range(16))
-def test_random_wide_configurations(crtlib, seed):
-    """random wide pictures, knobs, formats and systems through the lane shape (wide-run decoder where it applies)"""
+def test_random_wide_configurations(crtlib, seed, lpw):
+    """random wide pictures, knobs, formats and systems through the lane shape (wide-run decoder where it applies), with each of
+    its two instantiations pinned"""
     rng = np.random.default_rng(7000 + seed)
-    _run_case(crtlib, _random_wide_case(rng), fused=bool(seed & 1), steps=2, n=2, shape=1)
+    _run_case(crtlib, _random_wide_case(rng), fused=bool(seed & 1), steps=2, n=2, shape=1, wide_lpw=lpw)
 
 
 @pytest.mark.parametrize("seed", range(48))
@@ -1100,10 +1107,12 @@ def test_random_configurations_bloom_lane_per_scanline(crtlib, seed):
     _run_case(crtlib, case, fused=bool(seed & 1), steps=2, n=3, shape=1)
 
 
-@pytest.mark.parametrize("name,n,w,h,noise", [("ntsc", 4096, 640, 480, 24), ("ntsc", 64, 1920, 1080, 0), ("ntscbloom", 4096, 640, 480, 24)])
+@pytest.mark.parametrize("name,n,w,h,noise", [("ntsc", 4096, 640, 480, 24), ("ntsc", 64, 1920, 1080, 0), ("ntsc", 512, 1920, 1080, 0),
+                                              ("ntscbloom", 4096, 640, 480, 24)])
 def test_full_size_batch_properties(crtlib, name, n, w, h, noise):
-    """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24) and configs[2]'s per-GPU
-    share (512 frames of 1920x1080 over 8 GPUs = 64, noise 0): (a) replication -- fields that carry the same image,
+    """BASELINE configs[1] at the bench's full batch (4096 fields of 640x480, noise 24), configs[2]'s per-GPU
+    share (512 frames of 1920x1080 over 8 GPUs = 64, noise 0) and ALL of configs[2] on one GPU (512 frames: the wide-run decoder
+    with 16 scanlines per wave and the large signal tile chosen by wave count, as in the bench's `1080p_batch512`): (a) replication -- fields that carry the same image,
     parity and state produce the same picture and state wherever they sit in the batch; (b) a checksum over all
     pictures is reproducible from run to run; (c) one field of EVERY (image, parity) class equals the oracle -- with (a) that
     covers every field of the batch."""
@@ -1270,14 +1279,78 @@ def test_a_kept_graph_keeps_its_tables(crtlib):
     g.close()
 
 
-@pytest.mark.parametrize("name,n,noise", [("ntsc", 24, 0), ("ntsc", 24, 150), ("ntsc", 520, 60), ("snes", 24, 100), ("pv1k", 12, 90),
-                                          ("nes", 24, 80), ("ntscbloom", 24, 40)])
-def test_wild_sync_states_against_the_oracle(crtlib, name, n, noise):
+def test_a_kept_nes_graph_keeps_both_of_its_tables(crtlib):
+    """a NES context caches TWO tables that are rebuilt independently -- the skeleton fields (burst table, i.e. hue)
+    and the PPU sample table (black / white point) -- and one shared "a graph reads the current set" flag let this sequence through:
+    capture graph A; an eager pass with another black point moves the sample table to a fresh buffer and clears the flag; an eager
+    pass with another hue then rebuilds the skeleton IN PLACE -- the buffer A still reads.  The flags are per table now: A, replayed
+    after both eager passes, must give what an eager pass with A's settings gives."""
+    import torch
+    n, outw, outh = 3, 640, 480
+    ppu = np.stack([R.synth_ppu(256, 240, 500 + k) for k in range(n)])
+    full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
+    full[:, :240] = torch.from_numpy(ppu.astype(np.int16)).to("cuda:0")
+
+    def settings(hue):
+        return crtlib.Settings(full[:, :240], hue=hue, dot_crawl_offset=[k % 3 for k in range(n)])
+
+    def eager_result(hue, black):
+        g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, "nes", device=0)
+        g.scanlines = 1
+        g.black_point = black
+        g.fieldpass(settings(hue), 12)
+        g.synchronize()
+        out = g.out.clone()
+        g.close()
+        return out
+    want = eager_result(0, 0)
+    assert not torch.equal(want, eager_result(90, 0)) and not torch.equal(want, eager_result(0, 6))
+    g = crtlib.CRT(n, outw, outh, crtlib.FMT_BGRA, "nes", device=0)
+    g.scanlines = 1
+    g.reserve(n)
+    side = torch.cuda.Stream()
+    g.use_stream(side)
+    s0 = settings(0)
+    g._load_field_state(s0)
+    torch.cuda.synchronize()
+    state0 = g.state.clone()
+    p0 = g.params(s0, 12)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        g.fieldpass(s0, 12, params=p0)
+    gen0 = g.table_generation()
+    for hue, black in ((0, 6), (90, 6)):                  # the sample table moves; then the skeleton is rebuilt
+        g.black_point = black
+        s = settings(hue)
+        g.state.copy_(state0)
+        torch.cuda.synchronize()
+        g.fieldpass(s, 12, params=g.params(s, 12))
+        g.synchronize()
+    assert g.table_generation() >= gen0 + 2
+    for _ in range(2):
+        g.state.copy_(state0)
+        g.out.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g.out, want), "the NES graph no longer encodes with the tables it was captured with"
+    del graph
+    g.close()
+
+
+@pytest.mark.parametrize("name,n,noise,fpb4", [("ntsc", 24, 0, 0), ("ntsc", 24, 150, 0), ("ntsc", 520, 60, 1), ("snes", 24, 100, 0), ("pv1k", 12, 90, 0),
+                                               ("nes", 24, 80, 0), ("ntscbloom", 24, 40, 0), ("ntsc", 24, 150, 1), ("snes", 24, 100, 1), ("nes", 24, 80, 1)])
+def test_wild_sync_states_against_the_oracle(crtlib, name, n, noise, fpb4):
     """Fields started from sync states far from lock -- vertical sync candidates in the middle of the picture under heavy noise,
     hsync values that put the search window or the burst window into the picture, values near the line end (windows that wrap)
-    -- next to ordinary ones, in one batch (520 fields: four fields per workgroup of the sync kernel).  Every field, three
-    consecutive field-passes, against the oracle: hsync, vsync, rn, the burst integrators the chain starts from (the ccf preset
-    of crt_modulate is applied by the sync kernel's own lanes in a fused pass, k_hsync_wave preset_ccf) and every picture byte.
+    -- next to ordinary ones, in one batch.  Every field, three consecutive field-passes, against the oracle: hsync, vsync, rn,
+    the burst integrators the chain starts from (the ccf preset of crt_modulate is applied by the sync kernel's own lanes in a
+    fused pass, k_hsync_wave preset_ccf) and every picture byte.  fpb4: the sync kernel pinned to FOUR fields per workgroup
+    (CRTHIP_SYNC_KERNEL=3, read when the context is created; batches below 768 fields take one field per workgroup by themselves)
+    -- the shape in which wave 0's chain lanes preset and integrate the other three waves' fields, for the systems with line
+    classes (snes, nes: class -> ccf row through CCF_SHIFT) as well (the PV-1000's 25 chain lanes per field do not
+    fit four fields into a wave).  Round 6: these are also the fields whose decoder windows do not fit the padded signal lines of
+    the fused path and are decoded from the per-field scratch copy (crt_sync.hip).
     (Rounds 4's speculative sync chain was tested with these inputs; the chain is gone, the inputs stayed.)"""
     import torch
     nes = name == "nes"
@@ -1298,7 +1371,18 @@ def test_wild_sync_states_against_the_oracle(crtlib, name, n, noise):
     fields = [k & 1 for k in range(n)]
     outs = {}
     for spec in (1,):      # (one pass; the dict keeps the shape the comparisons below were written for)
-        g = crtlib.CRT(n, 640, 480, crtlib.FMT_BGRA, name, device=0)
+        import os
+        saved = os.environ.get("CRTHIP_SYNC_KERNEL")
+        if fpb4:
+            os.environ["CRTHIP_SYNC_KERNEL"] = "3"
+        try:
+            g = crtlib.CRT(n, 640, 480, crtlib.FMT_BGRA, name, device=0)
+        finally:
+            if fpb4:
+                if saved is None:
+                    del os.environ["CRTHIP_SYNC_KERNEL"]
+                else:
+                    os.environ["CRTHIP_SYNC_KERNEL"] = saved
         g.scanlines = 1
         g.state[:, crtlib.ST_HSYNC] = torch.tensor(hs, dtype=torch.int32, device="cuda:0")
         g.state[:, crtlib.ST_VSYNC] = torch.tensor(vs, dtype=torch.int32, device="cuda:0")

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""is k_decode_wide's run-to-run spread at 1920x1080 a matter of where the pictures sit?
+
+Every variant is measured in FRESH processes (the spread in question is between consecutive processes on one box): the batch
+ABI's picture stride padded off the tight 8 294 400 bytes (the picture inside a field stays tight, so parity and the algorithmic
+bytes are untouched), and the decoder's workgroups field-interleaved (CRTHIP_WIDE_ORDER=-1, since this measurement the default; 1 = in order) so that the waves resident together
+write rows of different pictures.  Per process: 1920x1080 x 2048, noise 0, one batch in flight, 3 warm-up + 10 timed field-passes
+with an event pair around every launch (crthip_profile_enable); printed: the decoder's and the encoder's mean launch duration
+and the field-pass on the host clock.
+
+    python tools/placement_sweep.py [--procs 5] [--batch 2048] > profiles/r06_1080p_placement.txt
+    python tools/placement_sweep.py --child PAD        (one measurement; prints one JSON line)
+"""
+import argparse
+import json
+import os
+import statistics
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ntsc-crt_amd"))
+
+
+def child(pad, batch, steps, warmup, w=1920, h=1080, noise=0):
+    import torch
+    import crtlib
+    dev = torch.device("cuda", 0)
+    tight = w * h * 4
+    stride = tight + pad
+    buf = torch.zeros(batch * stride + 4096, dtype=torch.uint8, device=dev)
+    out = buf[:batch * stride].view(batch, stride)[:, :tight].view(batch, h, w, 4)       # stride(0) = tight + pad bytes
+    g = crtlib.CRT(batch, w, h, crtlib.FMT_BGRA, "ntsc", device=0, out=out)
+    g.scanlines = 1
+    g.reserve(batch)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12345)
+    base = torch.randint(0, 256, (64, h + 1, w, 4), dtype=torch.uint8, device=dev, generator=gen)
+    images = base.repeat(batch // 64, 1, 1, 1)[:, :h]
+    s = crtlib.Settings(images, format=crtlib.FMT_BGRA, as_color=1, hue=0, field=[k & 1 for k in range(batch)], frame=0)
+    p = g.params(s, noise)
+    g._load_field_state(s)
+
+    def step(k):
+        g.fieldpass(s, noise, params=p)
+        g.state[:, crtlib.ST_FIELD] ^= 1
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    g.profile(True)
+    for k in range(steps):
+        step(k)
+    pr = g.profile_read()
+    g.profile(False)
+    rec = {"pad": pad, "order": int(os.environ.get("CRTHIP_WIDE_ORDER", "0")), "fieldpass_ms": round(wall, 4)}
+    rec["env"] = {k: v for k, v in os.environ.items() if k.startswith("CRTHIP_")}
+    for name, (ms, cnt) in pr.items():
+        rec[name + "_ms"] = round(ms / steps, 4)
+    rec["out_ptr_mod_64k"] = out.data_ptr() % 65536
+    print(json.dumps(rec))
+    g.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--child", type=int, default=None)
+    ap.add_argument("--procs", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--noise", type=int, default=0)
+    args = ap.parse_args()
+    if args.child is not None:
+        return child(args.child, args.batch, args.steps, args.warmup, args.w, args.h, args.noise)
+    # (CRTHIP_WIDE_ORDER: 1 = workgroups in order, the shipped order of rounds 4 / 5; -1 = one stride per field, round 6's default)
+    variants = [("tight (shipped)", 0, 1), ("stride + 256", 256, 1), ("stride + 1280", 1280, 1), ("stride + 4096", 4096, 1),
+                ("stride + 4352", 4352, 1), ("stride + 65792", 65792, 1), ("stride + 2 MiB + 256", 2097152 + 256, 1),
+                ("field-interleaved workgroups", 0, -1), ("field-interleaved, stride + 4352", 4352, -1)]
+    print("k_decode_wide<SysNTSC, 16> against picture placement: 1920x1080 x %d, noise 0, one batch in flight, %d fresh processes per variant,"
+          % (args.batch, args.procs))
+    print("%d timed field-passes each (tools/placement_sweep.py).  decode / active = mean launch duration (HIP events), fieldpass = host clock." % args.steps)
+    print()
+    print("%-36s | %-44s | %-7s %-7s | %-7s | %s" % ("variant", "decode ms per process", "median", "spread", "active", "fieldpass ms (median)"))
+    rows = []
+    # round robin over the variants, so that a drift of the box over the minutes hits all of them alike
+    results = {v[0]: [] for v in variants}
+    for r in range(args.procs):
+        for name, pad, order in variants:
+            env = dict(os.environ, CRTHIP_WIDE_ORDER=str(order))
+            try:
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(pad), "--batch", str(args.batch),
+                                      "--steps", str(args.steps), "--warmup", str(args.warmup)], env=env, stdout=subprocess.PIPE,
+                                     stderr=subprocess.DEVNULL, timeout=300).stdout.decode()
+                results[name].append(json.loads(out.strip().splitlines()[-1]))
+            except Exception as ex:                               # noqa: BLE001 - a line of the sweep may fail; say so
+                print("# %s run %d failed: %s" % (name, r, ex))
+    for name, pad, order in variants:
+        rs = results[name]
+        if not rs:
+            continue
+        dec = [x["decode_ms"] for x in rs]
+        med = statistics.median(dec)
+        spread = (max(dec) - min(dec)) / med * 100.0
+        print("%-36s | %-44s | %7.3f %6.1f%% | %7.3f | %.3f" % (name, " ".join("%.3f" % d for d in dec), med, spread,
+                                                              statistics.median(x["active_ms"] for x in rs),
+                                                              statistics.median(x["fieldpass_ms"] for x in rs)))
+        rows.append((name, med, spread))
+    print()
+    base = rows[0][1] if rows else 0.0
+    for name, med, spread in rows[1:]:
+        print("%-36s %+5.1f %% against the shipped layout's median" % (name, (med / base - 1.0) * 100.0))
+
+
+if __name__ == "__main__":
+    main()
