@@ -357,6 +357,20 @@ int  crthip_set_pixel_tile(crthip_ctx *ctx, int pixels);
  * leaves), 16 = always the 64-byte pieces, 32 or 64 = always the large ones.  Same bytes either way (tests, A/B measurements).
  * Environment: CRTHIP_SIG_TILE sets the default of new contexts. */
 int  crthip_set_signal_tile(crthip_ctx *ctx, int dwords);
+/* Signal layout of the fused path (round 6).  The reference addresses analog[] / inp[] flat: line n of a field starts at sample
+ * n * CRT_HRES (crt_ntsc.c:322, crt_core.c:438-461), and so do the stage-level entry points above and the drop-in libraries.  The
+ * signal crthip_fieldpass keeps in its own workspace between its encoder and its decoder is not visible to anybody; by default
+ * (1) it lives in PADDED lines -- 1024 bytes apart (2048 for the PV-1000's 1920-sample lines), active rows on 128-byte boundaries,
+ * the head of every line repeated behind its predecessor so that windows over a line end stay contiguous -- which is what lets the
+ * encoder store whole aligned cache lines.  0 = the flat layout there too (A/B measurements; also what geometries the padded
+ * layout does not cover fall back to: row overhangs of more than 16 samples, x offsets that put the row before column 114, the
+ * rand()-noise VHS build, CRT_DO_VSYNC 0).  Same pictures and states either way.  Environment: CRTHIP_SIG_PAD sets the default
+ * of new contexts.
+ * crthip_fieldpass_signal: the noisy signal of the first n fields of the context's LAST crthip_fieldpass, repacked into the
+ * reference's layout (n fields at crthip_field_stride() spacing: CRT_INPUT_SIZE samples + the CRTHIP_TAIL mirror), i.e. what
+ * crt_demodulate leaves in CRT.inp -- for parity tests of the fused path; *padded (optional) tells which layout it came from. */
+int  crthip_set_signal_layout(crthip_ctx *ctx, int padded);
+int  crthip_fieldpass_signal(crthip_ctx *ctx, int n, signed char *d_inp_flat, int *padded);
 /* Wide-run decoder (wide pictures, crt_decode4.hip): scanlines per wavefront.  0 (default) = by batch size (8 below 96 fields of
  * 1920x1080, 16 from there on), 8 / 16 = always that instantiation.  Same pictures either way (tests pin each instantiation to the
  * oracle, A/B measurements).  Environment: CRTHIP_WIDE_LPW sets the default of new contexts. */

@@ -123,6 +123,8 @@ def load_library():
     L.crthip_set_shape.argtypes = [vp, ci]
     L.crthip_set_signal_tile.argtypes = [vp, ci]
     L.crthip_set_wide_lpw.argtypes = [vp, ci]
+    L.crthip_set_signal_layout.argtypes = [vp, ci]
+    L.crthip_fieldpass_signal.argtypes = [vp, ci, vp, C.POINTER(ci)]
     L.crthip_table_generation.argtypes = [vp]
     L.crthip_table_generation.restype = C.c_uint
     L.crthip_sequence.argtypes = [vp, PP, ci, vp, sz, vp, sz, vp, vp, C.POINTER(ci)]
@@ -441,6 +443,17 @@ class CRT:
     def set_signal_tile(self, dwords):
         """fieldpass(): the encoder's signal tile -- 0 by batch size (default), 16 = 64-byte store pieces, 32 / 64 = the large ones"""
         self._check(self.L.crthip_set_signal_tile(self.ctx, int(dwords)), "crthip_set_signal_tile")
+
+    def set_signal_layout(self, padded):
+        """fieldpass(): 1 (default) = the signal between encoder and decoder in padded, aligned lines; 0 = the reference's flat layout"""
+        self._check(self.L.crthip_set_signal_layout(self.ctx, int(bool(padded))), "crthip_set_signal_layout")
+
+    def fieldpass_signal(self):
+        """inp[] of the last fieldpass() in the reference's layout ([n, fstride] int8 like ``inp``) and whether it was kept padded"""
+        dst = self.torch.zeros((self.n, self.fstride), dtype=self.torch.int8, device=self.dev)
+        padded = C.c_int(0)
+        self._check(self.L.crthip_fieldpass_signal(self.ctx, self.n, C.c_void_p(dst.data_ptr()), C.byref(padded)), "crthip_fieldpass_signal")
+        return dst, bool(padded.value)
 
     def set_wide_lpw(self, lpw):
         """the wide-run decoder's scanlines per wavefront: 0 by batch size (default), 8 or 16 = always that instantiation"""

@@ -298,6 +298,19 @@ struct RowTiles {
         }
         __syncthreads();
     }
+    /* (r6) padded signal lines (crt_dev.h, sig_layout): the row was stored contiguously, its last `wrapn` samples behind the line's
+     * end -- where they are the COPY of the next line's head.  Their home, the head of the next line, is `delta` = PITCH - HRES bytes
+     * further on.  Called after the last drain (which ends with a barrier): the samples still sit in my own tile row -- groups of the
+     * row's last 16 samples are never overwritten by the (shorter) last tile. */
+    __device__ __forceinline__ void wrap_home(int destw, int wrapn, int delta)
+    {
+        const unsigned long long d = s_dst[lane];
+        if (d == 0) return;
+        for (int x = destw - wrapn; x < destw; x++) {
+            const unsigned dw = s_out[lane * OSTRIDE + ((x >> 2) & (OTILE - 1))];
+            gstore8(d + (unsigned) (x + delta), dw >> (8 * (x & 3)));
+        }
+    }
     /* after sample group g (4 samples = 1 dword per row): flush when the tile is full or the line ends */
     __device__ __forceinline__ void group_done(int g, int ngroups, int destw)
     {
@@ -339,8 +352,10 @@ template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT, int OT 
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
-         const uint2 *__restrict__ jump16, int order_k, int order_per)
+         const uint2 *__restrict__ jump16, int order_k, int order_per, int pitch, int shift, int wrapn)
 {
+    /* pitch / shift / wrapn: where a row goes -- HRES, 0, 0 = the reference's flat lines; the fused path's padded lines otherwise
+     * (crt_dev.h, sig_layout; wrapn = the row's samples that run over the end of its line) */
     using T = RowTiles<ACT, OT>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[64 * T::STRIDE];
@@ -369,7 +384,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     const int in_bpp = S::IS_NES ? 2 : P.in_bpp;
     const unsigned char *row = img + (size_t) sy * w * in_bpp;
     s_src[lane] = (unsigned long long) row;
-    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
+    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo)) : 0ull;
     __syncthreads();
     T tiles;
     tiles.init(s_pix, s_out, s_src, s_dst, lane, w * 4);
@@ -551,6 +566,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
             tiles.group_done(g, ngroups, destw);
         }
     }
+    if (wrapn > 0) tiles.wrap_home(destw, wrapn, pitch - S::HRES);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -569,7 +585,7 @@ template <class S, bool NOISE, bool CLAMP>
 __global__ void __launch_bounds__(64)
 k_active_row(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
              signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
-             const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1)
+             const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1, int pitch, int shift, int wrapn)
 {
     constexpr int R = 8, TS = 64, CCS = S::CCS;
     __shared__ int s_f[R][3][TS + 1];                    /* YIQ of the tile, then (in place) the low-passed values */
@@ -606,8 +622,8 @@ k_active_row(const crthip_params P, int n_fields, const unsigned char *__restric
         row_info(ps * 4 + c_rp, f, y, live);
         const crthip_state st = state[f];
         c_live[ps] = live;
-        c_start[ps] = (y + P.yo) * S::HRES + P.xo;
-        c_dst[ps] = (unsigned long long) (dst + (size_t) f * fstride + c_start[ps]);
+        c_start[ps] = (y + P.yo) * S::HRES + P.xo;                  /* flat sample index: the noise generator's position */
+        c_dst[ps] = (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo));   /* k_active: pitch / shift / wrapn */
         c_rn0[ps] = (unsigned) st.rn;
         const int crow = carrier_row<S>(y + P.yo, st.field, st.frame, st.aux);
 #pragma unroll
@@ -702,6 +718,11 @@ k_active_row(const crthip_params P, int n_fields, const unsigned char *__restric
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (x0 + k < destw) gstore8(d + k, (unsigned) smp[k]);
                 }
+                if (x0 + 4 > destw - wrapn) {               /* padded lines: the home of the samples behind the line's end (RowTiles::wrap_home) */
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (x0 + k >= destw - wrapn && x0 + k < destw) gstore8(d + (unsigned) (k + pitch - S::HRES), (unsigned) smp[k]);
+                }
             }
         }
         wave_lds_fence();
@@ -734,7 +755,7 @@ template <class S, bool NOISE, bool CLAMP, int ACT>
 __global__ void __launch_bounds__(64)
 k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
              signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
-             const uint2 *__restrict__ jump16, const signed char *__restrict__ tab)
+             const uint2 *__restrict__ jump16, const signed char *__restrict__ tab, int pitch, int shift, int wrapn)
 {
     using T = RowTiles<ACT>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
@@ -762,7 +783,7 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     const int ngroups = (destw + 3) >> 2;
     const int sy = source_row<S>(P, y, 0);                      /* crt_nes.c:165-168 */
     s_src[lane] = (unsigned long long) (img + (size_t) sy * w * 2);
-    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + start) : 0ull;
+    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo)) : 0ull;   /* k_active: pitch / shift / wrapn */
     __syncthreads();
     /* pixel tiles: ACT dwords = 2*ACT PPU pixels per row */
     T tiles;
@@ -794,6 +815,7 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
         tiles.put(g, pack4(smp[0], smp[1], smp[2], smp[3]));
         tiles.group_done(g, ngroups, destw);
     }
+    if (wrapn > 0) tiles.wrap_home(destw, wrapn, pitch - S::HRES);
 }
 
 /* The clean skeleton (blanking / sync / burst, 0 where crt_modulate writes nothing) of a whole field depends
@@ -955,6 +977,102 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
   }
 }
 
+
+/* (r6) The same for the fused path's PADDED signal lines (crt_dev.h, sig_layout).  Work is cut by line instead of by flat index, so
+ * that no 16-byte chunk straddles a line end (in the padded layout its two halves would be 114 bytes apart):
+ *     lines [0, yo)                          the whole line, CF = ceil(HRES / 16) chunks, the last one moved back to end with the line
+ *     lines [yo, yo + desth)                 left of the row  [a0, xo)  (CL chunks)  and right of it  [xo + destw, HRES)  (CR chunks)
+ *     lines [yo + desth, VRES)               [a0, HRES)
+ * a0 = wrap for a line whose predecessor carries an active row (the row's last `wrap` samples run into this line: k_active's), else 0.
+ * A chunk that lies inside the first PADW columns of line n >= 1 is stored a second time behind line n - 1 (the copy that makes
+ * windows over a line end contiguous); chunks that only partly do are not -- `padv` (crt_fused_layout) is what that guarantees. */
+template <class S, bool NOISE>
+__global__ void __launch_bounds__(256)
+k_margin_pad(const crthip_params P, int n_fields, signed char *__restrict__ dst, size_t fstride, int shift,
+             const crthip_state *__restrict__ state, const uint2 *__restrict__ jump16, const uint2 *__restrict__ jump1,
+             const signed char *__restrict__ skel, size_t skel_stride, int cl, int cr, unsigned act_magic, int wrap)
+{
+    using G = PadGeom<S>;
+    constexpr int CF = (S::HRES + 15) / 16;
+    const int head_chunks = P.yo * CF, act_per = cl + cr, act_chunks = P.desth * act_per;
+    const int per_field = head_chunks + act_chunks + (S::VRES - P.yo - P.desth) * CF;
+    const int q0 = blockIdx.x * 256 + threadIdx.x;
+    if (q0 >= per_field) return;
+    int line, k, lo, hi;
+    if (q0 < head_chunks) {
+        line = q0 / CF; k = q0 - line * CF; lo = 0; hi = S::HRES;
+    } else if (q0 < head_chunks + act_chunks) {
+        const int q = q0 - head_chunks;
+        const int y = act_per == 1 ? q : (int) __umulhi((unsigned) q, act_magic);       /* q / act_per (exact below 2^16) */
+        k = q - y * act_per;
+        line = P.yo + y;
+        if (k < cl) { lo = y > 0 ? wrap : 0; hi = P.xo; }
+        else { k -= cl; lo = P.xo + P.destw < S::HRES ? P.xo + P.destw : S::HRES; hi = S::HRES; }
+    } else {
+        const int q = q0 - head_chunks - act_chunks;
+        const int r = q / CF;
+        k = q - r * CF;
+        line = P.yo + P.desth + r;
+        lo = r == 0 ? wrap : 0; hi = S::HRES;
+    }
+    int col = lo + 16 * k, len = 16;
+    if (hi - lo >= 16) { if (col > hi - 16) col = hi - 16; }         /* the interval's last chunk ends with it (it overlaps its neighbour: same bytes) */
+    else { if (k > 0 || hi <= lo) return; len = hi - lo; }              /* an interval shorter than a chunk: bytes */
+    const int idx0 = line * S::HRES + col;                             /* flat sample index: skeleton and noise are functions of it */
+    const bool copy = line >= 1 && col + len <= G::PADW;
+  for (int f = blockIdx.y; f < n_fields; f += (int) gridDim.y) {
+    const crthip_state *st = state + f;
+    const int var = skeleton_variant<S>(st->field, st->frame, st->aux);
+    signed char *out = dst + (size_t) f * fstride + shift;
+    const v4i sk = load16u(skel + (size_t) var * skel_stride + idx0);
+    const int wds[4] = { sk.x, sk.y, sk.z, sk.w };
+    v4i pk;
+    if (NOISE) {
+        unsigned rn;
+        {
+            const uint2 j = jump16[idx0 >> 4], r = jump1[idx0 & 15];
+            rn = r.x * (j.x * (unsigned) st->rn + j.y) + r.y;
+        }
+        int vals[16];
+        v2u lcg_add = { LCG_ADD, 0u };
+        asm volatile("" : "+v"(lcg_add));
+        const int noise = P.noise;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            rn = lcg_step_mad64(rn, lcg_add);
+            const int v = (wds[i >> 2] << (24 - 8 * (i & 3))) >> 24;
+            vals[i] = clampi(v + (mul_lo_mad64((int) ((rn >> 16) & 0xffu) - 0x7f, noise) >> 8), -127, 127);
+        }
+        pk.x = (int) pack4(vals[0], vals[1], vals[2], vals[3]);
+        pk.y = (int) pack4(vals[4], vals[5], vals[6], vals[7]);
+        pk.z = (int) pack4(vals[8], vals[9], vals[10], vals[11]);
+        pk.w = (int) pack4(vals[12], vals[13], vals[14], vals[15]);
+    } else {
+        pk = sk;
+    }
+    signed char *home = out + line * G::PITCH + col;
+    if (len == 16) {
+        store16u(home, pk);
+        if (copy) store16u(home - G::PITCH + S::HRES, pk);
+    } else {
+        const int o4[4] = { pk.x, pk.y, pk.z, pk.w };
+        for (int i = 0; i < len; i++) {
+            const signed char b = (signed char) (o4[i >> 2] >> (8 * (i & 3)));
+            home[i] = b;
+            if (copy) home[i - G::PITCH + S::HRES] = b;
+        }
+    }
+    if (q0 == 0) {
+        /* mirror of the struct members behind inp[] (CRTHIP_TAIL): flat samples INPUT_SIZE .. + 15 = the head of line VRES, and its copy
+         * behind the last line */
+        for (int t = 0; t < 2; t++) {
+            signed char *tail = out + (t ? S::VRES * G::PITCH : (S::VRES - 1) * G::PITCH + S::HRES);
+            store4u(tail + 0, P.outw); store4u(tail + 4, P.outh); store4u(tail + 8, P.out_format); store4u(tail + 12, 0);
+        }
+    }
+  }
+}
+
 template <class S>
 static bool encoder_fast_ok(const crthip_params *p)
 {
@@ -973,8 +1091,9 @@ static bool encoder_fast_ok(const crthip_params *p)
 
 template <class S, bool FULL, bool FAST>
 static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                          signed char *dst, const crthip_state *d_state)
+                          signed char *dst, const crthip_state *d_state, const sig_layout &lay)
 {
+    const int wrapn = lay.pitch != S::HRES ? lay.wrap : 0;      /* flat lines: a row that runs over its line's end simply continues */
     ProfScope ps(c, CRTHIP_K_ACTIVE);
     const int total = n * p->desth;
     const dim3 grid((total + 63) / 64), block(64);
@@ -984,9 +1103,9 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
             /* the sample table depends on the black / white point only: rebuilt when those change, always on the
              * context's main stream (crt_run_encoder_prepare), never concurrently with a reader */
             if (FULL && p->noise != 0)
-                hipLaunchKernelGGL((k_active_nes<S, true, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
+                hipLaunchKernelGGL((k_active_nes<S, true, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, c->d_nes_tab, lay.pitch, lay.shift, wrapn);
             else
-                hipLaunchKernelGGL((k_active_nes<S, false, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_nes_tab);
+                hipLaunchKernelGGL((k_active_nes<S, false, FULL, 16>), grid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, c->d_nes_tab, lay.pitch, lay.shift, wrapn);
             return;
         }
     }
@@ -995,8 +1114,8 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
         /* kernel shape (crthip_set_shape): small batches take the scanline-parallel encoder */
         if (c->shape == 2 || (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS_ENC)) {
             const dim3 rgrid((total + 7) / 8);
-            if (noise) hipLaunchKernelGGL((k_active_row<S, true, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_jump1);
-            else hipLaunchKernelGGL((k_active_row<S, false, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, c->d_jump1);
+            if (noise) hipLaunchKernelGGL((k_active_row<S, true, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, c->d_jump1, lay.pitch, lay.shift, wrapn);
+            else hipLaunchKernelGGL((k_active_row<S, false, FULL>), rgrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, c->d_jump1, lay.pitch, lay.shift, wrapn);
             return;
         }
     }
@@ -1015,16 +1134,16 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
                                          : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
         if (in4 && big) {
 #define CRTHIP_LAUNCH_ACTIVE_BIG(NZ) \
-    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); \
-         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); } while (0)
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
+         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); } while (0)
             if (noise) CRTHIP_LAUNCH_ACTIVE_BIG(true); else CRTHIP_LAUNCH_ACTIVE_BIG(false);
 #undef CRTHIP_LAUNCH_ACTIVE_BIG
             return;
         }
     }
 #define CRTHIP_LAUNCH_ACTIVE(NZ, I4) \
-    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); \
-         else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, c->fstride, d_state, c->d_jump16, bo.K, bo.per); } while (0)
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
+         else hipLaunchKernelGGL((k_active<S, NZ, FAST, I4, FULL, 16>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); } while (0)
     if (noise) { if (in4) CRTHIP_LAUNCH_ACTIVE(true, true); else CRTHIP_LAUNCH_ACTIVE(true, false); }
     else       { if (in4) CRTHIP_LAUNCH_ACTIVE(false, true); else CRTHIP_LAUNCH_ACTIVE(false, false); }
 #undef CRTHIP_LAUNCH_ACTIVE
@@ -1051,20 +1170,43 @@ static void launch_margins(crthip_ctx *c, const crthip_params *p, int n, signed 
                            *p, n, dst, c->fstride, d_state, c->d_jump16, c->d_jump1, c->d_skel, head, gap, tail, gap_magic);
 }
 
+
+/* ... into padded signal lines (k_margin_pad) */
+template <class S>
+static void launch_margins_padded(crthip_ctx *c, const crthip_params *p, int n, signed char *dst, const crthip_state *d_state, const sig_layout &lay)
+{
+    ProfScope ps(c, CRTHIP_K_TEMPLATE);
+    constexpr int CF = (S::HRES + 15) / 16;
+    const int cl = (p->xo + 15) / 16;
+    const int right = S::HRES - (p->xo + p->destw);
+    const int cr = right > 0 ? (right + 15) / 16 : 0;
+    const int act_per = cl + cr;
+    const unsigned act_magic = act_per > 1 ? (unsigned) ((0x100000000ull + (unsigned) act_per - 1) / (unsigned) act_per) : 0u;
+    const int per_field = p->yo * CF + p->desth * act_per + (S::VRES - p->yo - p->desth) * CF;
+    const dim3 grid((per_field + 255) / 256, n < 65535 ? n : 65535);
+    if (p->noise != 0)
+        hipLaunchKernelGGL((k_margin_pad<S, true>), grid, dim3(256), 0, c->stream, *p, n, dst, lay.fstride, lay.shift, d_state,
+                           c->d_jump16, c->d_jump1, c->d_skel, c->fstride, cl, cr, act_magic, lay.wrap);
+    else
+        hipLaunchKernelGGL((k_margin_pad<S, false>), grid, dim3(256), 0, c->stream, *p, n, dst, lay.fstride, lay.shift, d_state,
+                           c->d_jump16, c->d_jump1, c->d_skel, c->fstride, cl, cr, act_magic, lay.wrap);
+}
+
 template <class S, bool FULL>
 static void launch_active_any(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                              signed char *dst, const crthip_state *d_state)
+                              signed char *dst, const crthip_state *d_state, const sig_layout &lay)
 {
-    if (encoder_fast_ok<S>(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state);
-    else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state);
+    if (encoder_fast_ok<S>(p) && !c->force_exact) launch_active<S, FULL, true>(c, p, n, d_images, istride, dst, d_state, lay);
+    else launch_active<S, FULL, false>(c, p, n, d_images, istride, dst, d_state, lay);
 }
 
 template <class S, bool FULL>
 static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
-                          signed char *dst, const crthip_state *d_state, int nes_setup)
+                          signed char *dst, const crthip_state *d_state, int nes_setup, const sig_layout &lay)
 {
     if (FULL) {
-        launch_margins<S>(c, p, n, dst, d_state);
+        if (lay.pitch != S::HRES) launch_margins_padded<S>(c, p, n, dst, d_state, lay);
+        else launch_margins<S>(c, p, n, dst, d_state);
     } else {
         constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
         ProfScope ps(c, CRTHIP_K_TEMPLATE);
@@ -1072,7 +1214,7 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
         hipLaunchKernelGGL((k_template<S>), dim3((total + 255) / 256), dim3(256), 0, c->stream,
                            *p, n, dst, c->fstride, d_state, nes_setup);
     }
-    launch_active_any<S, FULL>(c, p, n, d_images, istride, dst, d_state);
+    launch_active_any<S, FULL>(c, p, n, d_images, istride, dst, d_state, lay);
     return CRTHIP_OK;
 }
 
@@ -1226,8 +1368,11 @@ int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_
 {
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
-        int r = fused ? launch_encoder<S, true>(c, p, n, d_images, istride, dst, d_state, nes_setup)
-                      : launch_encoder<S, false>(c, p, n, d_images, istride, dst, d_state, nes_setup);
+        sig_layout flat;                                      /* the reference's layout: what every caller but the fused field-pass gets */
+        flat.pitch = S::HRES; flat.shift = 0; flat.padv = 0; flat.wrap = 0; flat.fstride = c->fstride;
+        const sig_layout &ly = lay && fused ? *lay : flat;
+        int r = fused ? launch_encoder<S, true>(c, p, n, d_images, istride, dst, d_state, nes_setup, ly)
+                      : launch_encoder<S, false>(c, p, n, d_images, istride, dst, d_state, nes_setup, ly);
         if (with_state) hipLaunchKernelGGL((k_encoder_state<S>), dim3((n + 63) / 64), dim3(64), 0, c->stream, *p, n, d_state);
         return r;
     });

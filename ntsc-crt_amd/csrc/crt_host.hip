@@ -145,6 +145,63 @@ k_seq_blend_step(int k, int outh, size_t pitch, unsigned char *out, size_t ostri
     }
 }
 
+
+/* (r6) the fused path's padded signal (crt_dev.h, sig_layout) back in the reference's flat layout, 16 samples per lane: what
+ * crthip_fieldpass_signal hands out (tests compare it with the oracle's inp[] byte for byte; nothing in a field-pass needs it) */
+template <class S>
+__global__ void __launch_bounds__(256)
+k_unpad(int n_fields, const signed char *__restrict__ src, size_t sstride, int shift, signed char *__restrict__ dst, size_t dstride)
+{
+    constexpr int CHUNKS = (S::INPUT_SIZE + CRTHIP_TAIL + 15) / 16;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= CHUNKS) return;
+    for (int f = blockIdx.y; f < n_fields; f += (int) gridDim.y)
+        store16u(dst + (size_t) f * dstride + q * 16, load16u(src + (size_t) f * sstride + shift + sig_phys<S>(q * 16)));
+}
+
+int crt_run_unpad(crthip_ctx *c, int n, const sig_layout *lay, const signed char *d_src, signed char *d_dst)
+{
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        if (lay->pitch == S::HRES) {
+            if (hipMemcpy2DAsync(d_dst, c->fstride, d_src, lay->fstride, (size_t) S::INPUT_SIZE + CRTHIP_TAIL, (size_t) n,
+                                 hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return CRTHIP_E_HIP;
+            return CRTHIP_OK;
+        }
+        constexpr int CHUNKS = (S::INPUT_SIZE + CRTHIP_TAIL + 15) / 16;
+        hipLaunchKernelGGL((k_unpad<S>), dim3((CHUNKS + 255) / 256, n < 65535 ? n : 65535), dim3(256), 0, c->stream, n, d_src, lay->fstride,
+                           lay->shift, d_dst, c->fstride);
+        return CRTHIP_OK;
+    });
+}
+
+/* Which layout the signal of a fused field-pass takes (crt_dev.h, sig_layout): padded lines whenever the geometry allows --
+ *   the row's overhang over its line (wrap = xo + destw - HRES) is at most 16 samples and ends inside the field,
+ *   the row starts at or behind column PADW (what is copied behind a line is then margin, never picture), and
+ *   the copies the margin kernel makes reach at least 80 columns (sync windows: 69, burst windows: 48 / 64)
+ * -- and the flat layout otherwise (odd x offsets, the rand()-noise VHS build, CRT_DO_VSYNC 0, crthip_set_signal_layout(ctx, 0)). */
+bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, sig_layout *lay)
+{
+    lay->pitch = c->sd.hres; lay->shift = 0; lay->padv = 0; lay->wrap = 0; lay->fstride = c->fstride;
+    if (!c->sig_pad || c->system == CRTHIP_SYSTEM_NTSCVHS || (p->flags & CRTHIP_F_NO_VSYNC)) return false;
+    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+        using S = decltype(tag);
+        using G = PadGeom<S>;
+        const int over = p->xo + p->destw - S::HRES, wrap = over > 0 ? over : 0;
+        if (wrap > 16 || p->xo < G::PADW || p->destw < 16 || p->yo < 0 || p->yo + p->desth + (wrap ? 1 : 0) > S::VRES) return 0;
+        /* k_margin_pad copies whole 16-byte chunks: [wrap, wrap + 16 m) behind a line that carries a row, [0, 16 m') elsewhere */
+        const int a = wrap + (G::PADW - wrap) / 16 * 16, b = G::PADW / 16 * 16;
+        const int padv = a < b ? a : b;
+        if (padv < 80) return 0;
+        lay->pitch = G::PITCH;
+        lay->shift = (128 - p->xo % 128) % 128;
+        lay->padv = padv;
+        lay->wrap = wrap;
+        lay->fstride = G::FSTRIDE;
+        return 1;
+    }) == 1;
+}
+
 extern "C" {
 
 int crthip_abi_version(void) { return CRTHIP_ABI_VERSION; }
@@ -191,6 +248,9 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     { const char *e = getenv("CRTHIP_WIDE_DECODE"); c->wide_decode = e ? atoi(e) != 0 : 1; }     /* A/B switch, crt_decode4.hip */
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     { const char *e = getenv("CRTHIP_WIDE_LPW"); c->wide_lpw_env = e && (atoi(e) == 8 || atoi(e) == 16) ? atoi(e) : 0; }   /* A/B switch, k_decode_wide */
+    { const char *e = getenv("CRTHIP_SIG_PAD"); c->sig_pad = e ? atoi(e) != 0 : 1; }       /* A/B switch: the fused path's signal layout (crt_dev.h, sig_layout) */
+    c->fstride_pad = 0;
+    dispatch_system(system, chroma_pattern, [&](auto tag) { c->fstride_pad = PadGeom<decltype(tag)>::FSTRIDE; return CRTHIP_OK; });
     { const char *e = getenv("CRTHIP_WIDE_ORDER"); c->wide_order_env = e ? atoi(e) : 0; }   /* A/B switches: workgroup order (crt_dev.h, block_item) */
     { const char *e = getenv("CRTHIP_DEC_ORDER"); c->dec_order_env = e ? atoi(e) : 0; }
     { const char *e = getenv("CRTHIP_ACT_ORDER"); c->act_order_env = e ? atoi(e) : 0; }
@@ -337,9 +397,11 @@ int crthip_reserve(crthip_ctx *c, int n)
     if (c->d_inp) hipFree(c->d_inp);
     if (c->d_lines) hipFree(c->d_lines);
     if (c->d_vhs_next) hipFree(c->d_vhs_next);
-    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->d_vhs_next = 0; c->cap_fields = 0;
+    c->d_analog = 0; c->d_inp = 0; c->d_lines = 0; c->d_vhs_next = 0; c->cap_fields = 0; c->last_n = 0;
     const size_t bytes = c->fstride * (size_t) n + 4096;
-    if (hipMalloc((void **) &c->d_inp, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc inp", hipSuccess);
+    /* inp[] of the fused path: padded lines + a scratch row per decoded line (crt_dev.h, sig_layout) -- about twice the flat field */
+    const size_t inp_bytes = (c->fstride_pad > c->fstride ? c->fstride_pad : c->fstride) * (size_t) n + 4096;
+    if (hipMalloc((void **) &c->d_inp, inp_bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc inp", hipSuccess);
     if (hipMalloc((void **) &c->d_analog, bytes) != hipSuccess) return set_err(c, CRTHIP_E_NOMEM, "hipMalloc analog", hipSuccess);
     if (hipMalloc((void **) &c->d_lines, sizeof(crthip_line) * (size_t) n * c->sd.lines) != hipSuccess)
         return set_err(c, CRTHIP_E_NOMEM, "hipMalloc lines", hipSuccess);
@@ -348,7 +410,7 @@ int crthip_reserve(crthip_ctx *c, int n)
         return set_err(c, CRTHIP_E_NOMEM, "hipMalloc VHS histories", hipSuccess);
     /* the internal second stream (VHS noise pair, overlap chunks) exists from here on: a field-pass creates nothing (graph capture) */
     if (crt_ensure_aux(c) != CRTHIP_OK) return set_err(c, CRTHIP_E_HIP, "internal stream", hipGetLastError());
-    HIPCHK(c, hipMemsetAsync(c->d_inp, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_inp, 0, inp_bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_analog, 0, bytes, c->stream));
     if (!c->sd.nes_timing) {                    /* bloom builds (none with the NES timing): the decoder's sort scratch, 4 bytes per scanline */
         const int rc = crt_reserve_bloom(c, n);
@@ -456,13 +518,14 @@ static crthip_params with_signal_envelope(const crthip_params *p)
 /* one chunk of a batch, fields [first, first+n), on the context's current stream.  `part` (bits): 1 = encoder + channel
  * noise, 4 = the sync chain up to the line table, 2 = the decoder (the rand()-noise VHS build and CRT_DO_VSYNC 0 run 1 and 4
  * as one unit under bit 1) */
-static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n, int part,
+static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int first, int n, int part, const sig_layout &lay,
                            const void *d_images, size_t istride, void *d_out, size_t ostride, crthip_state *d_state)
 {
+    /* lay: where this field-pass keeps its signal (crt_fused_layout; the same for every chunk and part of a call) */
     const unsigned char *img = (const unsigned char *) d_images + (size_t) first * istride;
     unsigned char *out = (unsigned char *) d_out + (size_t) first * ostride;
     crthip_state *st = d_state + first;
-    signed char *inp = c->d_inp + (size_t) first * c->fstride;
+    signed char *inp = c->d_inp + (size_t) first * lay.fstride;
     signed char *analog = c->d_analog + (size_t) first * c->fstride;
     crthip_line *ln = c->d_lines + (size_t) first * c->sd.lines;
     int rc = CRTHIP_OK;
@@ -496,7 +559,7 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
                  * leaves in the state (ccf preset, M6) is applied by the sync chain's own waves when it follows at once
                  * (k_hsync_wave, preset_ccf): one launch less per field-pass */
                 preset = (part & 4) && p->out_bpp != 0 && c->system != CRTHIP_SYSTEM_NTSCVHS;   /* (VHS also resets hsync there) */
-                rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, !preset);
+                rc = crt_run_encoder(c, p, n, img, istride, inp, st, true, 1, !preset, &lay);
             } else {
                 /* invalid input format: crt_modulate is a no-op, the decoder sees a clean field + noise
                  * (rn is advanced by k_vsync below) */
@@ -508,10 +571,10 @@ static int fieldpass_chunk(crthip_ctx *c, const crthip_params *p, int enc, int f
     }
     if ((part & 4) && p->out_bpp != 0) {
         const crthip_params q = enc == 0 ? with_signal_envelope(p) : *p;
-        rc = crt_run_sync(c, &q, n, inp, st, ln, 1, preset ? 1 : 0);
+        rc = crt_run_sync(c, &q, n, inp, st, ln, 1, preset ? 1 : 0, &lay);
         if (rc) return rc;
     }
-    if ((part & 2) && p->out_bpp != 0) rc = crt_run_decode(c, p, n, inp, ln, out, ostride);
+    if ((part & 2) && p->out_bpp != 0) rc = crt_run_decode(c, p, n, inp, ln, out, ostride, lay.fstride);
     return rc;
 }
 
@@ -539,6 +602,14 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         rc = crt_run_encoder_prepare(c, p, true);
         if (rc) return rc;
     }
+    /* the signal between this call's encoder and decoder: padded lines where the fused LCG-noise encoder writes it (crt_dev.h) */
+    sig_layout lay;
+    const bool vhs_rand_path = c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
+    if (enc != 0 || vhs_rand_path || !crt_fused_layout(c, p, &lay)) {
+        lay.pitch = c->sd.hres; lay.shift = 0; lay.padv = 0; lay.wrap = 0; lay.fstride = c->fstride;
+    }
+    c->last_lay = lay;
+    c->last_n = n;
     /* 0 = automatic.  The idea: run the vector / latency bound encoder + sync chain of one chunk under the HBM-write
      * bound decoder of the previous one.  Measured on MI355X (profiles/r02_overlap_sweep.txt): at 1080p the encoder's
      * image reads and the decoder's picture writes already saturate what HBM delivers for this access mix, running
@@ -550,7 +621,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
                                                     of the first: 3-4 % slower at 640x480 and 1080p alike (profiles/r03_1080p_experiments.txt) */
     const int nchunks = (want_chunks > 1 && n >= 256 * want_chunks && !c->prof) ? want_chunks : 1;
     if (nchunks == 1) {
-        rc = fieldpass_chunk(c, p, enc, 0, n, 7, d_images, istride, d_out, ostride, d_state);
+        rc = fieldpass_chunk(c, p, enc, 0, n, 7, lay, d_images, istride, d_out, ostride, d_state);
     } else {
         /* Two-stage software pipeline over the chunks: the encoder + sync chain of ALL chunks run back to back on an
          * internal stream, the decoders on the caller's stream, decoder k waiting for the event behind sync chain k.
@@ -566,7 +637,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         int used = 0;
         for (int k = 0, first = 0; first < n && rc == CRTHIP_OK; k++, first += per) {
             const int cnt = n - first < per ? n - first : per;
-            rc = fieldpass_chunk(c, p, enc, first, cnt, 1 | 4, d_images, istride, d_out, ostride, d_state);
+            rc = fieldpass_chunk(c, p, enc, first, cnt, 1 | 4, lay, d_images, istride, d_out, ostride, d_state);
             if (rc == CRTHIP_OK && hipEventRecord(c->ev_chunk[k], c->aux_stream) != hipSuccess) rc = CRTHIP_E_HIP;
             used = k + 1;
         }
@@ -574,7 +645,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
         for (int k = 0, first = 0; k < used && rc == CRTHIP_OK; k++, first += per) {
             const int cnt = n - first < per ? n - first : per;
             HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_chunk[k], 0));
-            rc = fieldpass_chunk(c, p, enc, first, cnt, 2, d_images, istride, d_out, ostride, d_state);
+            rc = fieldpass_chunk(c, p, enc, first, cnt, 2, lay, d_images, istride, d_out, ostride, d_state);
         }
         /* the caller's stream has waited for every event of the internal stream: nothing is left running there */
     }
@@ -589,6 +660,25 @@ int crthip_set_signal_tile(crthip_ctx *c, int dwords)
 {
     if (!c || (dwords != 0 && dwords != 16 && dwords != 32 && dwords != 64)) return CRTHIP_E_ARG;
     c->sig_tile_env = dwords;
+    return CRTHIP_OK;
+}
+
+int crthip_set_signal_layout(crthip_ctx *c, int padded)
+{
+    if (!c || (padded != 0 && padded != 1)) return CRTHIP_E_ARG;
+    c->sig_pad = padded;
+    return CRTHIP_OK;
+}
+
+int crthip_fieldpass_signal(crthip_ctx *c, int n, signed char *d_inp_flat, int *padded)
+{
+    if (!c || n <= 0 || !d_inp_flat) return CRTHIP_E_ARG;
+    if (n > c->last_n || !c->d_inp) return set_err(c, CRTHIP_E_ARG, "crthip_fieldpass_signal: no field-pass of that many fields went through this context", hipSuccess);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (padded) *padded = c->last_lay.pitch != c->sd.hres;
+    const int rc = crt_run_unpad(c, n, &c->last_lay, c->d_inp, d_inp_flat);
+    if (rc) return rc;
+    HIPCHK(c, hipGetLastError());
     return CRTHIP_OK;
 }
 
@@ -657,6 +747,9 @@ int crthip_seq_encode(crthip_ctx *c, const crthip_params *p, int n, int first_in
         if (rc) return rc;
     }
     c->seq_guess_n = 0;                                    /* a new video: no warm start for the sync chain */
+    /* sequence mode keeps the reference's flat signal layout (its phases are separate calls over the same workspace) */
+    c->last_lay.pitch = c->sd.hres; c->last_lay.shift = 0; c->last_lay.padv = 0; c->last_lay.wrap = 0; c->last_lay.fstride = c->fstride;
+    c->last_n = n;
     rc = crt_run_encoder_prepare(c, p, true);
     if (rc) return rc;
     if (vhs) {

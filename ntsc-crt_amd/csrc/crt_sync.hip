@@ -35,7 +35,7 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 /* D2 vsync, crt_core.c:379-396: first (line, j) whose running line sum <= VTHR.  Wave-wide: all 2 * VWIN candidate lines
  * are fetched up front, then searched in order with a prefix sum across the wave.  Returns the line found (the last
  * candidate if none) and j (HRES if none), the same in every lane. */
-template <class S>
+template <class S, int LP = S::HRES>       /* LP: bytes between line starts (HRES: flat; PadGeom::PITCH: the fused path's padded lines) */
 __device__ __forceinline__ void vsync_search(const signed char *__restrict__ in, const int vsync, const int lane, int &vline, int &vj)
 {
     vline = 0; vj = S::HRES;
@@ -50,7 +50,7 @@ __device__ __forceinline__ void vsync_search(const signed char *__restrict__ in,
         for (int i = 0; i < GROUP; i++) {
             const int l = posmod(vsync + g0 + i - S::VWIN, S::VRES);
 #pragma unroll
-            for (int pc = 0; pc < PIECES; pc++) cand[i][pc] = load16u(in + l * S::HRES + pc * 1024 + lane * 16);
+            for (int pc = 0; pc < PIECES; pc++) cand[i][pc] = load16u(in + l * LP + pc * 1024 + lane * 16);
         }
         /* all of them in flight together: without this the compiler sinks each load into the conditional block that
          * uses it, one memory round trip per candidate line (13 in a row in the steady state) */
@@ -162,12 +162,18 @@ __device__ __forceinline__ int burst_step(int acc, int s)
 /* preset_ccf (the fused field-pass): the burst integrators do not start from the state's ccf but from what crt_modulate leaves
  * there (crt_ntsc.c:325-329 and siblings: the burst level of the line class, << 7) -- k_encoder_state's work, done by the lanes
  * that are about to read it, which saves the fused path a launch; field / frame are masked like there. */
-template <class S, int FPB>
+/* PAD (r6): inp holds the fused path's padded signal lines (crt_dev.h, sig_layout) -- `shift` bytes, then line n at n * PITCH,
+ * `padv` valid bytes of the next line's head behind each.  Every window below is then addressed through sig_phys (line and column
+ * of its first byte; contiguous from there), the line table's pos becomes an offset in the padded field, and the few lines whose
+ * decoder window would run past the valid copy (hsync far from lock) get that window copied into a scratch row behind the field. */
+template <class S, int FPB, bool PAD>
 __global__ void __launch_bounds__(64 * FPB, 4)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
              crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn,
-             int preset_ccf)
+             int preset_ccf, int shift, int padv)
 {
+    using G = PadGeom<S>;
+    constexpr int LP = PAD ? G::PITCH : S::HRES;
     constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS, VPER = S::VPER;
     constexpr int WOFF = S::SYNC_BEG - S::HWIN;          /* first byte of the search window relative to ln + hsync */
     constexpr int CH = 64, NCH = (S::LINES + CH - 1) / CH;
@@ -193,7 +199,9 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
     int (*const s_acc)[CCS == 4 ? 4 : 8] = s_acc_[wv];
     int *const s_cnt = s_cnt_[wv], *const s_off = s_off_[wv];
 #define HSW_SYNC() do { if (FPB > 1) __syncthreads(); else wave_lds_fence(); } while (0)
-    const signed char *in = inp + (size_t) f * fstride;
+    const signed char *in = inp + (size_t) f * fstride + (PAD ? shift : 0);
+    /* offset of flat sample index a (>= 0) from `in` */
+    auto phys = [&](int a) { return PAD ? sig_phys<S>(a) : a; };
     crthip_state *st = state + f;
     int hsync = __builtin_amdgcn_readfirstlane(st->hsync);
     /* D2: the vertical sync search of this field, by the field's own wave (one launch and one trip through memory less
@@ -204,7 +212,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
         vsync = __builtin_amdgcn_readfirstlane(st->vsync);
         odd_field = __builtin_amdgcn_readfirstlane(st->odd_field);
     } else {
-        vsync_search<S>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
+        vsync_search<S, LP>(in, __builtin_amdgcn_readfirstlane(st->vsync), lane, vsync, vj_);
         vsync = __builtin_amdgcn_readfirstlane(vsync);
         odd_field = __builtin_amdgcn_readfirstlane(vj_) > S::HRES / 2;
     }
@@ -251,11 +259,13 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
         const int line = S::TOP + c * CH + lane;
         int b = win_base(line < S::BOT ? line : S::BOT);
         if (b < 0) b = 0;
+        b = phys(b);                                     /* (padded: 80 bytes from at most 24 columns before a line's end: inside the copy, padv >= 80) */
 #pragma unroll
         for (int q = 0; q < WPIECES; q++) wreg[q] = load16u(in + b + q * 16);
         /* every lane also brings the window of the line after the chunk (wrapped hsync values look there) */
         int be = win_base(S::TOP + (c + 1) * CH < S::BOT ? S::TOP + (c + 1) * CH : S::BOT);
         if (be < 0) be = 0;
+        be = phys(be);
 #pragma unroll
         for (int q = 0; q < WPIECES; q++) wext[q] = load16u(in + be + q * 16);
     };
@@ -317,7 +327,8 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                     } else {
                         const long ga = (long) my_lidx * S::HRES + h_in + WOFF;
                         v4i g = { 0, 0, 0, 0 };
-                        if (ga >= 0 && ga + 16 <= (long) fstride) g = load16u(in + ga);
+                        if (PAD) { if (ga >= 0 && ga < (long) (S::INPUT_SIZE + S::HRES)) g = load16u(in + phys((int) ga)); }
+                        else if (ga >= 0 && ga + 16 <= (long) fstride) g = load16u(in + ga);
                         w0 = (unsigned) g.x; w1 = (unsigned) g.y; w2 = (unsigned) g.z; w3 = (unsigned) g.w;
                     }
                     /* running sum biased by -(HTHR + 1): its sign bit says "sum <= HTHR"; the sign bits are shifted into
@@ -453,6 +464,19 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                     int ypos = lidx + 3;
                     if (ypos >= S::VRES) ypos -= S::VRES;
                     lp.pos = xpos + ypos * S::HRES;
+                    const bool reads_tail = lp.pos + S::AV_LEN + 8 > S::INPUT_SIZE;
+                    if constexpr (PAD) {
+                        /* where the decoders find the window: in place, or -- it would run past the valid copy behind its line -- in
+                         * the line's scratch row, filled here piece by piece (a piece starts inside a line: contiguous) */
+                        const int flat = lp.pos;
+                        lp.pos = shift + ypos * G::PITCH + xpos;
+                        if (xpos + G::DECWIN > S::HRES + padv) {
+                            const int srow = shift + (G::SCR_LINE0 + (line - S::TOP)) * G::PITCH;
+                            signed char *scr = const_cast<signed char *>(inp) + (size_t) f * fstride + srow;
+                            for (int o = 0; o < G::DECWIN; o += 16) store16u(scr + o, load16u(in + sig_phys<S>(flat + o)));
+                            lp.pos = srow;
+                        }
+                    }
                     int dci, dcq;
                     const int pa = posmod(hs, CCS);
                     if constexpr (CCS == 4) {                              /* :471-472 */
@@ -485,7 +509,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                             rank++;
                     }
                     nrows |= (rank & CRTHIP_LINE_RANK_MASK) << CRTHIP_LINE_RANK_SHIFT;
-                    nrows |= line_tier_flags<CCS>(lp.wave0, lp.wave1, P.saturation, P.loskip_wave_max, lp.pos + S::AV_LEN + 8 > S::INPUT_SIZE);
+                    nrows |= line_tier_flags<CCS>(lp.wave0, lp.wave1, P.saturation, P.loskip_wave_max, reads_tail);
                     lp.nrows = nrows;
                 }
                 v4i a, b;
@@ -517,7 +541,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
             }
             /* burst samples: CB_LEN bytes from ln + halign + CB_BEG (:459-461) */
             const int halign = CCS == 4 ? (rec_hs & ~3) : rec_hs - rec_hs % CCS;
-            const int baddr = lidx * S::HRES + halign + S::CB_BEG;
+            const int baddr = phys(lidx * S::HRES + halign + S::CB_BEG);      /* (padded: BPIECES * 16 <= padv bytes from any column) */
 #pragma unroll
             for (int q = 0; q < BPIECES; q++) {
                 breg[q] = !rec_skip ? load16u(in + baddr + q * 16) : v4i{0, 0, 0, 0};
@@ -656,19 +680,20 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
          * fields per workgroup (A/B).  (r5) threshold re-measured, session r5s23: 512 fields 0.078 (one) / 0.085 ms (four) and the
          * field-pass 0.566 / 0.606; 1024 fields 0.097 / 0.090; 4096 fields 0.188 / 0.165; 1080p x 2048 0.140 / 0.119 */
         constexpr bool FPB4_OK = 64 / (S::VPER * S::CCS) >= 4;
-        bool done = false;
+        const bool pad = lay && lay->pitch != S::HRES;
+        const size_t fstride = lay ? lay->fstride : c->fstride;
+        const int shift = pad ? lay->shift : 0, padv = pad ? lay->padv : 0;
+        const bool fpb4 = FPB4_OK && c->sync_kernel != 2 && (n >= SYNC_FPB4_MIN_FIELDS || c->sync_kernel == 3);
+#define CRTHIP_LAUNCH_SYNC(FPB, PADV) \
+    hipLaunchKernelGGL((k_hsync_wave<S, FPB, PADV>), dim3((n + FPB - 1) / FPB), dim3(64 * FPB), 0, c->stream, *p, n, d_inp, fstride, d_state, d_lines, \
+                       c->whole_field, advance_rn, preset_ccf, shift, padv)
         if constexpr (FPB4_OK) {
-            if (c->sync_kernel != 2 && (n >= SYNC_FPB4_MIN_FIELDS || c->sync_kernel == 3)) {
-                hipLaunchKernelGGL((k_hsync_wave<S, 4>), dim3((n + 3) / 4), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                                   c->whole_field, advance_rn, preset_ccf);
-                done = true;
-            }
+            if (fpb4) { if (pad) CRTHIP_LAUNCH_SYNC(4, true); else CRTHIP_LAUNCH_SYNC(4, false); }
         }
-        if (!done)
-            hipLaunchKernelGGL((k_hsync_wave<S, 1>), dim3(n), dim3(64), 0, c->stream, *p, n, d_inp, c->fstride, d_state, d_lines,
-                               c->whole_field, advance_rn, preset_ccf);
+        if (!fpb4) { if (pad) CRTHIP_LAUNCH_SYNC(1, true); else CRTHIP_LAUNCH_SYNC(1, false); }
+#undef CRTHIP_LAUNCH_SYNC
         if (p->bloom)
-            hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, c->fstride, d_lines);
+            hipLaunchKernelGGL((k_bloom<S>), dim3(n), dim3(256), 0, c->stream, *p, n, d_inp, fstride, d_lines);
         return CRTHIP_OK;
     });
 }

@@ -82,7 +82,7 @@ CASES = [
 ]
 
 
-def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=0, wide_lpw=0):
+def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=0, wide_lpw=0, sig_pad=1, want_padded=None):
     """shape: 1 = lane-per-scanline kernels (the throughput shape; forced, because small batches would otherwise
     pick the other one), 2 = scanline-parallel kernels, 0 = the library's own choice;  wide_lpw: 8 / 16 pins the wide-run
     decoder's scanlines per wavefront (0: by batch size, i.e. 8 for the small batches of these tests)"""
@@ -97,6 +97,7 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=
     g.set_shape(shape)
     g.set_signal_tile(sig_tile)
     g.set_wide_lpw(wide_lpw)
+    g.set_signal_layout(sig_pad)                     # fused path: padded signal lines (round 6) or the reference's flat ones
     for k, v in knobs.items():
         setattr(g, k, v)
     fields = [k & 1 for k in range(n)]
@@ -126,6 +127,15 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=
         if not fused:
             ginp = g.inp.cpu().numpy()
             glines = g.line_table.cpu().numpy()
+        elif R.bpp4fmt(ifmt) and R.bpp4fmt(ofmt):
+            # the fused path's own signal, repacked into the reference's layout (crthip_fieldpass_signal): inp[] is compared for
+            # the fused path too since round 6 -- whichever layout the workspace keeps it in
+            fsig, was_padded = g.fieldpass_signal()
+            fsig = fsig.cpu().numpy()
+            if want_padded is not None:
+                assert was_padded == want_padded, "signal layout of the fused path: padded=%s" % was_padded
+        else:
+            fsig = None
         for k, c in enumerate(ocrts):
             what = "%s fused=%s step %d field %d" % (name, fused, step, k)
             c.modulate()
@@ -139,6 +149,8 @@ def _run_case(crtlib, case, fused, steps=4, n=3, exact=False, shape=1, sig_tile=
             undefined[k] = undefined[k] or R.reads_past_inp(orc, c.trace, c.get("vsync"), hs_before)
             if undefined[k]:
                 continue
+            if fused and fsig is not None:
+                np.testing.assert_array_equal(fsig[k, :orc.input_size], c.inp, err_msg=what + " inp of the fused path")
             if not fused:
                 np.testing.assert_array_equal(ginp[k, :orc.input_size], c.inp, err_msg=what + " inp")
                 tr = c.trace
@@ -170,6 +182,38 @@ def test_stagewise_parity(crtlib, case):
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_fused_fieldpass_parity(crtlib, case):
     _run_case(crtlib, CASES[case], fused=True)
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_fused_fieldpass_flat_signal_layout_parity(crtlib, case):
+    """Round 6: the fused path keeps its signal in PADDED lines by default (crt_dev.h, sig_layout; every other fused test runs that).
+    The reference's flat layout is still what geometries outside the padded layout's reach, sequence mode and every stage-level
+    call use: forced here (crthip_set_signal_layout(ctx, 0)) for the whole table, inp[] compared as well."""
+    _run_case(crtlib, CASES[case], fused=True, steps=2, sig_pad=0, want_padded=False)
+
+
+@pytest.mark.parametrize("sig_tile", [0, 32])
+@pytest.mark.parametrize("name,case", [("ntsc", 0), ("ntsc", 1), ("ntsc", 2), ("ntsc", 5), ("ntsc", 9), ("ntsc", 13), ("ntscp0", 18), ("snes", 1), ("temp", 1),
+                                       ("pv1k", 1), ("nesrgb", 1), ("ntscbloom", 1), ("pv1kbloom", 1), ("vhslcg", 1), ("ntscnovsync", 1)])
+def test_padded_signal_layout_is_what_the_fused_path_runs(crtlib, name, case, sig_tile):
+    """... and the default really is the padded layout for every system at its standard geometry (crthip_fieldpass_signal reports
+    which layout the workspace held), with inp[] -- repacked to the reference's layout -- equal to the oracle's byte for byte, all
+    shapes of the sync chain's windows included (four steps: the sync state moves).  The rand()-noise VHS build and CRT_DO_VSYNC 0
+    produce their signal by other kernels and stay flat; so does the VHS build with the LCG noise (one system is one layout)."""
+    c = CASES[case] if name.startswith("ntsc") and not name.endswith(("bloom", "novsync")) or name == "ntscp0" else (name,) + F4_CASES[case]
+    c = (name,) + tuple(c[1:])
+    _run_case(crtlib, c, fused=True, steps=4, sig_tile=sig_tile, want_padded=name not in ("vhslcg", "ntscnovsync"))
+
+
+def test_padded_signal_layout_falls_back_for_rows_it_cannot_hold(crtlib):
+    """An x offset that makes more than 16 samples of the active row run over the line end is legal in the reference (flat index,
+    crt_ntsc.c:322: the row continues in the next line's front porch) and outside the padded layout: the flat one takes it.  Up to
+    16 samples (xoffset 4: 3 samples, xoffset 16: 15) the padded layout stores the overhang twice -- behind its line and at the
+    head of the next (RowTiles::wrap_home)."""
+    for xoff, padded in ((24, False), (16, True), (4, True)):
+        case = ("ntsc", 640, 480, R.FMT_BGRA, 640, 480, R.FMT_BGRA, 30, dict(as_color=1, xoffset=xoff, yoffset=1), dict(scanlines=1))
+        _run_case(crtlib, case, fused=True, steps=2, want_padded=padded)
+        _run_case(crtlib, case, fused=True, steps=2, want_padded=padded, shape=2)      # the scanline-parallel encoder's stores
 
 
 @pytest.mark.parametrize("fused", [False, True])

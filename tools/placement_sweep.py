@@ -63,6 +63,25 @@ def child(pad, batch, steps, warmup, w=1920, h=1080, noise=0):
     for name, (ms, cnt) in pr.items():
         rec[name + "_ms"] = round(ms / steps, 4)
     rec["out_ptr_mod_64k"] = out.data_ptr() % 65536
+    if os.environ.get("SWEEP_SERIES"):
+        # per-launch durations (is a slow process slow in every launch?) and the board's state
+        series = {"decode": [], "active": []}
+        g.profile(True)
+        for k in range(steps):
+            step(k)
+            pr = g.profile_read()
+            for nm in series:
+                series[nm].append(round(pr[nm][0], 3))
+        g.profile(False)
+        rec["series"] = series
+        try:
+            smi = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower", "--json"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=30).stdout.decode()
+            j = json.loads(smi)
+            card = j[sorted(j)[0]]
+            rec["smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("temperature", "sclk", "mclk", "fclk", "power"))}
+        except Exception as ex:                                  # noqa: BLE001
+            rec["smi"] = str(ex)[:80]
     print(json.dumps(rec))
     g.close()
 
