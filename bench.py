@@ -207,8 +207,8 @@ def compact_record(full):
     if cfg.get("batches_in_flight_tuning"):      # S -> frames/sec
         out["config"]["batches_in_flight_fps"] = {s_: _r(v["value"], 5) for s_, v in cfg["batches_in_flight_tuning"].items()}
     rf = full.get("roofline") or {}
-    out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
-                                                  "algorithmic_bytes_per_field", "kernel_own_frac", "pipeline_frac")}
+    out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio",
+                                                  "traffic_dominant_kernel", "algorithmic_bytes_per_field", "kernel_own_frac", "pipeline_frac")}
     out["roofline"]["kernel_ms"] = {k: _r(v) for k, v in (rf.get("kernel_ms") or {}).items() if v}
     if rf.get("traffic_source"):
         out["roofline"]["traffic_source"] = rf["traffic_source"].split(" (")[0]
@@ -298,13 +298,19 @@ def north_star_table(world, headline, weak1080, strong512):
     def one(rec):
         return (rec or {}).get("one_batch_in_flight") or rec or {}
     row = {"n_gpus": world}
+    # frac_* = the whole launch sequence against 8 TB/s on the wall clock (pipeline_frac); kernel_frac_* = roofline.frac as specified
+    # (the pass's algorithmic bytes over the dominant kernel's duration); kernel_own_frac_* = that kernel on the bytes it moves itself
     if headline:
+        hrf = headline.get("roofline") or {}
         row.update(fps_640=_r(headline["value"], 6), fps_640_one_batch=_r(one(headline).get("value"), 6),
-                   frac_640=_r((headline.get("roofline") or {}).get("pipeline_frac"), 3))
+                   frac_640=_r(hrf.get("pipeline_frac"), 3), frac_640_one_batch=_r(one(headline).get("pipeline_frac"), 3),
+                   kernel_frac_640=_r(hrf.get("frac"), 3), kernel_own_frac_640=_r(hrf.get("kernel_own_frac"), 3))
     if weak1080:
+        wrf = weak1080.get("roofline") or {}
         row.update(fps_1080p_weak=_r(weak1080["value"], 6), fps_1080p_weak_one_batch=_r(one(weak1080).get("value"), 6),
-                   frac_1080p_weak=_r((weak1080.get("roofline") or {}).get("pipeline_frac"), 3),
-                   frac_1080p_weak_one_batch=_r(one(weak1080).get("pipeline_frac"), 3))
+                   frac_1080p_weak=_r(wrf.get("pipeline_frac"), 3),
+                   frac_1080p_weak_one_batch=_r(one(weak1080).get("pipeline_frac"), 3),
+                   kernel_frac_1080p=_r(wrf.get("frac"), 3), kernel_own_frac_1080p=_r(wrf.get("kernel_own_frac"), 3))
     if strong512:
         ms = one(strong512).get("ms_per_step")
         row.update(configs2_frames=512, configs2_ms=_r(ms), configs2_fps=_r(512.0 / (ms * 1e-3) if ms else None, 6),
@@ -523,6 +529,7 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
     achieved = abytes * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
     own_gbs = own[dom] * n / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
     traffic = None
+    traffic_kernel = None
     valu = None
     traffic_stale = None
     if traffic_file and os.path.exists(traffic_file):        # PMC passes (tools/prof_bench.sh, prof_sq.sh) on this very workload
@@ -530,8 +537,13 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
             tj = json.load(open(traffic_file))
             if tj.get("workload") == wl["name"]:
                 traffic_stale = tj.get("source_hash") != kernel_source_hash()
-                traffic = tj.get("k_" + dom + "_bytes_per_field")
+                # the whole pass's counted bytes -- the figure that stands beside the whole pass's ALGORITHMIC bytes
+                # (`traffic_ratio` = counted / algorithmic, >= 1: what the intermediate signal, margins and sync windows add); the
+                # dominant kernel's own counted bytes go out separately
+                traffic = tj.get("all_kernels_bytes_per_field")
                 traffic = traffic * n if traffic else None
+                traffic_kernel = tj.get("k_" + dom + "_bytes_per_field")
+                traffic_kernel = traffic_kernel * n if traffic_kernel else None
                 # the vector-ALU side of the same kernels: wave64 instructions (SQ_INSTS_VALU from the committed counter
                 # passes) over the time measured HERE, against one instruction per 4 cycles and SIMD -- the rate these
                 # instruction mixes issue at on gfx950 (profiles/r02_valu_mixed_sequences.txt)
@@ -574,6 +586,9 @@ def run_workload(torch, crtlib, shard, dist, dev, rank, world, local, wl, steps,
                      # as specified: the field-pass's algorithmic bytes per launch / the dominant kernel's duration
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
+                     "traffic_what": "HBM bytes of ALL kernels of one field-pass launch sequence (counters), to be read against algorithmic_bytes_per_field x fields",
+                     "traffic_ratio": (traffic / (abytes * n)) if traffic else None,
+                     "traffic_dominant_kernel": traffic_kernel,
                      # the kernels changed since the PMC passes that produced `traffic` (hash of csrc/ differs)
                      "traffic_stale": traffic_stale,
                      # NOT measured in this run: PMC passes need rocprofv3 around the process (tools/prof_bench.sh)

@@ -188,8 +188,9 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
  * 128-byte line at a time (measured: 3-8x the algorithmic HBM traffic, profiles/r01_v1_*).  Instead
  * all global I/O goes through LDS tiles [64 rows][TILE] that the wave fills / drains COOPERATIVELY
  * with row-contiguous 16-byte pieces (8 lanes x 16 B = one 128-byte line of one row per 8 lanes),
- * while each lane reads / writes only its own row of the tile.  Row stride = TILE+1 dwords, all LDS
- * accesses are 32-bit: bank = (row + column) % 32, conflict-free for both access directions.
+ * while each lane reads / writes only its own row of the tile.  Row addressing: TileRows (crt_dev.h) -- (r6) one pad dword per
+ * row PAIR for the 16-dword tiles, which is conflict-free for both access directions; the odd row stride TILE + 1 of rounds 1-5
+ * was that only for the lane-per-row direction (the counters said so: profiles/r05_headline_sq_counters.json).
  * Workgroup = one wave, so __syncthreads() is only an ordering fence between the two phases.
  */
 /* decoder input tile: IN_TILE_DW dwords (64 samples) per row.  8 dwords would buy a fifth wave per SIMD (fewer
@@ -212,17 +213,27 @@ __device__ __forceinline__ unsigned unpack_selector(int format)
 /* TG = tier GROUP of this launch: 0 -> tiers 0 / 1, 1 -> tiers 2 / 3, 2 -> tiers 4 / 5 (FIR).  A wave takes the loop compiled for
  * its own tier -- two copies of the line loop in one kernel, chosen once per wave -- so that a field-pass launches two decoder
  * kernels where it launched four, three of which usually had nothing to do (5 us each in a 230 us step). */
+#ifndef DEC_IN_TILE_DW
+#define DEC_IN_TILE_DW 16                  /* (A/B builds: -DDEC_IN_TILE_DW=8 -DDEC_WAVES_PER_EU=5, profiles/r06_decode_occupancy.txt) */
+#endif
+#ifdef DEC_WAVES_PER_EU
+#define DEC_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(DEC_WAVES_PER_EU, DEC_WAVES_PER_EU)))
+#else
+#define DEC_OCCUPANCY_ATTR
+#endif
 template <class S, int TG, bool BPP3, int PXT, bool BLOOM = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) DEC_OCCUPANCY_ATTR
 k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
          const crthip_line *__restrict__ lines, unsigned char *__restrict__ outp, size_t ostride, int min_tier,
          int want_rank, const int *__restrict__ perm, int order_k, int order_per)
 {
     constexpr int TLO = 2 * TG;
-    constexpr int IN_TILE_DW = 16, IN_PIECES = IN_TILE_DW / 4, IN_STRIDE = IN_TILE_DW + 1;
-    __shared__ unsigned s_in[64 * IN_STRIDE];
-    constexpr int PX_TILE = PXT, PX_STRIDE = PXT + 1, PX_PIECES = PXT / 4;
-    __shared__ unsigned s_px[64 * PX_STRIDE];
+    constexpr int IN_TILE_DW = DEC_IN_TILE_DW, IN_PIECES = IN_TILE_DW / 4;
+    using TIN = TileRows<IN_TILE_DW>;                 /* row addressing of both tiles: conflict-free lane-per-row AND cooperatively (crt_dev.h) */
+    __shared__ unsigned s_in[TIN::DWORDS];
+    constexpr int PX_TILE = PXT, PX_PIECES = PXT / 4;
+    using TPX = TileRows<PXT>;
+    __shared__ unsigned s_px[TPX::DWORDS];
     __shared__ unsigned long long s_src[64], s_dst[64];
     __shared__ int s_nrows[64];
 
@@ -344,7 +355,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
         wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < IN_PIECES; i++) {
-            unsigned *d = s_in + (i * IN_ROWS + in_row) * IN_STRIDE + in_piece * 4;
+            unsigned *d = s_in + TIN::row(i * IN_ROWS + in_row) + in_piece * 4;
             d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
         }
         wave_lds_fence();
@@ -356,7 +367,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
         }
         const int xq_end = (t + 1) * IN_TILE_DW < NQ ? (t + 1) * IN_TILE_DW : NQ;
         for (int xq = t == t0 ? xq0 : t * IN_TILE_DW; xq < xq_end; xq++) {
-            const int word = (int) s_in[lane * IN_STRIDE + (xq - t * IN_TILE_DW)];
+            const int word = (int) s_in[TIN::row(lane) + (xq - t * IN_TILE_DW)];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = xq * 4 + k;
@@ -446,7 +457,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                         r = clampi(r, 0, 255); g = clampi(g, 0, 255); b = clampi(b, 0, 255);
                         rgb = lshl_or(lshl_or((unsigned) r, 8, (unsigned) g), 8, (unsigned) b);
                     }
-                    s_px[lane * PX_STRIDE + (px - px0)] = rgb;
+                    s_px[TPX::row(lane) + (px - px0)] = rgb;
                     ppos += dx;
                     px++;
                     if (px == tile_end) {
@@ -462,7 +473,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                 const int nr = s_nrows[rr_];
                                 if (nr > 0 && have > 0) {
                                     const unsigned long long d = s_dst[rr_] + (size_t) (px0 + piece * 4) * 4;
-                                    const unsigned *sp = s_px + rr_ * PX_STRIDE + piece * 4;
+                                    const unsigned *sp = s_px + TPX::row(rr_) + piece * 4;
                                     unsigned v[4] = { sp[0], sp[1], sp[2], sp[3] };
                                     if (blend) {
 #pragma unroll
@@ -506,7 +517,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                                 const int nr = s_nrows[rr_];
                                 if (nr > 0 && c < cnt) {
                                     const unsigned long long d = s_dst[rr_] + (size_t) (px0 + c) * 3;
-                                    int rgb3 = (int) s_px[rr_ * PX_STRIDE + c];
+                                    int rgb3 = (int) s_px[TPX::row(rr_) + c];
                                     if (blend) {
                                         const int o0 = (int) gload8(d), o1 = (int) gload8(d + 1), o2 = (int) gload8(d + 2);
                                         const int old = rgb_order ? (o0 << 16 | o1 << 8 | o2) : (o2 << 16 | o1 << 8 | o0);

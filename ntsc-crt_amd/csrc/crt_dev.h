@@ -431,6 +431,25 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
 #define WIDE_LPW8_MAX_WAVES 1440           /* k_decode_wide: 8 scanlines per wave while 16 per wave would make fewer waves than this (1080p: < 96 fields; measured: 32 fields -10 %, 64 -4 %, 128 +4 %) */
 #define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
 
+/* LDS tile of 64 rows x T dwords that one wave accesses in two ways: LANE PER ROW (every lane its own row, all lanes the same
+ * column) and COOPERATIVELY (row-contiguous 16-byte pieces: T / 4 lanes per row, each four consecutive dwords, as four dword --
+ * or two ds_read2 / ds_write2 -- accesses).  A dword access is served in two groups of 32 lanes over 32 banks
+ * (/opt/skills/guides/MI355X_MICROARCH.md, LDS).  The odd row stride T + 1 of rounds 1-5 makes the first pattern conflict-free
+ * for every T, the second only for T >= 32: with T = 16 a group covers 8 rows x 4 pieces and rows r and r + 4 meet on three of
+ * their four banks whatever the odd stride (2-way conflicts: SQ_LDS_BANK_CONFLICT 68 % of k_decode's LDS cycles in
+ * profiles/r05_headline_sq_counters.json -- free for the stores, whose cycles are set by their data path, twice the cycles for
+ * the drain's reads).  One pad dword per 32 / T ROWS instead of per row --
+ *     dword (row, col)  ->  row * T + (row >> log2(32 / T)) + col             (T = 16: row pairs 33 apart; T = 8: row quads)
+ * -- is conflict-free for BOTH patterns (exhaustive check over strides and pads: profiles/r06_lds_tile_layout.txt; T = 64, the
+ * 256-byte signal pieces, stays 2-way cooperatively whatever the layout: one row's 16 pieces are 64 consecutive dwords), costs
+ * nothing per access (the row term is a per-lane constant either way) and is a little smaller. */
+template <int T> struct TileRows {
+    static_assert(T == 8 || T == 16 || T == 32 || T == 64, "tile width in dwords");
+    static constexpr int SH = T == 16 ? 1 : 2;                                        /* (T < 32) */
+    static constexpr int DWORDS = T >= 32 ? 64 * (T + 1) : 64 * T + (64 >> SH);
+    __host__ __device__ static constexpr int row(int r) { return T >= 32 ? r * (T + 1) : r * T + (r >> SH); }
+};
+
 /* (r6) Workgroup order.  Workgroup b of a launch takes work item block_item(b): itself (K = 0: consecutive workgroups -- which
  * the dispatcher deals round robin over the 8 XCDs and which are resident together -- work on neighbouring scanlines of the same
  * pictures), or the launch's `total` items dealt out in K strides of per = ceil(total / K): consecutive workgroups are then `per`

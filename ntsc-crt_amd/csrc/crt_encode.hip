@@ -176,9 +176,11 @@ __device__ __forceinline__ bool format_blue_low(int format)
  * wave (11 instead of 8 waves per CU behind the image fetches). */
 template <int ACT, int OT = ACT>
 struct RowTiles {
-    static constexpr int TILE = ACT, STRIDE = ACT + 1, PIECES = ACT / 4;     /* 16-byte pieces per tile row */
+    static constexpr int TILE = ACT, PIECES = ACT / 4;                        /* 16-byte pieces per tile row */
+    using TP = TileRows<ACT>;                                                 /* row addressing of the two tiles (crt_dev.h): conflict-free */
+    using TO = TileRows<OT>;                                                  /*   lane-per-row and cooperatively                          */
     static constexpr int ROWS = 64 / PIECES;                                  /* rows per load instruction */
-    static constexpr int OTILE = OT, OSTRIDE = OT + 1, OPIECES = OT / 4, OROWS = 64 / OPIECES;
+    static constexpr int OTILE = OT, OPIECES = OT / 4, OROWS = 64 / OPIECES;
     unsigned *s_pix, *s_out;
     const unsigned long long *s_src, *s_dst;
     int lane, prow, piece, oprow, opiece;
@@ -231,13 +233,13 @@ struct RowTiles {
              * per-dword predicates (16 execute-mask round trips per tile as compiled before) */
 #pragma unroll
             for (int i = 0; i < PIECES; i++) {
-                unsigned *d = s_pix + (i * ROWS + prow) * STRIDE + piece * 4;
+                unsigned *d = s_pix + TP::row(i * ROWS + prow) + piece * 4;
                 d[0] = (unsigned) stage[i].x; d[1] = (unsigned) stage[i].y; d[2] = (unsigned) stage[i].z; d[3] = (unsigned) stage[i].w;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < PIECES; i++) {
-                unsigned *d = s_pix + (i * ROWS + prow) * STRIDE;
+                unsigned *d = s_pix + TP::row(i * ROWS + prow);
                 if (dw0 + 0 >= 0) d[dw0 + 0] = (unsigned) stage[i].x;
                 if (dw0 + 1 >= 0) d[dw0 + 1] = (unsigned) stage[i].y;
                 if (dw0 + 2 >= 0) d[dw0 + 2] = (unsigned) stage[i].z;
@@ -262,12 +264,12 @@ struct RowTiles {
             if (need < last_tile) fetch(need + 1);
         }
     }
-    __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[lane * STRIDE + (idx & (TILE - 1))]; }
-    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[lane * OSTRIDE + (g & (OTILE - 1))] = pack; }
+    __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[TP::row(lane) + (idx & (TILE - 1))]; }
+    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[TO::row(lane) + (g & (OTILE - 1))] = pack; }
     /* sample k of group g as one LDS byte store: no packing arithmetic on the vector unit */
     __device__ __forceinline__ void put_byte(int g, int k, int v)
     {
-        ((unsigned char *) s_out)[(lane * OSTRIDE + (g & (OTILE - 1))) * 4 + k] = (unsigned char) v;
+        ((unsigned char *) s_out)[(TO::row(lane) + (g & (OTILE - 1))) * 4 + k] = (unsigned char) v;
     }
     /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
     __device__ __forceinline__ void drain(int g0, int ng, int destw)
@@ -280,7 +282,7 @@ struct RowTiles {
             const int r = i * OROWS + oprow;
             const unsigned long long d = s_dst[r];
             if (d != 0 && opiece * 4 < ng && nbytes > 0) {
-                const unsigned *sp = s_out + r * OSTRIDE + opiece * 4;
+                const unsigned *sp = s_out + TO::row(r) + opiece * 4;
                 v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
 #if defined(ENC_DBG) && ENC_DBG == 1          /* measurement build: no signal stores (-128 never leaves the clamp) */
                 if (o.x != (int) 0x80808080) continue;
@@ -307,7 +309,7 @@ struct RowTiles {
         const unsigned long long d = s_dst[lane];
         if (d == 0) return;
         for (int x = destw - wrapn; x < destw; x++) {
-            const unsigned dw = s_out[lane * OSTRIDE + ((x >> 2) & (OTILE - 1))];
+            const unsigned dw = s_out[TO::row(lane) + ((x >> 2) & (OTILE - 1))];
             gstore8(d + (unsigned) (x + delta), dw >> (8 * (x & 3)));
         }
     }
@@ -358,8 +360,8 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
      * (crt_dev.h, sig_layout; wrapn = the row's samples that run over the end of its line) */
     using T = RowTiles<ACT, OT>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
-    __shared__ unsigned s_pix[64 * T::STRIDE];
-    __shared__ unsigned s_out[64 * T::OSTRIDE];
+    __shared__ unsigned s_pix[T::TP::DWORDS];
+    __shared__ unsigned s_out[T::TO::DWORDS];
     __shared__ unsigned long long s_src[64], s_dst[64];
 
     const int lane = threadIdx.x;
@@ -759,8 +761,8 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
 {
     using T = RowTiles<ACT>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
-    __shared__ unsigned s_pix[64 * T::STRIDE];
-    __shared__ unsigned s_out[64 * T::STRIDE];
+    __shared__ unsigned s_pix[T::TP::DWORDS];
+    __shared__ unsigned s_out[T::TO::DWORDS];
     __shared__ unsigned long long s_src[64], s_dst[64];
     __shared__ unsigned s_tab[NES_TAB_SIZE / 4];
 

@@ -127,3 +127,26 @@ def test_traffic_files_carry_a_source_hash_when_fresh():
     import bench
     h = bench.kernel_source_hash()
     assert len(h) == 16 and h == bench.kernel_source_hash()
+
+
+def test_committed_traffic_files_stand_beside_the_algorithmic_bytes():
+    """`roofline.traffic` is the counted HBM bytes of ALL kernels of a field-pass, printed beside the pass's
+    algorithmic bytes -- so their ratio must be >= 1 for every committed counter file (a ratio below 1 would mean the line compares a
+    part with the whole, as it did when `traffic` was the dominant kernel's bytes only)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    geo = {"headline": ("ntsc", 640, 480, 4, 640, 480), "1080p_batch2048": ("ntsc", 1920, 1080, 4, 1920, 1080),
+           "640x480_batch1": ("ntsc", 640, 480, 4, 640, 480), "bloom_batch4096": ("ntscbloom", 640, 480, 4, 640, 480),
+           "nes_pattern0": ("nesp0", 256, 240, 2, 640, 480), "pv1k_batch4096": ("pv1k", 640, 480, 4, 640, 480),
+           "vhs_832x624": ("vhs", 832, 624, 4, 832, 624)}
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json")))
+    assert files
+    for f in files:
+        tj = json.load(open(f))
+        system, w, h, in_bpp, outw, outh = geo[tj["workload"]]
+        abytes, own = bench.algorithmic_bytes(system, w, h, in_bpp, outw, outh, 4, 1, 0)
+        ratio = tj["all_kernels_bytes_per_field"] / abytes
+        assert ratio >= 1.0 and (ratio < 3.0 or tj["fields_per_launch"] < 64), (f, ratio)      # (one field per launch: the tables' traffic is not amortised)
+        dom = max(("decode", "active"), key=lambda k: tj.get("k_%s_bytes_per_field" % k, 0))
+        assert tj["k_%s_bytes_per_field" % dom] < tj["all_kernels_bytes_per_field"]

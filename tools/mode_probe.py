@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=6)
     args = ap.parse_args()
-    orders = [1, 8, 64, 256, -1]
+    orders = [int(x) for x in os.environ.get("MODE_ORDERS", "1,8,64,256,-1").split(",")]
     print("k_decode_wide<SysNTSC, 16>, 1920x1080 x 2048, per process: mean of 10 launches, then the 10 launches one by one (synchronised), rocm-smi after")
     for r in range(args.procs):
         for k in orders:
@@ -27,9 +27,9 @@ def main():
                 out = subprocess.run([sys.executable, os.path.join(HERE, "placement_sweep.py"), "--child", "0"], env=env, stdout=subprocess.PIPE,
                                      stderr=subprocess.DEVNULL, timeout=300).stdout.decode()
                 j = json.loads(out.strip().splitlines()[-1])
-                print("round %d order %4d | decode %.3f active %.3f fieldpass %.3f | %s | %s" % (
+                print("round %d order %4d | decode %.3f active %.3f fieldpass %.3f | %s | %s | %s" % (
                     r, k, j["decode_ms"], j["active_ms"], j["fieldpass_ms"], " ".join("%.2f" % v for v in j["series"]["decode"]),
-                    json.dumps(j.get("smi"))[:400]))
+                    json.dumps(j.get("ptrs")), json.dumps(j.get("smi"))[:300]))
             except Exception as ex:                               # noqa: BLE001
                 print("round %d order %d failed: %s" % (r, k, ex))
             sys.stdout.flush()

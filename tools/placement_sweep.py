@@ -63,6 +63,7 @@ def child(pad, batch, steps, warmup, w=1920, h=1080, noise=0):
     for name, (ms, cnt) in pr.items():
         rec[name + "_ms"] = round(ms / steps, 4)
     rec["out_ptr_mod_64k"] = out.data_ptr() % 65536
+    rec["ptrs"] = {"out": hex(out.data_ptr()), "images": hex(images.data_ptr()), "state": hex(g.state.data_ptr())}
     if os.environ.get("SWEEP_SERIES"):
         # per-launch durations (is a slow process slow in every launch?) and the board's state
         series = {"decode": [], "active": []}
