@@ -62,12 +62,18 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
     static_assert(S::CCS == 4, "tiers 0 / 1 of the 4-samples-per-cycle systems");
     static_assert(LPW == 16 || LPW == 8, "scanlines per wave");
     constexpr int RING = WIDE_RING;
-    constexpr int IN_DW = 16, IN_STRIDE = IN_DW + 1;
+    constexpr int IN_DW = 16, IN_STRIDE = IN_DW + 1;      /* (IN_STRIDE: the allocation; rows are addressed by TileRows, crt_dev.h) */
+    using TIN = TileRows<IN_DW>;
     /* LDS, 13.5 KB (12 waves per CU): the { q, i } ring -- one dword per sample --, the luma ring -- 16-bit values, scanlines l and
      * l + 8 sharing a dword so that both rings are addressed by sample * 4 -- and the input tile (64 samples per scanline).
      * A scanline's ring is 129 dwords apart from the next and the luma ring starts 16 banks after the chroma ring: the filter stage
      * stores sample x of all 16 scanlines with ONE instruction, and at a stride of 128 dwords its 32-lane halves met on a single bank
-     * (SQ_LDS_BANK_CONFLICT: 80 % of all LDS cycles, the filter stage alone 1.35 ms at 1080p x 2048 -- profiles/r04_experiments.txt 10) */
+     * (SQ_LDS_BANK_CONFLICT: 80 % of all LDS cycles, the filter stage alone 1.35 ms at 1080p x 2048 -- profiles/r04_experiments.txt 10).
+     * What the counter still shows (121 M of 308 M LDS cycles per launch, profiles/r06_1080p_sq_counters.json) is by design: the I and
+     * the Q lane of a scanline file the two halves of ONE dword (two 16-bit stores to one bank; a single store would cost two more
+     * vector instructions per sample and lane), and the pixel stage's taps are a gather -- lane l reads sample 1.57 l of the ring, so
+     * lanes 20 apart meet on a bank (2-way; 16 reads beside 110 vector instructions per scanline and run).  Neither is on the
+     * kernel's critical resource (its picture stores); the input tile's rows are conflict-free since round 6 (TileRows). */
     constexpr int RSTRIDE = RING + 1;
     constexpr int OFF_IQ = 0, OFF_Y = LPW * RSTRIDE * 4 + (LPW == 8 ? 32 : 0), OFF_IN = OFF_Y + 8 * RSTRIDE * 4 + (LPW == 8 ? 32 : 0);
     static_assert((OFF_Y / 4) % 32 == 16 && OFF_IN % 16 == 0, "bank offset of the luma ring, alignment of the input tile");
@@ -151,14 +157,14 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
             if (t != have_tile) {
                 wave_lds_fence();
                 if (has_line) {
-                    unsigned *d = s_in + l * IN_STRIDE + c * 4;
+                    unsigned *d = s_in + TIN::row(l) + c * 4;
                     d[0] = (unsigned) nxt.x; d[1] = (unsigned) nxt.y; d[2] = (unsigned) nxt.z; d[3] = (unsigned) nxt.w;
                 }
                 wave_lds_fence();
                 have_tile = t;
                 if (t + 1 < NT) nxt = gload16u(src + (t + 1) * (IN_DW * 4) + c * 16);
             }
-            const int word = (int) s_in[(has_line ? l : 0) * IN_STRIDE + (xq & (IN_DW - 1))];
+            const int word = (int) s_in[TIN::row(has_line ? l : 0) + (xq & (IN_DW - 1))];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int x = xq * 4 + k;

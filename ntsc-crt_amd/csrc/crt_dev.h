@@ -182,6 +182,8 @@ template <class S> __device__ __forceinline__ int carrier_row(int n, int field, 
 template <class S> struct PadGeom {
     static constexpr int PITCH = (S::HRES + 64 + 127) / 128 * 128;
     static constexpr int PADW = PITCH - S::HRES;                       /* bytes behind a line (114 for NTSC) */
+    static constexpr int PADC = PADW < 96 ? PADW : 96;                 /* ... of which the margin kernel fills at most this many with the copy (what the
+                                                                          windows need is 80: six 16-byte chunks per line, every store counts there) */
     static constexpr int DECWIN = (((S::AV_LEN + 3) / 4 + 15) / 16) * 64;   /* bytes every decoder shape reads from crthip_line.pos at most */
     static constexpr int SCR_LINE0 = S::VRES + 1;                      /* first scratch row (one per decoded line) */
     static constexpr size_t FSTRIDE = (size_t) (S::VRES + 1 + S::LINES) * PITCH;

@@ -447,6 +447,16 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         const int ky0 = blue_low ? 7471 : 19595, ky1 = 38470, ky2 = blue_low ? 19595 : 7471;
         const int ki0 = blue_low ? -21103 : 39059, ki1 = -18022, ki2 = blue_low ? 39059 : -21103;
         const int kq0 = blue_low ? 20382 : 13894, kq1 = -34275, kq2 = blue_low ? 13894 : 20382;
+        /* (r6) the same sums as TWO-term dot products: bytes 0 and 2 of the pixel side by side as 16-bit halves (one v_perm), their
+         * two coefficients packed into one scalar register, byte 1 (green) times its coefficient through the accumulator --
+         * v_mul_u32_u24_sdwa + v_dot2_i32_i16 per row instead of three multiplies and a three-operand add.  A packed coefficient
+         * must fit 16 signed bits: 38470 (Y) and -34275 (Q) are green's, i.e. the lone multiply's; the I row's 39059 goes in as
+         * 32767 + 6292, the second part by a second dot product whose other half is 0.  Exact integer sums, below 2^31: the same
+         * values bit for bit.  15 -> 11 vector instructions per pixel (the encoder runs at its arithmetic, profiles/r06_ab_*). */
+        const int kyp = (ky2 << 16) | ky0, kqp = (int) (((unsigned) kq2 << 16) | ((unsigned) kq0 & 0xffffu));
+        const int ki0a = ki0 > 32767 ? 32767 : ki0, ki2a = ki2 > 32767 ? 32767 : ki2;
+        const int kipa = (int) (((unsigned) ki2a << 16) | ((unsigned) ki0a & 0xffffu));
+        const int kipb = (int) (((unsigned) (ki2 - ki2a) << 16) | ((unsigned) (ki0 - ki0a) & 0xffffu));
 
         /* FAST + cooperative tiles: the three one-pole low-passes (iirf, crt_ntsc.c:117-126) as one v_mad_i64_i32
          * each.  h' = h + ((c*(s-h)) >> 11) is the high half of (c << 21)*(s-h) + {0, h}; for c >= 1024 the
@@ -464,9 +474,11 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
         /* loop invariants the compiler would otherwise re-materialise per sample (constant-bus limit of VOP3) */
         int neg_noise127 = -0x7f * noise;
         asm volatile("" : "+v"(neg_noise127));
-        int neg_noise127_256 = -0x7f * noise * 256, ire_base_1024 = ire_base * 1024;
+        int neg_noise127_256 = -0x7f * noise * 256, ire_base_1024 = ire_base * 1024, ire_base_65536 = ire_base * 65536;
+        const int white64 = white * 64;
         asm volatile("" : "+v"(neg_noise127_256));
         asm volatile("" : "+v"(ire_base_1024));
+        asm volatile("" : "+v"(ire_base_65536));
         const int noise256 = noise * 256;
         v2u lcg_add = { LCG_ADD, 0u };
         asm volatile("" : "+v"(lcg_add));
@@ -501,11 +513,19 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                             asm volatile("" : "+v"(pixel));
                         }
                         const int c0 = pixel & 255, c1 = (pixel >> 8) & 255, c2 = (pixel >> 16) & 255;
-                        const int y_ = (ky0 * c0 + ky1 * c1 + ky2 * c2) >> 14;
+                        int y_;
+                        if (FAST && IN4) {
+                            const int p02 = (int) __builtin_amdgcn_perm(pixel, pixel, 0x0c020c00u);     /* { byte 2, byte 0 } as 16-bit halves */
+                            y_ = dot2_vs(p02, kyp, ky1 * c1) >> 14;
+                            fi = dot2_vs(p02, kipb, dot2_vs(p02, kipa, ki1 * c1)) >> 14;
+                            fq = dot2_vs(p02, kqp, kq1 * c1) >> 14;
+                        } else {
+                            y_ = (ky0 * c0 + ky1 * c1 + ky2 * c2) >> 14;
+                            fi = (ki0 * c0 + ki1 * c1 + ki2 * c2) >> 14;
+                            fq = (kq0 * c0 + kq1 * c1 + kq2 * c2) >> 14;
+                        }
                         if (I64) fyp = (fyp & ~HI_HALF) | (long) ((unsigned long) (unsigned) y_ << 32);
                         else fy = y_;
-                        fi = (ki0 * c0 + ki1 * c1 + ki2 * c2) >> 14;
-                        fq = (kq0 * c0 + kq1 * c1 + kq2 * c2) >> 14;
                         have_col = col;
                     }
                     if (I64) {
@@ -540,20 +560,25 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                          * shift is "take the high word" and both ride on the add;
                          * base + (v * white >> 10) == (v * white + (base << 10)) >> 10: one multiply-add */
                         const int miq = add_hiwords(__mul24(oi, ccI), __mul24(oq, ccQ));
-                        ire = mad24_vv(oy + miq, white, ire_base_1024) >> 10;
+                        /* (r6) with noise to add, the >> 10 is not taken at all: white and the base scaled by another 2^6 leave the
+                         * level in the HIGH word, the clamp to [0, 110] works on the scaled value (monotone: same result), and the
+                         * noise add below takes the high words of both its operands (|white| < 2^17, host-checked) */
+                        if (NOISE) ire = mad24_vv(oy + miq, white64, ire_base_65536);
+                        else ire = mad24_vv(oy + miq, white, ire_base_1024) >> 10;
                     } else {
                         const int mi = (oi * ccI) >> 4;
                         const int mq = (oq * ccQ) >> 4;
                         ire = ire_base + (((oy + mi + mq) * white) >> 10);
                     }
-                    ire = clampi(ire, 0, 110);
+                    if (FAST && NOISE) ire = clampi(ire, 0, (110 << 16) | 0xffff);
+                    else ire = clampi(ire, 0, 110);
                     if (NOISE) {
                         rn = lcg_step_mad64(rn, lcg_add);
                         const int nb = (int) ((rn >> 16) & 0xffu);
                         if (FAST) {
                             /* ((byte - 0x7f) * noise) >> 8 added to ire: the product scaled by 256 so that the
                              * shift becomes "take the high word" and rides on the add (|noise| < 2^15 on this path) */
-                            ire = add_hiword(ire, mad24_vv(nb, noise256, neg_noise127_256));
+                            ire = add_hiwords(ire, mad24_vv(nb, noise256, neg_noise127_256));
                         } else {
                             ire += (nb * noise + neg_noise127) >> 8;
                         }
@@ -986,7 +1011,7 @@ k_margin(const crthip_params P, int n_fields, signed char *__restrict__ dst, siz
  *     lines [yo, yo + desth)                 left of the row  [a0, xo)  (CL chunks)  and right of it  [xo + destw, HRES)  (CR chunks)
  *     lines [yo + desth, VRES)               [a0, HRES)
  * a0 = wrap for a line whose predecessor carries an active row (the row's last `wrap` samples run into this line: k_active's), else 0.
- * A chunk that lies inside the first PADW columns of line n >= 1 is stored a second time behind line n - 1 (the copy that makes
+ * A chunk that lies inside the first PADC columns of line n >= 1 is stored a second time behind line n - 1 (the copy that makes
  * windows over a line end contiguous); chunks that only partly do are not -- `padv` (crt_fused_layout) is what that guarantees. */
 template <class S, bool NOISE>
 __global__ void __launch_bounds__(256)
@@ -1021,7 +1046,7 @@ k_margin_pad(const crthip_params P, int n_fields, signed char *__restrict__ dst,
     if (hi - lo >= 16) { if (col > hi - 16) col = hi - 16; }         /* the interval's last chunk ends with it (it overlaps its neighbour: same bytes) */
     else { if (k > 0 || hi <= lo) return; len = hi - lo; }              /* an interval shorter than a chunk: bytes */
     const int idx0 = line * S::HRES + col;                             /* flat sample index: skeleton and noise are functions of it */
-    const bool copy = line >= 1 && col + len <= G::PADW;
+    const bool copy = line >= 1 && col + len <= G::PADC;
   for (int f = blockIdx.y; f < n_fields; f += (int) gridDim.y) {
     const crthip_state *st = state + f;
     const int var = skeleton_variant<S>(st->field, st->frame, st->aux);
@@ -1080,7 +1105,11 @@ static bool encoder_fast_ok(const crthip_params *p)
 {
     const int wh = p->white < 0 ? -p->white : p->white;
     const int nz = p->noise < 0 ? -p->noise : p->noise;
-    bool ok = wh < (1 << 23) && nz < (1 << 15);                   /* noise * 256 is a 24-bit multiplier in k_active */
+    const int ib = p->ire_base < 0 ? -p->ire_base : p->ire_base;
+    /* noise * 256 is a 24-bit multiplier in k_active; (y + i + q) * white * 64 + (ire_base << 16) must not wrap: |y + i + q| <= 1020 +
+     * 608 + 533 (8-bit pixels through crt_ntsc.c:307-309, carriers <= 16 / 16), so 2161 * 2^13 * 64 + 2^13 * 2^16 < 2^31.  (Rounds 1-5
+     * let white up to 2^23 into the fast kernels, where the product could wrap differently from the reference's; nothing sane is near.) */
+    bool ok = wh < (1 << 13) && ib < (1 << 13) && nz < (1 << 15);
     if (p->flags & CRTHIP_F_HIPASS) ok = false;                   /* the debug build's high-pass lives in the exact kernels */
     for (int r = 0; r < CRTHIP_CARRIER_ROWS; r++)                  /* ... and so are the carriers * 4096 */
         for (int k = 0; k < CRTHIP_MAX_CCS; k++)
@@ -1136,7 +1165,8 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
                                          : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
         if (in4 && big) {
 #define CRTHIP_LAUNCH_ACTIVE_BIG(NZ) \
-    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
+    do { if (wide_in && c->sig_tile_env == 32) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
+         else if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
          else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); } while (0)
             if (noise) CRTHIP_LAUNCH_ACTIVE_BIG(true); else CRTHIP_LAUNCH_ACTIVE_BIG(false);
 #undef CRTHIP_LAUNCH_ACTIVE_BIG

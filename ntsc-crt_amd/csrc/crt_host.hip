@@ -190,7 +190,7 @@ bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, sig_layout *l
         const int over = p->xo + p->destw - S::HRES, wrap = over > 0 ? over : 0;
         if (wrap > 16 || p->xo < G::PADW || p->destw < 16 || p->yo < 0 || p->yo + p->desth + (wrap ? 1 : 0) > S::VRES) return 0;
         /* k_margin_pad copies whole 16-byte chunks: [wrap, wrap + 16 m) behind a line that carries a row, [0, 16 m') elsewhere */
-        const int a = wrap + (G::PADW - wrap) / 16 * 16, b = G::PADW / 16 * 16;
+        const int a = wrap + (G::PADC - wrap) / 16 * 16, b = G::PADC / 16 * 16;
         const int padv = a < b ? a : b;
         if (padv < 80) return 0;
         lay->pitch = G::PITCH;
