@@ -1165,8 +1165,7 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
                                          : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
         if (in4 && big) {
 #define CRTHIP_LAUNCH_ACTIVE_BIG(NZ) \
-    do { if (wide_in && c->sig_tile_env == 32) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
-         else if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
          else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); } while (0)
             if (noise) CRTHIP_LAUNCH_ACTIVE_BIG(true); else CRTHIP_LAUNCH_ACTIVE_BIG(false);
 #undef CRTHIP_LAUNCH_ACTIVE_BIG
