@@ -29,7 +29,7 @@ def main():
                 j = json.loads(out.strip().splitlines()[-1])
                 print("round %d order %4d | decode %.3f active %.3f fieldpass %.3f | %s | %s | %s" % (
                     r, k, j["decode_ms"], j["active_ms"], j["fieldpass_ms"], " ".join("%.2f" % v for v in j["series"]["decode"]),
-                    json.dumps(j.get("ptrs")), json.dumps(j.get("smi"))[:300]))
+                    json.dumps(j.get("ptrs")), json.dumps(j.get("under_load"))))
             except Exception as ex:                               # noqa: BLE001
                 print("round %d order %d failed: %s" % (r, k, ex))
             sys.stdout.flush()

@@ -75,6 +75,51 @@ def child(pad, batch, steps, warmup, w=1920, h=1080, noise=0):
                 series[nm].append(round(pr[nm][0], 3))
         g.profile(False)
         rec["series"] = series
+        # the board's clocks and power WHILE the field-passes run (sysfs, sampled from a thread every 20 ms over ~1.5 s of launches)
+        import glob
+        import threading
+        devs = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(d + "/pp_dpm_mclk")]
+        samples, stop = [], threading.Event()
+
+        def active_level(path):
+            try:
+                for line in open(path):
+                    if line.rstrip().endswith("*"):
+                        return line.split(":")[1].strip().rstrip("*").strip()
+            except OSError:
+                return None
+            return None
+
+        def sampler():
+            d = devs[0]
+            hw = (glob.glob(d + "/hwmon/hwmon*") or [None])[0]
+            while not stop.is_set():
+                row = {k: active_level("%s/pp_dpm_%s" % (d, k)) for k in ("sclk", "mclk", "fclk", "socclk")}
+                if hw:
+                    for name, f in (("power_uW", "power1_average"), ("power_in_uW", "power1_input"), ("temp_junction_mC", "temp2_input"), ("temp_mem_mC", "temp3_input")):
+                        try:
+                            row[name] = int(open(hw + "/" + f).read())
+                        except (OSError, ValueError):
+                            pass
+                samples.append(row)
+                time.sleep(0.02)
+        if devs:
+            th = threading.Thread(target=sampler)
+            th.start()
+            for k in range(400):
+                step(k)
+            torch.cuda.synchronize()
+            stop.set()
+            th.join()
+            import collections
+            summ = {}
+            for key in ("sclk", "mclk", "fclk", "socclk"):
+                summ[key] = dict(collections.Counter(r_.get(key) for r_ in samples))
+            for key in ("power_uW", "power_in_uW", "temp_junction_mC", "temp_mem_mC"):
+                vals = [r_[key] for r_ in samples if key in r_]
+                if vals:
+                    summ[key] = [min(vals), max(vals)]
+            rec["under_load"] = summ
         try:
             smi = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower", "--json"], stdout=subprocess.PIPE,
                                  stderr=subprocess.DEVNULL, timeout=30).stdout.decode()
