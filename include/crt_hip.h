@@ -362,9 +362,10 @@ int  crthip_set_signal_tile(crthip_ctx *ctx, int dwords);
  * signal crthip_fieldpass keeps in its own workspace between its encoder and its decoder is not visible to anybody; by default
  * (1) it lives in PADDED lines -- 1024 bytes apart (2048 for the PV-1000's 1920-sample lines), active rows on 128-byte boundaries,
  * the head of every line repeated behind its predecessor so that windows over a line end stay contiguous -- which is what lets the
- * encoder store whole aligned cache lines.  0 = the flat layout there too (A/B measurements; also what geometries the padded
- * layout does not cover fall back to: row overhangs of more than 16 samples, x offsets that put the row before column 114, the
- * rand()-noise VHS build, CRT_DO_VSYNC 0).  Same pictures and states either way.  Environment: CRTHIP_SIG_PAD sets the default
+ * encoder store whole aligned cache lines.  0 = the flat layout there too (A/B measurements; also what the library takes by itself
+ * where the padded layout does not reach or does not pay: row overhangs of more than 16 samples, x offsets that put the row before
+ * column 114, the rand()-noise VHS build, CRT_DO_VSYNC 0, the NES's PPU-pixel encoder, and the batches of up to 256 fields that go to
+ * the scanline-parallel encoder).  Same pictures and states either way.  Environment: CRTHIP_SIG_PAD sets the default
  * of new contexts.
  * crthip_fieldpass_signal: the noisy signal of the first n fields of the context's LAST crthip_fieldpass, repacked into the
  * reference's layout (n fields at crthip_field_stride() spacing: CRT_INPUT_SIZE samples + the CRTHIP_TAIL mirror), i.e. what

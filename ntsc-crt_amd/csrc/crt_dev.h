@@ -663,7 +663,7 @@ static inline int crt_ensure_aux(crthip_ctx *c)
 /* launch entry points of the other translation units (enqueue on c->stream; no synchronisation) */
 int crt_run_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                     signed char *dst, crthip_state *d_state, bool fused, int nes_setup, bool with_state, const sig_layout *lay = nullptr);
-bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, sig_layout *lay);
+bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, int n, sig_layout *lay);
 int crt_run_unpad(crthip_ctx *c, int n, const sig_layout *lay, const signed char *d_src, signed char *d_dst);
 int crt_run_encoder_state(crthip_ctx *c, const crthip_params *p, int n, crthip_state *d_state);
 int crt_run_encoder_prepare(crthip_ctx *c, const crthip_params *p, bool fused);

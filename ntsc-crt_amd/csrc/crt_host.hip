@@ -179,11 +179,19 @@ int crt_run_unpad(crthip_ctx *c, int n, const sig_layout *lay, const signed char
  *   the row's overhang over its line (wrap = xo + destw - HRES) is at most 16 samples and ends inside the field,
  *   the row starts at or behind column PADW (what is copied behind a line is then margin, never picture), and
  *   the copies the margin kernel makes reach at least 80 columns (sync windows: 69, burst windows: 48 / 64)
- * -- and the flat layout otherwise (odd x offsets, the rand()-noise VHS build, CRT_DO_VSYNC 0, crthip_set_signal_layout(ctx, 0)). */
-bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, sig_layout *lay)
+ * -- and the flat layout otherwise (odd x offsets, the rand()-noise VHS build, CRT_DO_VSYNC 0, the NES, small batches,
+ * crthip_set_signal_layout(ctx, 0)). */
+bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, int n, sig_layout *lay)
 {
     lay->pitch = c->sd.hres; lay->shift = 0; lay->padv = 0; lay->wrap = 0; lay->fstride = c->fstride;
     if (!c->sig_pad || c->system == CRTHIP_SYSTEM_NTSCVHS || (p->flags & CRTHIP_F_NO_VSYNC)) return false;
+    /* ... and only where it pays (profiles/r06_ab_padded_by_system.txt, one box, padded against flat): the lane-per-row RGB encoder,
+     * whose row stores it aligns -- NTSC 640x480 x 1024 +5 %, SNES +5.6 %, PV-1000 +4.5 %, bloom +5.4 % -- but not the NES's table
+     * encoder (never store-bound: the margin kernel's copies cost 1.1 % and buy nothing) and not the batches the library gives to the
+     * scanline-parallel encoder by itself (dword stores per lane: 640x480 x 64 -0.8 %, 1080p x 64 -3.5 %).  A FORCED scanline-parallel
+     * shape keeps the padded lines (tests run k_active_row's padded stores that way). */
+    if (c->sd.ppu_input) return false;
+    if (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS_ENC) return false;
     return dispatch_system(c->system, c->pattern, [&](auto tag) {
         using S = decltype(tag);
         using G = PadGeom<S>;
@@ -605,7 +613,7 @@ int crthip_fieldpass(crthip_ctx *c, const crthip_params *p, int n, const void *d
     /* the signal between this call's encoder and decoder: padded lines where the fused LCG-noise encoder writes it (crt_dev.h) */
     sig_layout lay;
     const bool vhs_rand_path = c->system == CRTHIP_SYSTEM_NTSCVHS && !(p->flags & CRTHIP_F_VHS_LCG_NOISE);
-    if (enc != 0 || vhs_rand_path || !crt_fused_layout(c, p, &lay)) {
+    if (enc != 0 || vhs_rand_path || !crt_fused_layout(c, p, n, &lay)) {
         lay.pitch = c->sd.hres; lay.shift = 0; lay.padv = 0; lay.wrap = 0; lay.fstride = c->fstride;
     }
     c->last_lay = lay;

@@ -352,10 +352,39 @@ def test_scanline_parallel_wide_variant_on_ordinary_inputs(crtlib, case, mode):
 
 
 def test_library_picks_the_shape_by_batch_size(crtlib):
-    """crthip_set_shape(0): small batches -> scanline-parallel, large ones -> lane-per-scanline; same pictures"""
-    _run_case(crtlib, CASES[1], fused=True, shape=0, steps=2, n=2)
+    """crthip_set_shape(0): small batches -> scanline-parallel, large ones -> lane-per-scanline; same pictures.  The signal layout
+    follows the encoder (round 6, crt_fused_layout): flat lines with the scanline-parallel encoder the library picks for up to 256
+    fields, padded lines with the lane-per-row one."""
+    _run_case(crtlib, CASES[1], fused=True, shape=0, steps=2, n=2, want_padded=False)
     _run_case(crtlib, ("ntsc", 96, 240, R.FMT_BGRA, 64, 48, R.FMT_BGRA, 24, dict(as_color=1), dict(scanlines=1)),
-              fused=True, shape=0, steps=1, n=300)
+              fused=True, shape=0, steps=1, n=300, want_padded=True)
+
+
+def test_the_nes_keeps_flat_signal_lines(crtlib):
+    """... and the NES's PPU-pixel encoder (a table look-up per sample, never store-bound) keeps the reference's flat lines: the copies
+    behind padded lines cost its margin kernel more than the alignment gives (profiles/r06_ab_padded_by_system.txt); NES-RGB, an RGB
+    encoder with the NES's timing, takes the padded ones."""
+    import torch
+    n = 3
+    ppu = np.stack([R.synth_ppu(256, 240, 900 + k) for k in range(n)])
+    full = torch.zeros((n, 241, 256), dtype=torch.int16, device="cuda:0")
+    full[:, :240] = torch.from_numpy(ppu.astype(np.int16)).to("cuda:0")
+    g = crtlib.CRT(n, 640, 480, crtlib.FMT_BGRA, "nes", device=0)
+    g.set_shape(1)
+    g.fieldpass(crtlib.Settings(full[:, :240], hue=0, dot_crawl_offset=[k % 3 for k in range(n)]), 12)
+    g.synchronize()
+    sig, padded = g.fieldpass_signal()
+    assert not padded
+    orc = R.Oracle("nes")
+    for k in range(n):
+        c = orc.new_crt(640, 480, R.FMT_BGRA)
+        c.settings(np.concatenate([ppu[k], ppu[k][-1:]], axis=0), w=256, h=240, dot_crawl_offset=k % 3, hue=0)
+        c.modulate()
+        c.demodulate(12)
+        np.testing.assert_array_equal(sig[k, :orc.input_size].cpu().numpy(), c.inp, err_msg="NES field %d: inp of the fused path" % k)
+        np.testing.assert_array_equal(g.out[k].cpu().numpy().reshape(-1), c.out)
+    g.close()
+    _run_case(crtlib, ("nesrgb",) + F4_CASES[1], fused=True, steps=2, want_padded=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------
