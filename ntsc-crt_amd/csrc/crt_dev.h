@@ -429,6 +429,7 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * more than the pieces give (profiles/r04_experiments.txt section 19, profiles/r05_experiments.txt sections 2-4) */
 #define SIG_TILE64_MIN_WAVES_WIDE 6144     /* wide image tile (w >= 1280): 256-byte pieces */
 #define SIG_TILE32_MIN_WAVES      6720     /* narrow image tile: 128-byte pieces */
+#define MARGIN_SIDE_MIN_FIELDS 512         /* launch_encoder: k_margin on the internal stream beside k_active from this many fields on */
 #define SYNC_FPB4_MIN_FIELDS 768            /* k_hsync_wave: four fields per workgroup from here on, one below (crt_sync.hip) */
 #define WIDE_LPW8_MAX_WAVES 1440           /* k_decode_wide: 8 scanlines per wave while 16 per wave would make fewer waves than this (1080p: < 96 fields; measured: 32 fields -10 %, 64 -4 %, 128 +4 %) */
 #define WIDE_SHAPE_MIN_FIELDS 32           /* wide pictures: k_decode_wide instead of k_decode_row from here on (crt_decode.hip) */
@@ -555,6 +556,8 @@ struct crthip_ctx {
     int overlap_chunks;         /* crthip_fieldpass: chunks alternating between two streams (1 = off) */
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join, ev_chunk[CRTHIP_MAX_CHUNKS];
+    hipEvent_t ev_mfork, ev_mjoin;   /* the margin kernel beside the active-video kernel (crt_encode.hip, launch_encoder) */
+    int margin_side;            /* CRTHIP_MARGIN_SIDE: 1 (default) = large fused batches run k_margin on the internal stream beside k_active, 0 = in sequence (A/B) */
     bool prof;
     double prof_ms[CRTHIP_K_COUNT];
     int prof_n[CRTHIP_K_COUNT];
@@ -657,6 +660,8 @@ static inline int crt_ensure_aux(crthip_ctx *c)
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return CRTHIP_E_HIP;
     for (int k = 0; k < CRTHIP_MAX_CHUNKS; k++)
         if (hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming) != hipSuccess) return CRTHIP_E_HIP;
+    if (hipEventCreateWithFlags(&c->ev_mfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_mjoin, hipEventDisableTiming) != hipSuccess) return CRTHIP_E_HIP;
     return CRTHIP_OK;
 }
 

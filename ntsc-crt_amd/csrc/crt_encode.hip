@@ -1235,9 +1235,26 @@ template <class S, bool FULL>
 static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const void *d_images, size_t istride,
                           signed char *dst, const crthip_state *d_state, int nes_setup, const sig_layout &lay)
 {
+    /* (r6) The margins and the active rows are disjoint bytes and independent work: the margin kernel is bound by its stores (16 bytes
+     * per lane, the copies behind padded lines on top), the active-video kernel by its arithmetic since its rows are aligned -- so for
+     * batches that fill the chip the first runs on the context's internal stream BESIDE the second, fenced by events on both sides
+     * (to the caller everything is still ordered on its stream; captured into a graph it is a fork and a join).  Not while a profile
+     * is being taken (per-kernel durations are of kernels running alone), not on the internal stream itself (overlap chunks).
+     * CRTHIP_MARGIN_SIDE=0: in sequence (A/B: profiles/r06_ab_margin_side.txt). */
+    bool side = false;
     if (FULL) {
+        side = c->margin_side && c->aux_stream && c->ev_mfork && !c->prof && n >= MARGIN_SIDE_MIN_FIELDS && c->stream != c->aux_stream;
+        hipStream_t main_stream = c->stream;
+        if (side) {
+            if (hipEventRecord(c->ev_mfork, main_stream) != hipSuccess || hipStreamWaitEvent(c->aux_stream, c->ev_mfork, 0) != hipSuccess) side = false;
+            else c->stream = c->aux_stream;
+        }
         if (lay.pitch != S::HRES) launch_margins_padded<S>(c, p, n, dst, d_state, lay);
         else launch_margins<S>(c, p, n, dst, d_state);
+        if (side) {
+            c->stream = main_stream;
+            if (hipEventRecord(c->ev_mjoin, c->aux_stream) != hipSuccess) return CRTHIP_E_HIP;
+        }
     } else {
         constexpr int CHUNKS = (S::INPUT_SIZE + 15) / 16;
         ProfScope ps(c, CRTHIP_K_TEMPLATE);
@@ -1246,6 +1263,7 @@ static int launch_encoder(crthip_ctx *c, const crthip_params *p, int n, const vo
                            *p, n, dst, c->fstride, d_state, nes_setup);
     }
     launch_active_any<S, FULL>(c, p, n, d_images, istride, dst, d_state, lay);
+    if (side && hipStreamWaitEvent(c->stream, c->ev_mjoin, 0) != hipSuccess) return CRTHIP_E_HIP;
     return CRTHIP_OK;
 }
 

@@ -256,6 +256,7 @@ int crthip_create(crthip_ctx **out, int device, int system, int chroma_pattern)
     { const char *e = getenv("CRTHIP_WIDE_DECODE"); c->wide_decode = e ? atoi(e) != 0 : 1; }     /* A/B switch, crt_decode4.hip */
     { const char *e = getenv("CRTHIP_AC_TILE"); c->ac_tile_env = e && (atoi(e) == 16 || atoi(e) == 32) ? atoi(e) : 0; }   /* A/B switch, k_active */
     { const char *e = getenv("CRTHIP_WIDE_LPW"); c->wide_lpw_env = e && (atoi(e) == 8 || atoi(e) == 16) ? atoi(e) : 0; }   /* A/B switch, k_decode_wide */
+    { const char *e = getenv("CRTHIP_MARGIN_SIDE"); c->margin_side = e ? atoi(e) != 0 : 1; }   /* A/B switch: k_margin beside k_active (crt_encode.hip) */
     { const char *e = getenv("CRTHIP_SIG_PAD"); c->sig_pad = e ? atoi(e) != 0 : 1; }       /* A/B switch: the fused path's signal layout (crt_dev.h, sig_layout) */
     c->fstride_pad = 0;
     dispatch_system(system, chroma_pattern, [&](auto tag) { c->fstride_pad = PadGeom<decltype(tag)>::FSTRIDE; return CRTHIP_OK; });
@@ -355,6 +356,8 @@ void crthip_destroy(crthip_ctx *c)
     free(c->pend);
     if (c->aux_stream) {
         hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join);
+        if (c->ev_mfork) hipEventDestroy(c->ev_mfork);
+        if (c->ev_mjoin) hipEventDestroy(c->ev_mjoin);
         for (int k = 0; k < CRTHIP_MAX_CHUNKS; k++) hipEventDestroy(c->ev_chunk[k]);
     }
     if (c->d_jump16) hipFree(c->d_jump16);
