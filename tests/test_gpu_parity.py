@@ -1543,7 +1543,7 @@ def test_full_batch_every_field_checked_against_the_oracle(crtlib):
         assert (int(st[k, crtlib.ST_HSYNC]), int(st[k, crtlib.ST_VSYNC]), int(st[k, crtlib.ST_RN])) == (hs, vs, rn), "field %d state" % k
 
 
-@pytest.mark.parametrize("name,shape", [("ntsc", 0), ("ntsc", 1), ("ntscbloom", 1), ("nes", 0), ("ntsc-1080p", 1)])
+@pytest.mark.parametrize("name,shape", [("ntsc", 0), ("ntsc", 1), ("ntscbloom", 1), ("nes", 0), ("ntsc-1080p", 1), ("ntsc-many", 0)])
 def test_fieldpass_is_graph_capturable(crtlib, name, shape):
     """crthip_fieldpass only enqueues kernels on the context's stream (no allocation, no synchronisation once the
     workspace is reserved -- the bloom build's sort scratch included), so a caller can capture the launch sequence into a
@@ -1552,8 +1552,13 @@ def test_fieldpass_is_graph_capturable(crtlib, name, shape):
     decoder (crt_decode4.hip); the bloom case is the one whose two memset nodes broke the second replay (round 4)."""
     import torch
     n, w, h = 6, 640, 480
+    ow = oh = None
     if name.endswith("-1080p"):
         name, n, w, h = name[:-6], 3, 1920, 1080
+    if name.endswith("-many"):
+        # round 6: from 512 fields on the margin kernel runs on the context's internal stream beside the active-video kernel --
+        # under capture a fork and a join inside the graph (crt_encode.hip, launch_encoder)
+        name, n, w, h, ow, oh = name[:-5], 640, 64, 48, 96, 240
     nes = name == "nes"
     if nes:
         ppu = np.stack([R.synth_ppu(256, 240, 40 + k) for k in range(n)])
@@ -1569,7 +1574,7 @@ def test_fieldpass_is_graph_capturable(crtlib, name, shape):
             return crtlib.Settings(imgs, format=crtlib.FMT_BGRA, field=[k & 1 for k in range(n)], frame=0)
 
     def context():
-        g = crtlib.CRT(n, w, h, crtlib.FMT_BGRA, name, device=0)
+        g = crtlib.CRT(n, ow or w, oh or h, crtlib.FMT_BGRA, name, device=0)
         g.scanlines = 1
         g.set_shape(shape)
         g.reserve(n)
