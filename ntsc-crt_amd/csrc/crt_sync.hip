@@ -170,8 +170,10 @@ template <class S, int FPB, bool PAD>
 __global__ void __launch_bounds__(64 * FPB, 4)
 k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict__ inp, size_t fstride,
              crthip_state *__restrict__ state, crthip_line *__restrict__ lines, uint2 whole_field, int advance_rn,
-             int preset_ccf, int shift, int padv)
+             int preset_ccf, int shift, int padv, signed char *__restrict__ scratch)
 {
+    /* scratch (PAD): the same workspace as inp, as the pointer the scratch rows behind every field are WRITTEN through (rows VRES + 1 ...;
+     * nothing this kernel reads lies there: its windows end in line VRES) */
     using G = PadGeom<S>;
     constexpr int LP = PAD ? G::PITCH : S::HRES;
     constexpr int CCS = S::CCS, NB = S::CB_LEN / S::CCS, VPER = S::VPER;
@@ -472,7 +474,7 @@ k_hsync_wave(const crthip_params P, int n_fields, const signed char *__restrict_
                         lp.pos = shift + ypos * G::PITCH + xpos;
                         if (xpos + G::DECWIN > S::HRES + padv) {
                             const int srow = shift + (G::SCR_LINE0 + (line - S::TOP)) * G::PITCH;
-                            signed char *scr = const_cast<signed char *>(inp) + (size_t) f * fstride + srow;
+                            signed char *scr = scratch + (size_t) f * fstride + srow;
                             for (int o = 0; o < G::DECWIN; o += 16) store16u(scr + o, load16u(in + sig_phys<S>(flat + o)));
                             lp.pos = srow;
                         }
@@ -686,7 +688,7 @@ int crt_run_sync(crthip_ctx *c, const crthip_params *p, int n, const signed char
         const bool fpb4 = FPB4_OK && c->sync_kernel != 2 && (n >= SYNC_FPB4_MIN_FIELDS || c->sync_kernel == 3);
 #define CRTHIP_LAUNCH_SYNC(FPB, PADV) \
     hipLaunchKernelGGL((k_hsync_wave<S, FPB, PADV>), dim3((n + FPB - 1) / FPB), dim3(64 * FPB), 0, c->stream, *p, n, d_inp, fstride, d_state, d_lines, \
-                       c->whole_field, advance_rn, preset_ccf, shift, padv)
+                       c->whole_field, advance_rn, preset_ccf, shift, padv, pad ? const_cast<signed char *>(d_inp) : nullptr)   /* (padded: the library's own workspace) */
         if constexpr (FPB4_OK) {
             if (fpb4) { if (pad) CRTHIP_LAUNCH_SYNC(4, true); else CRTHIP_LAUNCH_SYNC(4, false); }
         }
