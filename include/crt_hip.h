@@ -371,6 +371,12 @@ int  crthip_set_signal_tile(crthip_ctx *ctx, int dwords);
  * reference's layout (n fields at crthip_field_stride() spacing: CRT_INPUT_SIZE samples + the CRTHIP_TAIL mirror), i.e. what
  * crt_demodulate leaves in CRT.inp -- for parity tests of the fused path; *padded (optional) tells which layout it came from. */
 int  crthip_set_signal_layout(crthip_ctx *ctx, int padded);
+/* Host only (no device needed): which layout a crthip_fieldpass of n_fields with these (finalized) parameters takes under the default
+ * switches and kernel shape `shape` (crthip_set_shape) -- returns 1 = padded, 0 = flat, < 0 = error; layout[] = { bytes between line
+ * starts, bytes in front of line 0, valid copy bytes behind every line, samples of an active row beyond its line's end }, *field_stride
+ * = bytes between the fields of the workspace.  (What crthip_reserve sizes the workspace for, and what the CPU tests check the
+ * geometry rules with.) */
+int  crthip_signal_layout_query(const crthip_params *p, int n_fields, int shape, int layout[4], size_t *field_stride);
 int  crthip_fieldpass_signal(crthip_ctx *ctx, int n, signed char *d_inp_flat, int *padded);
 /* Wide-run decoder (wide pictures, crt_decode4.hip): scanlines per wavefront.  0 (default) = by batch size (8 below 96 fields of
  * 1920x1080, 16 from there on), 8 / 16 = always that instantiation.  Same pictures either way (tests pin each instantiation to the

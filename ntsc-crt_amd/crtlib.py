@@ -124,6 +124,7 @@ def load_library():
     L.crthip_set_signal_tile.argtypes = [vp, ci]
     L.crthip_set_wide_lpw.argtypes = [vp, ci]
     L.crthip_set_signal_layout.argtypes = [vp, ci]
+    L.crthip_signal_layout_query.argtypes = [PP, ci, ci, C.POINTER(ci), C.POINTER(sz)]
     L.crthip_fieldpass_signal.argtypes = [vp, ci, vp, C.POINTER(ci)]
     L.crthip_table_generation.argtypes = [vp]
     L.crthip_table_generation.restype = C.c_uint

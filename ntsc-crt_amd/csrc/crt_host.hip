@@ -181,18 +181,21 @@ int crt_run_unpad(crthip_ctx *c, int n, const sig_layout *lay, const signed char
  *   the copies the margin kernel makes reach at least 80 columns (sync windows: 69, burst windows: 48 / 64)
  * -- and the flat layout otherwise (odd x offsets, the rand()-noise VHS build, CRT_DO_VSYNC 0, the NES, small batches,
  * crthip_set_signal_layout(ctx, 0)). */
-bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, int n, sig_layout *lay)
+/* (the rule without a context: crthip_signal_layout_query lets a host -- and the CPU tests -- ask it) */
+static bool layout_rule(int system, int pattern, const struct crt_sysdef &sd, size_t flat_stride, const crthip_params *p, int n, int shape,
+                        int sig_pad, sig_layout *lay)
 {
-    lay->pitch = c->sd.hres; lay->shift = 0; lay->padv = 0; lay->wrap = 0; lay->fstride = c->fstride;
-    if (!c->sig_pad || c->system == CRTHIP_SYSTEM_NTSCVHS || (p->flags & CRTHIP_F_NO_VSYNC)) return false;
+    lay->pitch = sd.hres; lay->shift = 0; lay->padv = 0; lay->wrap = 0; lay->fstride = flat_stride;
+    if (!sig_pad || system == CRTHIP_SYSTEM_NTSCVHS || (p->flags & CRTHIP_F_NO_VSYNC)) return false;
     /* ... and only where it pays (profiles/r06_ab_padded_by_system.txt, one box, padded against flat): the lane-per-row RGB encoder,
      * whose row stores it aligns -- NTSC 640x480 x 1024 +5 %, SNES +5.6 %, PV-1000 +4.5 %, bloom +5.4 % -- but not the NES's table
      * encoder (never store-bound: the margin kernel's copies cost 1.1 % and buy nothing) and not the batches the library gives to the
      * scanline-parallel encoder by itself (dword stores per lane: 640x480 x 64 -0.8 %, 1080p x 64 -3.5 %).  A FORCED scanline-parallel
      * shape keeps the padded lines (tests run k_active_row's padded stores that way). */
-    if (c->sd.ppu_input) return false;
-    if (c->shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS_ENC) return false;
-    return dispatch_system(c->system, c->pattern, [&](auto tag) {
+    if (sd.ppu_input) return false;
+    if (shape == 0 && n <= ROWS_SHAPE_MAX_FIELDS_ENC) return false;
+    if (p->in_bpp == 0) return false;                 /* crt_modulate refuses the format: the noise kernel writes the (flat) field */
+    return dispatch_system(system, pattern, [&](auto tag) {
         using S = decltype(tag);
         using G = PadGeom<S>;
         const int over = p->xo + p->destw - S::HRES, wrap = over > 0 ? over : 0;
@@ -208,6 +211,11 @@ bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, int n, sig_la
         lay->fstride = G::FSTRIDE;
         return 1;
     }) == 1;
+}
+
+bool crt_fused_layout(const crthip_ctx *c, const crthip_params *p, int n, sig_layout *lay)
+{
+    return layout_rule(c->system, c->pattern, c->sd, c->fstride, p, n, c->shape, c->sig_pad, lay);
 }
 
 extern "C" {
@@ -672,6 +680,18 @@ int crthip_set_signal_tile(crthip_ctx *c, int dwords)
     if (!c || (dwords != 0 && dwords != 16 && dwords != 32 && dwords != 64)) return CRTHIP_E_ARG;
     c->sig_tile_env = dwords;
     return CRTHIP_OK;
+}
+
+int crthip_signal_layout_query(const crthip_params *p, int n_fields, int shape, int layout[4], size_t *field_stride)
+{
+    if (!p || p->finalized != CRTHIP_PARAMS_MAGIC || n_fields <= 0 || shape < 0 || shape > 2) return CRTHIP_E_ARG;
+    struct crt_sysdef sd;
+    if (crt_sysdef_get(&sd, p->system, p->chroma_pattern) != CRTHIP_OK) return CRTHIP_E_ARG;
+    sig_layout lay;
+    const bool padded = layout_rule(p->system, p->chroma_pattern, sd, crthip_field_stride(p->system, p->chroma_pattern), p, n_fields, shape, 1, &lay);
+    if (layout) { layout[0] = lay.pitch; layout[1] = lay.shift; layout[2] = lay.padv; layout[3] = lay.wrap; }
+    if (field_stride) *field_stride = lay.fstride;
+    return padded ? 1 : 0;
 }
 
 int crthip_set_signal_layout(crthip_ctx *c, int padded)

@@ -2,6 +2,7 @@
 include/crt_hip.h declares, and its C89 host setup (crt_setup.c) derives the same constants
 as the oracle.  No compute calls -- there is no GPU here."""
 import ctypes as C
+import numpy as np
 import os
 import re
 import subprocess
@@ -193,3 +194,92 @@ def test_missing_gpu_fails_loudly(lib):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         lib.CRT(1, 640, 480)
+
+
+SYSTEM_LINES = {"ntsc": (910, 262), "ntscp0": (912, 262), "snes": (909, 262), "temp": (910, 262), "pv1k": (1920, 262), "nesrgb": (909, 262)}
+
+
+@pytest.mark.parametrize("name", sorted(SYSTEM_LINES))
+def test_signal_layout_rules_and_margin_coverage(lib, name):
+    """Round 6: the fused path keeps its signal in padded lines.  crthip_signal_layout_query is the host-side rule
+    (no device): checked here against the rule restated, and -- for every geometry it calls padded -- the margin kernel's lane ->
+    (line, column) mapping (k_margin_pad, crt_encode.hip; restated below) must cover every sample outside the active rectangle, none
+    inside, copy the head of every line behind its predecessor up to `padv` exactly where the active-video kernel does not write,
+    and never store past the pad."""
+    L = lib.load_library()
+    hres, vres = SYSTEM_LINES[name]
+    pitch = (hres + 64 + 127) // 128 * 128
+    padw = pitch - hres
+    padc = min(padw, 96)
+    seen_padded = seen_flat = 0
+    for xoff in (0, 4, 8, 12, 16, 20, 24, 40, -40, -150):
+        for raw, (w, h) in ((0, (640, 480)), (1, (200, 100)), (1, (753, 236))):
+            for n, shape in ((4096, 0), (300, 0), (64, 0), (64, 1), (64, 2)):
+                try:
+                    p = lib.make_params(name, w=w, h=h, outw=640, outh=480, xoffset=xoff, raw=raw)
+                except ValueError:
+                    continue
+                lay = (C.c_int * 4)()
+                fs = C.c_size_t(0)
+                rc = L.crthip_signal_layout_query(C.byref(p), n, shape, lay, C.byref(fs))
+                assert rc in (0, 1)
+                xo, yo, destw, desth = p.xo, p.yo, p.destw, p.desth
+                wrap = max(0, xo + destw - hres)
+                a = wrap + (padc - wrap) // 16 * 16
+                padv = min(a, padc // 16 * 16)
+                inside = xo >= 0 and yo >= 0 and destw > 0 and yo + desth + (1 if wrap else 0) <= vres
+                want = (inside and wrap <= 16 and xo >= padw and destw >= 16 and padv >= 80 and not (shape == 0 and n <= 256))
+                assert rc == int(want), (name, xoff, raw, n, shape, rc, xo, destw, wrap, padv)
+                if not rc:
+                    seen_flat += 1
+                    assert lay[0] == hres and fs.value == L.crthip_field_stride(p.system, p.chroma_pattern)
+                    continue
+                seen_padded += 1
+                assert (lay[0], lay[2], lay[3]) == (pitch, padv, wrap) and (lay[1] + xo) % 128 == 0 and 0 <= lay[1] < 128
+                assert fs.value == (vres + 1 + 240) * pitch
+                if n != 4096:
+                    continue
+                # --- k_margin_pad's mapping, restated ---
+                cf = (hres + 15) // 16
+                cl = (xo + 15) // 16
+                right = hres - (xo + destw)
+                cr = (right + 15) // 16 if right > 0 else 0
+                per = cl + cr
+                home = np.zeros((vres, hres), dtype=np.int32)
+                copy = np.zeros((vres, padw), dtype=np.int32)
+                for q0 in range(yo * cf + desth * per + (vres - yo - desth) * cf):
+                    if q0 < yo * cf:
+                        line, k, lo, hi = q0 // cf, q0 % cf, 0, hres
+                    elif q0 < yo * cf + desth * per:
+                        q = q0 - yo * cf
+                        y, k = q // per, q % per
+                        line = yo + y
+                        if k < cl:
+                            lo, hi = (wrap if y > 0 else 0), xo
+                        else:
+                            k, lo, hi = k - cl, min(xo + destw, hres), hres
+                    else:
+                        q = q0 - yo * cf - desth * per
+                        r, k = q // cf, q % cf
+                        line, lo, hi = yo + desth + r, (wrap if r == 0 else 0), hres
+                    col, ln = lo + 16 * k, 16
+                    if hi - lo >= 16:
+                        col = min(col, hi - 16)
+                    else:
+                        if k > 0 or hi <= lo:
+                            continue
+                        ln = hi - lo
+                    home[line, col:col + ln] += 1
+                    if line >= 1 and col + ln <= padc:
+                        copy[line - 1, col:col + ln] += 1
+                active = np.zeros(vres * hres + 16, dtype=bool)
+                for y in range(desth):
+                    s0 = (y + yo) * hres + xo
+                    active[s0:s0 + destw] = True
+                active = active[:vres * hres].reshape(vres, hres)
+                assert ((home > 0) == ~active).all(), (name, xoff, raw, "margin samples written / left out")
+                # behind line l: the head of line l + 1, margin part by the margin kernel, overhang part by the active-video kernel
+                want_copy = ~active[1:, :padv]
+                assert ((copy[:-1, :padv] > 0) == want_copy).all(), (name, xoff, raw, "copies behind the lines")
+                assert (active[1:, :padv].sum(axis=1) <= wrap).all() and not (copy[:, padc:] > 0).any()
+    assert seen_padded > 10 and seen_flat > 10
