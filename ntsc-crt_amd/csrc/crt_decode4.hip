@@ -8,7 +8,7 @@
  * system gives 5.2 TB/s; for 1 KB runs it gives 5.85.  Emitting a 256-pixel run needs ~105 samples of y/i/q of that scanline at
  * once, i.e. 600-800 bytes of LDS per scanline -- 38-51 KB for 64 scanlines.  So this kernel takes 16 scanlines per wave and gets its
  * 64 lanes busy in the filter stage by giving every scanline FOUR lanes, one per cascade that tiers 0 / 1 run (luma low, luma
- * high, I high, Q high: crt_decode_lane.h, eq_step64 -- four independent chains of four one-pole stages): a lane runs 12
+ * high, I high, Q high: crt_decode_lane.h, eq_step64_yiq -- four independent chains of four one-pole stages): a lane runs 12
  * stage instructions per sample instead of 48, the band sums (crt_core.c:218-232) are formed with one quad DPP exchange, and
  * every lane files its result into the scanline's rings in LDS with one 16-bit store at its own offset.  The pixel stage then
  * walks the 16 scanlines one after the other, lane = four consecutive pixels: the two taps from the rings (offsets and weights
@@ -115,7 +115,7 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
     const unsigned long long dst = (unsigned long long) (outp + (size_t) f * ostride + (size_t) (nrows > 0 ? lp.beg : 0) * pitch);
 
     /* my cascade: input multiplier by sample phase (luma: 2^16, i.e. the sample itself; chroma: the demodulation carriers << 7,
-     * crt_core.c:476-479, 541-542), input offset, stage multiplier and form (eq_step64: coefficients >= 2^15 take x' = u + ...),
+     * crt_core.c:476-479, 541-542), input offset, stage multiplier and form (eq_step64_yiq: coefficients >= 2^15 take x' = u + ...),
      * top-band gain, output shift */
     const int w0 = lp.wave0 * 128, w1 = lp.wave1 * 128;
     int wk[4];
@@ -172,14 +172,14 @@ k_decode_wide(const crthip_params P, int n_fields, const signed char *__restrict
                 /* my cascade's input: s + bright | (s * wave) >> 9, as the high word of the product with the pre-scaled multiplier */
                 const int ut = TIER == 0 ? __mul24(s, wk[k]) : mul_lo_mad64(s, wk[k]);      /* tier 1: carriers << 7 beyond 24 bits */
                 const int u = add_hiword(bl, ut);
-                /* four stages, eq_step64: x' = hi32(M * (in - x) + {2^31, near1 ? in : x}) */
+                /* four stages, eq_step64_yiq: x' = hi32(M * (in - x) + {2^31, near1 ? in : x}) */
 #define WIDE_STAGE(X, IN) X = hi32(mad64_vv((IN) - X, M, pair_of(near1 ? (IN) : X)))
                 WIDE_STAGE(x0, u);
                 WIDE_STAGE(x1, x0);
                 WIDE_STAGE(x2, x1);
                 WIDE_STAGE(x3, x2);
 #undef WIDE_STAGE
-                /* band sums (crt_core.c:218-232; eq_step64 / eq_step64_chroma): top band on my own history; the luma-high lane
+                /* band sums (crt_core.c:218-232; eq_step64_yiq): top band on my own history; the luma-high lane
                  * takes the luma-low lane's output from its left neighbour in the quad, the others take themselves (difference 0) */
                 const int r = x3 + (__mul24(h2 - x3, g2) >> 16);
                 h2 = h1; h1 = h0; h0 = u;

@@ -74,77 +74,59 @@ __device__ __forceinline__ void eq64_reset(Eq64 &f)
     f.lo0 = f.lo1 = f.lo2 = f.lo3 = f.hi0 = f.hi1 = f.hi2 = f.hi3 = (long) KROUND64;
     f.h0 = f.h1 = f.h2 = 0;
 }
-/* lfm / hfm: pre-shifted multipliers (see above); NEAR1: coefficients are >= 2^15.
+/* Tiers 0 and 1: the three equalisers of one sample.  ylfm ... qhfm: pre-shifted multipliers (see above); the luma coefficients are
+ * >= 2^15 (x' = u + ...), the chroma ones below (x' = x + ...).
  * The band gains (crt_core.c:203-206) are applied as (r * g) >> 16 per band IN 32-BIT WRAPPING ARITHMETIC, i.e.
  * a gain of 65536 is "sign-extend the low 16 bits".  Inside the envelopes that is the identity:
  *   luma   |lo3|, |hi3| <= 2727                     -> low band = lo3, mid band (gain 8192) = (hi3 - lo3) >> 3
  *   chroma gains (65536, 65536, g2): low + mid = lo3 + (hi3 - lo3) = hi3 whenever |lo3|, |hi3 - lo3| < 2^15.
- *          LOSKIP (tier 0, |wave| <= LOSKIP_WAVE_MAX): every stage output stays inside the hull of its inputs
- *          (0 < c < 2^16, round-to-nearest never overshoots), the input is |s * wave >> 9| <= 16383, hence
- *          |lo3| <= 16383 and |hi3 - lo3| <= 32766: the four low stages feed nothing and are not computed. */
-template <bool NEAR1, int G1, int G2, bool LOSKIP>
-__device__ __forceinline__ int eq_step64(Eq64 &f, const int lfm, const int hfm, const long sp)
+ *          Every stage output stays inside the hull of its inputs (0 < c < 2^16, round-to-nearest never overshoots), the input
+ *          is |s * wave >> 9| <= 16383 (|wave| <= LOSKIP_WAVE_MAX), hence |lo3| <= 16383 and |hi3 - lo3| <= 32766: the four low
+ *          stages of I and Q feed nothing and are not computed (lines that need them are flagged CRTHIP_LINE_KEEPLO -> tier 2).
+ * Chroma input: u = (s * wave) >> 9 is handed over as the product with the carrier pre-scaled by 2^7, ut = s * (wave << 7) =
+ * u * 2^16 + fraction, and every consumer takes its high word inside the subtraction it feeds (SDWA): the shift costs no
+ * instruction.  |ut| <= 127 * 120 000 * 128 < 2^31 in these tiers; in tier 0 (|wave| <= 65 532) wave << 7 is still a 24-bit
+ * multiplier.  The 3-deep input history (crt_core.c:229-231) holds the products likewise.
+ * (r6) The four cascades that remain -- luma low, luma high, I high, Q high -- are independent of each other and are advanced SIDE
+ * BY SIDE, stage by stage (four differences, four multiply-adds, the re-arming moves), pinned in that order: written cascade after
+ * cascade every instruction waited on the one issued just before it (profiles/r02_valu_mixed_sequences.txt: 3.54 against 3.37
+ * cycles per instruction at 4 waves per SIMD).  k_decode 1.594 -> 1.552 ms at 640x480 x 4096, -1.7 ... -3.1 % at every batch size
+ * measured (profiles/r06_ab_cascades_side_by_side.txt). */
+template <int G1, int G2>
+__device__ __forceinline__ void eq_step64_yiq(Eq64 &y, Eq64 &ci_, Eq64 &cq_, const int ylfm, const int yhfm, const int ihfm, const int qhfm,
+                                              const long sp, const int uti, const int utq, int &cy, int &ci, int &cq)
 {
-#define EQ64_STAGE(X, UPAIR, M) X = rearm(mad64(hi32(UPAIR) - hi32(X), M, NEAR1 ? UPAIR : X))
-    static_assert(!LOSKIP || G1 == 65536, "dropping the low cascade needs low gain == mid gain == 65536");
-    if (!LOSKIP) {
-        EQ64_STAGE(f.lo0, sp, lfm);
-        EQ64_STAGE(f.lo1, f.lo0, lfm);
-        EQ64_STAGE(f.lo2, f.lo1, lfm);
-        EQ64_STAGE(f.lo3, f.lo2, lfm);
-    }
-    EQ64_STAGE(f.hi0, sp, hfm);
-    EQ64_STAGE(f.hi1, f.hi0, hfm);
-    EQ64_STAGE(f.hi2, f.hi1, hfm);
-    EQ64_STAGE(f.hi3, f.hi2, hfm);
-#undef EQ64_STAGE
-    const int lo3 = hi32(f.lo3), hi3 = hi32(f.hi3);
+#define EQ64_PIN() __builtin_amdgcn_sched_barrier(0)
+    int d0 = hi32(sp) - hi32(y.lo0), d1 = hi32(sp) - hi32(y.hi0), d2 = sub_hiword(uti, hi32(ci_.hi0)), d3 = sub_hiword(utq, hi32(cq_.hi0));
+    EQ64_PIN();
+    long a0 = mad64(d0, ylfm, sp), a1 = mad64(d1, yhfm, sp), a2 = mad64(d2, ihfm, ci_.hi0), a3 = mad64(d3, qhfm, cq_.hi0);
+    EQ64_PIN();
+    y.lo0 = rearm(a0); y.hi0 = rearm(a1); ci_.hi0 = rearm(a2); cq_.hi0 = rearm(a3);
+    EQ64_PIN();
+#define EQ64_STAGES(P, N)                                                                                                        \
+    d0 = hi32(y.lo##P) - hi32(y.lo##N); d1 = hi32(y.hi##P) - hi32(y.hi##N);                                                      \
+    d2 = hi32(ci_.hi##P) - hi32(ci_.hi##N); d3 = hi32(cq_.hi##P) - hi32(cq_.hi##N);                                              \
+    EQ64_PIN();                                                                                                                  \
+    a0 = mad64(d0, ylfm, y.lo##P); a1 = mad64(d1, yhfm, y.hi##P); a2 = mad64(d2, ihfm, ci_.hi##N); a3 = mad64(d3, qhfm, cq_.hi##N); \
+    EQ64_PIN();                                                                                                                  \
+    y.lo##N = rearm(a0); y.hi##N = rearm(a1); ci_.hi##N = rearm(a2); cq_.hi##N = rearm(a3);                                       \
+    EQ64_PIN();
+    EQ64_STAGES(0, 1)
+    EQ64_STAGES(1, 2)
+    EQ64_STAGES(2, 3)
+#undef EQ64_STAGES
+#undef EQ64_PIN
+    const int lo3 = hi32(y.lo3), hi3 = hi32(y.hi3);
     int r;
-    if (LOSKIP) r = hi3;
-    else if (NEAR1 && G1 == 8192) r = lo3 + ((hi3 - lo3) >> 3);        /* luma envelope, see above */
-    else {
-        r = (lo3 * 65536) >> 16;
-        if (G1 == 65536 || G1 == 8192) r += ((hi3 - lo3) * G1) >> 16;
-        else r += __mul24(hi3 - lo3, G1) >> 16;
-    }
-    if (G2 != 0) {
-        r += __mul24(f.h2 - hi3, G2) >> 16;
-        f.h2 = f.h1; f.h1 = f.h0; f.h0 = hi32(sp);
-    }
-    return r;
-}
-
-/* Tiers 0 and 1, chroma: the equaliser input u = (s * wave) >> 9 is handed over as the product with the carrier pre-scaled
- * by 2^7, ut = s * (wave << 7) = u * 2^16 + fraction, and every consumer takes its high word inside the subtraction it
- * feeds (SDWA): the shift costs no instruction.  |ut| <= 127 * 120 000 * 128 < 2^31 in these tiers; in tier 0
- * (|wave| <= 65 532) wave << 7 is still a 24-bit multiplier.  The 3-deep input history (crt_core.c:229-231) holds the
- * products likewise.  LO = with the low cascade (tier 1; see eq_step64 for when it can be dropped). */
-template <bool LO, int G2>
-__device__ __forceinline__ int eq_step64_chroma(Eq64 &f, const int lfm, const int hfm, const int ut)
-{
-    if (LO) {
-        f.lo0 = rearm(mad64(sub_hiword(ut, hi32(f.lo0)), lfm, f.lo0));
-        f.lo1 = rearm(mad64(hi32(f.lo0) - hi32(f.lo1), lfm, f.lo1));
-        f.lo2 = rearm(mad64(hi32(f.lo1) - hi32(f.lo2), lfm, f.lo2));
-        f.lo3 = rearm(mad64(hi32(f.lo2) - hi32(f.lo3), lfm, f.lo3));
-    }
-    f.hi0 = rearm(mad64(sub_hiword(ut, hi32(f.hi0)), hfm, f.hi0));
-    f.hi1 = rearm(mad64(hi32(f.hi0) - hi32(f.hi1), hfm, f.hi1));
-    f.hi2 = rearm(mad64(hi32(f.hi1) - hi32(f.hi2), hfm, f.hi2));
-    f.hi3 = rearm(mad64(hi32(f.hi2) - hi32(f.hi3), hfm, f.hi3));
-    const int hi3 = hi32(f.hi3);
-    int r;
-    if (LO) {                                               /* gains 65536, 65536: sign-extended low halves (crt_core.c:203-206) */
-        const int lo3 = hi32(f.lo3);
-        r = ((lo3 * 65536) >> 16) + (((hi3 - lo3) * 65536) >> 16);
-    } else {
-        r = hi3;                                            /* low + mid band, see eq_step64 (LOSKIP) */
-    }
-    if (G2 != 0) {
-        r += __mul24(sub_hiword(f.h2, hi3), G2) >> 16;
-        f.h2 = f.h1; f.h1 = f.h0; f.h0 = ut;
-    }
-    return r;
+    if (G1 == 8192) r = lo3 + ((hi3 - lo3) >> 3);                      /* luma envelope, see above */
+    else r = ((lo3 * 65536) >> 16) + (__mul24(hi3 - lo3, G1) >> 16);
+    r += __mul24(y.h2 - hi3, G2) >> 16;
+    y.h2 = y.h1; y.h1 = y.h0; y.h0 = hi32(sp);
+    cy = r;
+    const int i3 = hi32(ci_.hi3);
+    ci = i3 + (__mul24(sub_hiword(ci_.h2, i3), 1311) >> 16);            /* I: top band gain 1311, Q: none (crt_core.c:272-286) */
+    ci_.h2 = ci_.h1; ci_.h1 = ci_.h0; ci_.h0 = uti;
+    cq = hi32(cq_.hi3);
 }
 
 /* eqf of a USE_CONVOLUTION build of the reference (crt_core.c:119-147): a symmetric FIR kernel over a 7-deep
@@ -287,7 +269,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     s_nrows[lane] = nrows;
     wave_lds_fence();
 
-    /* tiers 0 and 1 multiply by the carriers scaled by 2^7 (eq_step64_chroma) */
+    /* tiers 0 and 1 multiply by the carriers scaled by 2^7 (eq_step64_yiq) */
     constexpr int WSCALE = TIER <= 1 ? 128 : 1;
     const int w0 = lp.wave0 * WSCALE, w1 = lp.wave1 * WSCALE, nw0 = -lp.wave0 * WSCALE, nw1 = -lp.wave1 * WSCALE;
     /* 5 samples per chroma cycle (PV-1000, crt_core.c:497-505, 544-549): the line table carries dci / dcq, the carriers
@@ -318,7 +300,7 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
     eq64_reset(wy); eq64_reset(wi_); eq64_reset(wq_);
     /* tier 0 multipliers: luma coefficients are 2^16 + c', chroma ones < 2^15 (host-checked) */
     const int ylfm = (ylf - 65536) << 16, yhfm = (yhf - 65536) << 16;
-    const int ilfm = ilf << 16, ihfm = ihf << 16, qlfm = qlf << 16, qhfm = qhf << 16;
+    const int ihfm = ihf << 16, qhfm = qhf << 16;              /* (the chroma low cascades are not computed in these tiers) */
     int py = 0, pi = 0, pq = 0;                    /* yiq of the previous sample */
 
     /* wave-uniform output pixel schedule, crt_core.c:528-531,555-562 */
@@ -384,15 +366,13 @@ k_decode(const crthip_params P, int n_fields, const signed char *__restrict__ in
                 int cy, ci, cq;
                 if (TIER == 0) {
                     /* luma stays unshifted here: (y << 4) * w >> 2 == (y * w) << 2 while nothing wraps, see D9 */
-                    cy = eq_step64<true, GY1, GY2, false>(wy, ylfm, yhfm, pair_of(s + bright));
-                    ci = eq_step64_chroma<false, 1311>(wi_, ilfm, ihfm, __mul24(s, wi)) >> 3;   /* wi, wq: carriers << 7 here */
-                    cq = eq_step64_chroma<false, 0>(wq_, qlfm, qhfm, __mul24(s, wq)) >> 3;
+                    eq_step64_yiq<GY1, GY2>(wy, wi_, wq_, ylfm, yhfm, ihfm, qhfm, pair_of(s + bright), __mul24(s, wi), __mul24(s, wq), cy, ci, cq);
+                    ci >>= 3; cq >>= 3;                        /* wi, wq: carriers << 7 here */
                 } else if (TIER == 1) {
                     /* carriers << 7 beyond 24 bits: the products come from the 64-bit multiply-add (exact low dword,
                      * |s * (wave << 7)| < 2^31 up to |wave| = 120000) */
-                    cy = eq_step64<true, GY1, GY2, false>(wy, ylfm, yhfm, pair_of(s + bright));
-                    ci = eq_step64_chroma<false, 1311>(wi_, ilfm, ihfm, mul_lo_mad64(s, wi)) >> 3;
-                    cq = eq_step64_chroma<false, 0>(wq_, qlfm, qhfm, mul_lo_mad64(s, wq)) >> 3;
+                    eq_step64_yiq<GY1, GY2>(wy, wi_, wq_, ylfm, yhfm, ihfm, qhfm, pair_of(s + bright), mul_lo_mad64(s, wi), mul_lo_mad64(s, wq), cy, ci, cq);
+                    ci >>= 3; cq >>= 3;
                 } else if (FIR) {
                     const int uy = s + bright, ui = mulq<FAST>(s, wi) >> 9, uq = mulq<FAST>(s, wq) >> 9;
 #define CRT_FIR3(M) do { cy = fir_step<M>(fy, uy, k) << 4; ci = fir_step<M>(fi, ui, k) >> 3; cq = fir_step<M>(fq, uq, k) >> 3; } while (0)

@@ -341,7 +341,7 @@ __device__ __forceinline__ int mad24_vv(int v, int s_uniform, int acc_v)
 }
 /* v_mad_i64_i32: vgpr * sgpr + 64-bit register pair (used as "multiply, shift and accumulate in one instruction": the
  * state of a one-pole filter lives in the HIGH half of a pair, the multiplier is pre-shifted so that the wanted
- * quotient bits land there; see eq_step64 in crt_decode.hip and the encoder's low-passes in crt_encode.hip) */
+ * quotient bits land there; see eq_step64_yiq in crt_decode_lane.h and the encoder's low-passes in crt_encode.hip) */
 __device__ __forceinline__ long mad64_vs(int d, int m_uniform, long acc)
 {
     long r, carry;

@@ -529,10 +529,20 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         have_col = col;
                     }
                     if (I64) {
+#ifdef ENC_INTERLEAVE
+                        /* the three low-passes side by side: differences, then the multiply-adds (cf. eq_step64_yiq, crt_decode_lane.h) */
+                        const int dy = pair_hi(fyp) - pair_hi(hyp), di = fi - pair_hi(hip), dq = fq - pair_hi(hqp);
+                        const long ay = S::IIR_Y_NEAR ? fyp : (hyp & HI_HALF), ai = hip & HI_HALF, aq = hqp & HI_HALF;
+                        __builtin_amdgcn_sched_barrier(0);
+                        hyp = mad64_vs(dy, my_, ay); hip = mad64_vs(di, mi_, ai); hqp = mad64_vs(dq, mq_, aq);
+                        if (NOISE) rn = lcg_step_mad64(rn, lcg_add);
+                        __builtin_amdgcn_sched_barrier(0);
+#else
                         if (S::IIR_Y_NEAR) hyp = mad64_vs(pair_hi(fyp) - pair_hi(hyp), my_, fyp);
                         else hyp = mad64_vs(pair_hi(fyp) - pair_hi(hyp), my_, hyp & HI_HALF);
                         hip = mad64_vs(fi - pair_hi(hip), mi_, hip & HI_HALF);
                         hqp = mad64_vs(fq - pair_hi(hqp), mq_, hqp & HI_HALF);
+#endif
                         hy = pair_hi(hyp); hi = pair_hi(hip); hq = pair_hi(hqp);
                     } else if (S::BANDLIMIT) {
                         hy += mulq<FAST>(fy - hy, cy_) >> 11;       /* iirf, crt_ntsc.c:117-126 */
@@ -555,6 +565,25 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         cph = cph == S::CCS - 1 ? 0 : cph + 1;
                     }
                     int ire;
+#ifdef ENC_INTERLEAVE
+                    if constexpr (FAST && NOISE && I64) {
+                        /* the noise term (its own chain: LCG state -> byte -> scaled) between the steps of the level's chain */
+                        const int pI = __mul24(oi, ccI);
+                        const int nb = (int) ((rn >> 16) & 0xffu);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int pQ = __mul24(oq, ccQ);
+                        const int nz = mad24_vv(nb, noise256, neg_noise127_256);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int miq = add_hiwords(pI, pQ);
+                        ire = mad24_vv(oy + miq, white64, ire_base_65536);
+                        ire = clampi(ire, 0, (110 << 16) | 0xffff);
+                        ire = add_hiwords(ire, nz);
+                        ire = clampi(ire, -127, 127);
+                        tiles.put_byte(g, k, ire);
+                        cpos += cstep;
+                        continue;
+                    }
+#endif
                     if (FAST) {
                         /* (h * cc) >> 4 twice: the carriers are pre-scaled by 2^12 (cI / cQ above), so that each
                          * shift is "take the high word" and both ride on the add;
