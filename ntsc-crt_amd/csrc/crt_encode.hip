@@ -529,20 +529,15 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         have_col = col;
                     }
                     if (I64) {
-#ifdef ENC_INTERLEAVE
-                        /* the three low-passes side by side: differences, then the multiply-adds (cf. eq_step64_yiq, crt_decode_lane.h) */
+                        /* (r6) the three low-passes side by side -- differences, then the multiply-adds, the noise generator's step with
+                         * them -- instead of one after the other: no instruction waits on the one issued just before it (cf. eq_step64_yiq,
+                         * crt_decode_lane.h; k_active 0.874 -> 0.856 ms at 640x480 x 4096, profiles/r06_ab_encoder_side_by_side.txt) */
                         const int dy = pair_hi(fyp) - pair_hi(hyp), di = fi - pair_hi(hip), dq = fq - pair_hi(hqp);
                         const long ay = S::IIR_Y_NEAR ? fyp : (hyp & HI_HALF), ai = hip & HI_HALF, aq = hqp & HI_HALF;
                         __builtin_amdgcn_sched_barrier(0);
                         hyp = mad64_vs(dy, my_, ay); hip = mad64_vs(di, mi_, ai); hqp = mad64_vs(dq, mq_, aq);
                         if (NOISE) rn = lcg_step_mad64(rn, lcg_add);
                         __builtin_amdgcn_sched_barrier(0);
-#else
-                        if (S::IIR_Y_NEAR) hyp = mad64_vs(pair_hi(fyp) - pair_hi(hyp), my_, fyp);
-                        else hyp = mad64_vs(pair_hi(fyp) - pair_hi(hyp), my_, hyp & HI_HALF);
-                        hip = mad64_vs(fi - pair_hi(hip), mi_, hip & HI_HALF);
-                        hqp = mad64_vs(fq - pair_hi(hqp), mq_, hqp & HI_HALF);
-#endif
                         hy = pair_hi(hyp); hi = pair_hi(hip); hq = pair_hi(hqp);
                     } else if (S::BANDLIMIT) {
                         hy += mulq<FAST>(fy - hy, cy_) >> 11;       /* iirf, crt_ntsc.c:117-126 */
@@ -565,9 +560,9 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         cph = cph == S::CCS - 1 ? 0 : cph + 1;
                     }
                     int ire;
-#ifdef ENC_INTERLEAVE
                     if constexpr (FAST && NOISE && I64) {
-                        /* the noise term (its own chain: LCG state -> byte -> scaled) between the steps of the level's chain */
+                        /* (r6, with the low-passes above) the noise term -- its own chain: generator state (stepped above) -> byte -> scaled --
+                         * between the steps of the level's chain; the arithmetic is the FAST && NOISE branch below, line for line */
                         const int pI = __mul24(oi, ccI);
                         const int nb = (int) ((rn >> 16) & 0xffu);
                         __builtin_amdgcn_sched_barrier(0);
@@ -583,7 +578,6 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         cpos += cstep;
                         continue;
                     }
-#endif
                     if (FAST) {
                         /* (h * cc) >> 4 twice: the carriers are pre-scaled by 2^12 (cI / cQ above), so that each
                          * shift is "take the high word" and both ride on the add;
