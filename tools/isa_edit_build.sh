@@ -5,6 +5,7 @@
 # wait state the compiler puts behind every inline-asm block whose result the next instruction reads -- it has to assume the block
 # wrote a partial register (dst_sel forwarding, gfx940+); blocks that do hold an SDWA / op_sel destination keep theirs), then
 # (EDIT=pad: tools/pad_dependent_valu.py instead -- a wait state between every two adjacent dependent vector instructions), then
+# (EDIT=none: no edit -- for device-only compiler options, given in $DEVFLAGS, that the host pass does not take), then
 # assembler, device link, bundle and the host half of the unit with that bundle embedded -- the same steps `hipcc -###` prints.
 # The other objects are taken from ntsc-crt_amd/lib/ (build that first), or from ntsc-crt_amd/$BASE/ to stack several edited units.
 set -e
@@ -17,8 +18,8 @@ out=$root/ntsc-crt_amd/$libdir
 tmp=$(mktemp -d /tmp/isaedit_XXXX)
 mkdir -p $out
 for o in crt_encode crt_noise crt_sync crt_decode crt_decode2 crt_decode3 crt_decode4 crt_host crt_setup; do cp $root/ntsc-crt_amd/${BASE:-lib}/$o.o $out/ 2>/dev/null || true; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 $FL --cuda-device-only -S $src -o $tmp/dev.s 2>/dev/null
-if [ "${EDIT:-strip}" = pad ]; then python3 $root/tools/pad_dependent_valu.py $tmp/dev.s $tmp/dev2.s; else python3 $root/tools/strip_asm_nops.py $tmp/dev.s $tmp/dev2.s; fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $FL $DEVFLAGS --cuda-device-only -S $src -o $tmp/dev.s 2>/dev/null
+if [ "${EDIT:-strip}" = pad ]; then python3 $root/tools/pad_dependent_valu.py $tmp/dev.s $tmp/dev2.s; elif [ "${EDIT:-strip}" = none ]; then cp $tmp/dev.s $tmp/dev2.s; else python3 $root/tools/strip_asm_nops.py $tmp/dev.s $tmp/dev2.s; fi
 $LL/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $tmp/dev2.s -o $tmp/dev.o
 $LL/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared $tmp/dev.o -o $tmp/dev.out
 $LL/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$tmp/dev.out -output=$tmp/dev.hipfb
