@@ -182,22 +182,31 @@ struct RowTiles {
     static constexpr int ROWS = 64 / PIECES;                                  /* rows per load instruction */
     static constexpr int OTILE = OT, OPIECES = OT / 4, OROWS = 64 / OPIECES;
     unsigned *s_pix, *s_out;
-    const unsigned long long *s_src, *s_dst;
+    unsigned long long my_src, my_dst;                  /* my own row's image row / signal row (0: none); other rows' by lane_u64 */
     int lane, prow, piece, oprow, opiece;
     int row_bytes, last_tile, have;
     bool shift8;                 /* alpha-first pixel formats: the colour bytes are moved to bits 0-23 once per tile, here */
     v4i stage[PIECES];
 
-    __device__ __forceinline__ void init(unsigned *pix, unsigned *out, const unsigned long long *src,
-                                         const unsigned long long *dst, int lane_, int row_bytes_)
+    __device__ __forceinline__ void init(unsigned *pix, unsigned *out, unsigned long long src, unsigned long long dst, int lane_, int row_bytes_)
     {
-        s_pix = pix; s_out = out; s_src = src; s_dst = dst;
+        s_pix = pix; s_out = out; my_src = src; my_dst = dst;
         lane = lane_; prow = lane_ / PIECES; piece = lane_ % PIECES;
         oprow = lane_ / OPIECES; opiece = lane_ % OPIECES;
         shift8 = false;
         row_bytes = row_bytes_;
         last_tile = (row_bytes_ - 1) / (TILE * 4);
         have = 0;
+    }
+    /* (r6) the row pointers of the 64 rows live in their lanes' registers and travel by ds_bpermute_b32 (the LDS crossbar, no LDS
+     * memory) where rounds 1-5 kept two 64-entry tables in LDS: 1 KB less per wave -- with gfx950's 1280-byte allocation granule that is
+     * 12 instead of 11 waves per CU for the 16-dword image / 32-dword sample tile pair (all lanes are active wherever this is called) */
+    __device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int src_lane) const
+    {
+        const int a = src_lane << 2;
+        const unsigned lo = (unsigned) __builtin_amdgcn_ds_bpermute(a, (int) (unsigned) v);
+        const unsigned hi = (unsigned) __builtin_amdgcn_ds_bpermute(a, (int) (unsigned) (v >> 32));
+        return ((unsigned long long) hi << 32) | lo;
     }
     __device__ __forceinline__ int piece_offset(int tile) const
     {
@@ -212,7 +221,7 @@ struct RowTiles {
 #if defined(ENC_DBG) && ENC_DBG == 2          /* measurement build: no image loads (tools/sessions; never shipped) */
             stage[i] = v4i{ off + i, lane, tile, 7 };
 #else
-            stage[i] = image_piece<ACT>(s_src[i * ROWS + prow] + off);
+            stage[i] = image_piece<ACT>(lane_u64(my_src, i * ROWS + prow) + off);
 #endif
         }
     }
@@ -280,7 +289,7 @@ struct RowTiles {
 #pragma unroll 2
         for (int i = 0; i < OPIECES; i++) {
             const int r = i * OROWS + oprow;
-            const unsigned long long d = s_dst[r];
+            const unsigned long long d = lane_u64(my_dst, r);
             if (d != 0 && opiece * 4 < ng && nbytes > 0) {
                 const unsigned *sp = s_out + TO::row(r) + opiece * 4;
                 v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
@@ -306,7 +315,7 @@ struct RowTiles {
      * row's last 16 samples are never overwritten by the (shorter) last tile. */
     __device__ __forceinline__ void wrap_home(int destw, int wrapn, int delta)
     {
-        const unsigned long long d = s_dst[lane];
+        const unsigned long long d = my_dst;
         if (d == 0) return;
         for (int x = destw - wrapn; x < destw; x++) {
             const unsigned dw = s_out[TO::row(lane) + ((x >> 2) & (OTILE - 1))];
@@ -362,7 +371,6 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[T::TP::DWORDS];
     __shared__ unsigned s_out[T::TO::DWORDS];
-    __shared__ unsigned long long s_src[64], s_dst[64];
 
     const int lane = threadIdx.x;
     const int gid = block_item(blockIdx.x, order_k, order_per) * 64 + lane;     /* workgroup order: crt_dev.h */
@@ -385,11 +393,9 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     const int sy = source_row<S>(P, y, st.field & 1);
     const int in_bpp = S::IS_NES ? 2 : P.in_bpp;
     const unsigned char *row = img + (size_t) sy * w * in_bpp;
-    s_src[lane] = (unsigned long long) row;
-    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo)) : 0ull;
-    __syncthreads();
     T tiles;
-    tiles.init(s_pix, s_out, s_src, s_dst, lane, w * 4);
+    tiles.init(s_pix, s_out, (unsigned long long) row,
+               live ? (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo)) : 0ull, lane, w * 4);
 
     if constexpr (S::IS_NES) {
         /* crt_nes.c:162-193, images too narrow for the tile path (k_active_nes otherwise) */
@@ -811,7 +817,6 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[T::TP::DWORDS];
     __shared__ unsigned s_out[T::TO::DWORDS];
-    __shared__ unsigned long long s_src[64], s_dst[64];
     __shared__ unsigned s_tab[NES_TAB_SIZE / 4];
 
     const int lane = threadIdx.x;
@@ -832,12 +837,12 @@ k_active_nes(const crthip_params P, int n_fields, const unsigned char *__restric
     int col = 0, err = 0;
     const int ngroups = (destw + 3) >> 2;
     const int sy = source_row<S>(P, y, 0);                      /* crt_nes.c:165-168 */
-    s_src[lane] = (unsigned long long) (img + (size_t) sy * w * 2);
-    s_dst[lane] = live ? (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo)) : 0ull;   /* k_active: pitch / shift / wrapn */
-    __syncthreads();
+    __syncthreads();                                            /* s_tab */
     /* pixel tiles: ACT dwords = 2*ACT PPU pixels per row */
     T tiles;
-    tiles.init(s_pix, s_out, s_src, s_dst, lane, w * 2);
+    tiles.init(s_pix, s_out, (unsigned long long) (img + (size_t) sy * w * 2),
+               live ? (unsigned long long) (dst + (size_t) f * fstride + (size_t) (shift + (y + P.yo) * pitch + P.xo)) : 0ull,   /* k_active: pitch / shift / wrapn */
+               lane, w * 2);
     tiles.start();
 
     int ph = 4 * ((y + P.yo + st.aux) % 3);                    /* phasetab {0,4,8}; advances by 3 per sample, mod 12 */
