@@ -174,13 +174,24 @@ __device__ __forceinline__ bool format_blue_low(int format)
 /* OT: dwords per row of the OUTPUT (sample) tile.  The wide-input encoder (ACT = 32: whole 128-byte image lines per
  * piece group) keeps the 16-dword sample tile of the narrow one: 64-byte sample pieces either way, 4 KB less LDS per
  * wave (11 instead of 8 waves per CU behind the image fetches). */
-template <int ACT, int OT = ACT>
+/* (r6) OL: dwords per row of the sample tile that are IN LDS.  OL = OT: all of it (rounds 1-5).  OL = OT / 2 ("staged"): the lane
+ * pulls its first half back into OL registers when that half is complete, the second half reuses the LDS rows, and the drain goes
+ * through the same LDS bytes in two passes of 32 rows x OT dwords -- the signal still leaves in 4 * OT-byte pieces, but the wave
+ * holds half the LDS: 8.4 instead of 12.7 KB beside the 16-dword image tile (16 waves per CU instead of 12; the register file has the
+ * room: 77 + 16 + 16 transient of 128), 16.9 instead of 25 KB beside the 32-dword one.  k_active is not bound by its vector unit (61 %
+ * busy at 11 waves per CU, profiles/r06_headline_sq_counters.json), but waves are not everything either: staging pays for the 64-dword
+ * tile only (launch_active). */
+template <int ACT, int OT = ACT, int OL = OT>
 struct RowTiles {
     static constexpr int TILE = ACT, PIECES = ACT / 4;                        /* 16-byte pieces per tile row */
+    static constexpr bool STAGED = OL != OT;
+    static_assert(OL == OT || 2 * OL == OT, "the staged sample tile keeps exactly one half in registers");
     using TP = TileRows<ACT>;                                                 /* row addressing of the two tiles (crt_dev.h): conflict-free */
-    using TO = TileRows<OT>;                                                  /*   lane-per-row and cooperatively                          */
+    using TO = TileRows<OL>;                                                  /*   lane-per-row and cooperatively                          */
+    static_assert(!STAGED || TO::DWORDS >= 32 * (OT + 1), "the two-pass drain lays 32 rows of OT + 1 dwords over the tile");
     static constexpr int ROWS = 64 / PIECES;                                  /* rows per load instruction */
-    static constexpr int OTILE = OT, OPIECES = OT / 4, OROWS = 64 / OPIECES;
+    static constexpr int OTILE = OT, OPIECES = OL / 4, OROWS = 64 / OPIECES;  /* (pieces of the tile in LDS) */
+    unsigned r0[STAGED ? OL : 1];                                             /* staged: the first half of the current OT-dword block */
     unsigned *s_pix, *s_out;
     unsigned long long my_src, my_dst;                  /* my own row's image row / signal row (0: none); other rows' by lane_u64 */
     int lane, prow, piece, oprow, opiece;
@@ -274,11 +285,11 @@ struct RowTiles {
         }
     }
     __device__ __forceinline__ unsigned pixel_dword(int idx) const { return s_pix[TP::row(lane) + (idx & (TILE - 1))]; }
-    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[TO::row(lane) + (g & (OTILE - 1))] = pack; }
+    __device__ __forceinline__ void put(int g, unsigned pack) { s_out[TO::row(lane) + (g & (OL - 1))] = pack; }
     /* sample k of group g as one LDS byte store: no packing arithmetic on the vector unit */
     __device__ __forceinline__ void put_byte(int g, int k, int v)
     {
-        ((unsigned char *) s_out)[(TO::row(lane) + (g & (OTILE - 1))) * 4 + k] = (unsigned char) v;
+        ((unsigned char *) s_out)[(TO::row(lane) + (g & (OL - 1))) * 4 + k] = (unsigned char) v;
     }
     /* drain the sample tile: dwords [g0, g0+ng) of every row = samples [4*g0, ...) clipped to destw */
     __device__ __forceinline__ void drain(int g0, int ng, int destw)
@@ -318,14 +329,75 @@ struct RowTiles {
         const unsigned long long d = my_dst;
         if (d == 0) return;
         for (int x = destw - wrapn; x < destw; x++) {
-            const unsigned dw = s_out[TO::row(lane) + ((x >> 2) & (OTILE - 1))];
+            const unsigned dw = s_out[TO::row(lane) + ((x >> 2) & (OL - 1))];
             gstore8(d + (unsigned) (x + delta), dw >> (8 * (x & 3)));
         }
+    }
+    /* staged tile: the block's dwords [0, OL) are in r0, [OL, ng) in LDS.  Second half to registers, then twice: 32 lanes lay their
+     * row out at OT + 1 dwords per row (conflict-free both ways), the wave stores those 32 rows in 4 * OT-byte pieces */
+    __device__ __forceinline__ void drain_staged(int g0, int ng, int destw)
+    {
+        unsigned r1[OL];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OL; j++) r1[j] = s_out[TO::row(lane) + j];
+        __syncthreads();
+        constexpr int DSTRIDE = OT + 1, OP = OT / 4, ORW = 64 / OP;
+        const int orow = lane / OP, op = lane % OP;
+        const int first = (g0 + op * 4) * 4;
+        const int nbytes = destw - first < 16 ? destw - first : 16;
+        for (int ph = 0; ph < 2; ph++) {
+            if ((lane >> 5) == ph) {
+                unsigned *d = s_out + (lane & 31) * DSTRIDE;
+#pragma unroll
+                for (int j = 0; j < OL; j++) { d[j] = r0[j]; d[OL + j] = r1[j]; }
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int i = 0; i < 32 / ORW; i++) {
+                const int r = i * ORW + orow;
+                const unsigned long long d = lane_u64(my_dst, ph * 32 + r);
+                if (d != 0 && op * 4 < ng && nbytes > 0) {
+                    const unsigned *sp = s_out + r * DSTRIDE + op * 4;
+                    v4i o; o.x = (int) sp[0]; o.y = (int) sp[1]; o.z = (int) sp[2]; o.w = (int) sp[3];
+                    if (nbytes == 16) {
+                        gstore16u(d + first, o);
+                    } else {
+                        const int wds[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            if (k < nbytes) gstore8(d + first + k, (unsigned) (wds[k >> 2] >> (8 * (k & 3))));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    /* staged tile: sample x of my row straight to its home when it belongs to the `wrapn` samples that run over the line's end
+     * (wrap_home reads them back from the tile, which the two-pass drain has re-laid by then); wave-uniform condition at the caller */
+    __device__ __forceinline__ void wrap_byte(int x, int v, int delta)
+    {
+        if (my_dst != 0) gstore8(my_dst + (unsigned) (x + delta), (unsigned) v);
     }
     /* after sample group g (4 samples = 1 dword per row): flush when the tile is full or the line ends */
     __device__ __forceinline__ void group_done(int g, int ngroups, int destw)
     {
-        if ((g & (OTILE - 1)) == OTILE - 1 || g == ngroups - 1) drain(g & ~(OTILE - 1), (g & (OTILE - 1)) + 1, destw);
+        if constexpr (STAGED) {
+            const int gi = g & (OTILE - 1);
+            const bool last = g == ngroups - 1;
+            if (gi == OL - 1 && !last) {                 /* first half complete, more of this block to come: to registers */
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < OL; j++) r0[j] = s_out[TO::row(lane) + j];
+                __syncthreads();
+            } else if (gi == OTILE - 1 || last) {
+                if (gi < OL) drain(g & ~(OTILE - 1), gi + 1, destw);        /* the line ends inside a first half: still all in LDS */
+                else drain_staged(g & ~(OTILE - 1), gi + 1, destw);
+            }
+        } else {
+            if ((g & (OTILE - 1)) == OTILE - 1 || g == ngroups - 1) drain(g & ~(OTILE - 1), (g & (OTILE - 1)) + 1, destw);
+        }
     }
 };
 
@@ -359,7 +431,7 @@ template <class S> __device__ __forceinline__ int source_row(const crthip_params
  * small; 64 (256-byte pieces, 16.6 KB) is what large batches take: the encoder is bound by its MEMORY PATTERN -- image pieces in,
  * signal pieces out, no arithmetic at all reproduces its time (tools/ubench_enc.hip, profiles/r05_encoder_memory_shapes.txt) -- and
  * 64-byte pieces at the reference's odd line starts are its dearest part */
-template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT, int OT = 16>
+template <class S, bool NOISE, bool FAST, bool IN4, bool CLAMP, int ACT, int OT = 16, int OL = OT>
 __global__ void __launch_bounds__(64)
 k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ images, size_t istride,
          signed char *__restrict__ dst, size_t fstride, const crthip_state *__restrict__ state,
@@ -367,7 +439,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
 {
     /* pitch / shift / wrapn: where a row goes -- HRES, 0, 0 = the reference's flat lines; the fused path's padded lines otherwise
      * (crt_dev.h, sig_layout; wrapn = the row's samples that run over the end of its line) */
-    using T = RowTiles<ACT, OT>;
+    using T = RowTiles<ACT, OT, OL>;
     constexpr int AC_SHIFT = ACT == 32 ? 5 : 4;
     __shared__ unsigned s_pix[T::TP::DWORDS];
     __shared__ unsigned s_out[T::TO::DWORDS];
@@ -388,6 +460,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
     const int qstep = w / destw, rstep = w - qstep * destw;   /* column = floor(x*w/destw), incrementally */
     int col = 0, err = 0;                                     /* wave-uniform */
     const int ngroups = (destw + 3) >> 2;
+    const int wrap_x0 = wrapn > 0 ? destw - wrapn : 0x7fffffff;   /* staged sample tile: first sample that runs over the line's end */
 
     /* per-row source / destination, published to the whole wave */
     const int sy = source_row<S>(P, y, st.field & 1);
@@ -581,6 +654,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         ire = add_hiwords(ire, nz);
                         ire = clampi(ire, -127, 127);
                         tiles.put_byte(g, k, ire);
+                        if constexpr (T::STAGED) { if (x >= wrap_x0 && x < destw) tiles.wrap_byte(x, ire, pitch - S::HRES); }
                         cpos += cstep;
                         continue;
                     }
@@ -614,6 +688,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
                         ire = clampi(ire, -127, 127);
                     }
                     tiles.put_byte(g, k, ire);
+                    if constexpr (T::STAGED) { if (x >= wrap_x0 && x < destw) tiles.wrap_byte(x, ire, pitch - S::HRES); }
                     cpos += cstep;
                 } else {
                     tiles.put_byte(g, k, 0);
@@ -622,7 +697,7 @@ k_active(const crthip_params P, int n_fields, const unsigned char *__restrict__ 
             tiles.group_done(g, ngroups, destw);
         }
     }
-    if (wrapn > 0) tiles.wrap_home(destw, wrapn, pitch - S::HRES);
+    if constexpr (!T::STAGED) { if (wrapn > 0) tiles.wrap_home(destw, wrapn, pitch - S::HRES); }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1192,9 +1267,19 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
         const bool big = c->sig_tile_env ? c->sig_tile_env != 16
                                          : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
         if (in4 && big) {
+#ifndef CRTHIP_ENC_OL32
+/* dwords per row of the large sample tiles that are in LDS (RowTiles: staged when half of OT).  Measured (profiles/r06_ab_encoder_waves.txt):
+ * the 64-dword tile beside the wide image tile gains from staging (9 instead of 6 waves per CU: 1280x720 x 2048 k_active 0.779 -> 0.744 ms,
+ * 1080p equal), the 32-dword tile beside the narrow one loses (16 instead of 12 waves, but 0.818 -> 0.862 ms at 640x480 x 4096: the two-pass
+ * drain costs more than the waves give) and stays all in LDS */
+#define CRTHIP_ENC_OL32 32
+#endif
+#ifndef CRTHIP_ENC_OL64
+#define CRTHIP_ENC_OL64 32
+#endif
 #define CRTHIP_LAUNCH_ACTIVE_BIG(NZ) \
-    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
-         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); } while (0)
+    do { if (wide_in) hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 32, 64, CRTHIP_ENC_OL64>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); \
+         else hipLaunchKernelGGL((k_active<S, NZ, true, true, true, 16, 32, CRTHIP_ENC_OL32>), ogrid, block, 0, c->stream, *p, n, img, istride, dst, lay.fstride, d_state, c->d_jump16, bo.K, bo.per, lay.pitch, lay.shift, wrapn); } while (0)
             if (noise) CRTHIP_LAUNCH_ACTIVE_BIG(true); else CRTHIP_LAUNCH_ACTIVE_BIG(false);
 #undef CRTHIP_LAUNCH_ACTIVE_BIG
             return;
