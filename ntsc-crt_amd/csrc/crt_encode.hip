@@ -210,8 +210,8 @@ struct RowTiles {
         have = 0;
     }
     /* (r6) the row pointers of the 64 rows live in their lanes' registers and travel by ds_bpermute_b32 (the LDS crossbar, no LDS
-     * memory) where rounds 1-5 kept two 64-entry tables in LDS: 1 KB less per wave -- with gfx950's 1280-byte allocation granule that is
-     * 12 instead of 11 waves per CU for the 16-dword image / 32-dword sample tile pair (all lanes are active wherever this is called) */
+     * memory) where rounds 1-5 kept two 64-entry tables in LDS: 1 KB less per wave -- 12 672 instead of 13 696 B for the 16-dword
+     * image / 32-dword sample tile pair, i.e. 12 instead of 11 waves per CU (all lanes are active wherever this is called) */
     __device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int src_lane) const
     {
         const int a = src_lane << 2;
