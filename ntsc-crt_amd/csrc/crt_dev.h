@@ -428,7 +428,13 @@ __device__ __forceinline__ unsigned lcg_at(const uint2 *__restrict__ jump16, uns
  * residency rounds at the occupancy they leave (1080p: 1638 fields; 640x480: 1792 fields).  Below: a second, half-empty round costs
  * more than the pieces give (profiles/r04_experiments.txt section 19, profiles/r05_experiments.txt sections 2-4) */
 #define SIG_TILE64_MIN_WAVES_WIDE 6144     /* wide image tile (w >= 1280): 256-byte pieces */
-#define SIG_TILE32_MIN_WAVES      6720     /* narrow image tile: 128-byte pieces */
+/* narrow image tile, 128-byte pieces (12 waves per CU = 3072 at a time, against about 4096 with the 64-byte-piece tile): (r6, measured
+ * by batch size, profiles/r06_ab_signal_tile_by_batch.txt) they pay where the wave count fills one round of theirs (2880 waves: -14 %)
+ * and from where the small tile needs a second round (4800: -13 %, 5760: -10 %, 7680: -5 %); in between the large tile would run
+ * a thin second round (3840 waves: +13 %), below the band both are equal */
+#define SIG_TILE32_BAND_LO        2304
+#define SIG_TILE32_ONE_ROUND      3072
+#define SIG_TILE16_ONE_ROUND      4096
 #define MARGIN_SIDE_MIN_FIELDS 512         /* launch_encoder: k_margin on the internal stream beside k_active from this many fields on */
 #define SYNC_FPB4_MIN_FIELDS 768            /* k_hsync_wave: four fields per workgroup from here on, one below (crt_sync.hip) */
 #define WIDE_LPW8_MAX_WAVES 1440           /* k_decode_wide: 8 scanlines per wave while 16 per wave would make fewer waves than this (1080p: < 96 fields; measured: 32 fields -10 %, 64 -4 %, 128 +4 %) */

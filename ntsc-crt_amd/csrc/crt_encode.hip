@@ -1258,14 +1258,17 @@ static void launch_active(crthip_ctx *c, const crthip_params *p, int n, const vo
     const dim3 ogrid(bo.grid);
     const bool wide_in = c->ac_tile_env ? c->ac_tile_env == 32 : c->ac_tile ? c->ac_tile == 32 : p->w >= 1280;
     /* Larger signal pieces where the batch keeps the chip full at the lower occupancy their tile leaves (fused throughput path,
-     * 4-byte pixels, fast envelope): 256-byte pieces beside the wide image tile (26 KB of LDS, 6 waves per CU), 128-byte pieces
+     * 4-byte pixels, fast envelope): 256-byte pieces beside the wide image tile (16.9 KB of LDS with the tile staged, 9 waves per CU), 128-byte pieces
      * beside the narrow one (12.7 KB, 12 waves per CU).  Measured per batch size and system in profiles/r05_experiments.txt
      * (sections 2-4): 1080p x 2048 k_active 0.86 -> 0.79 ms, 640x480 x 4096 1.05 -> 0.98, VHS / bloom / 720p -4..9 %; below the
-     * thresholds (and for the 5-sample system, whose carrier table shares the LDS) the 64-byte pieces stay the faster ones.
+     * thresholds (crt_dev.h: by wave count, re-measured in round 6) and for the 5-sample system, whose carrier table shares the LDS, the
+     * 64-byte pieces stay the faster ones.
      * CRTHIP_SIG_TILE=16 pins the small tile, =32 / =64 the large one whatever the batch (A/B). */
     if constexpr (FULL && FAST && !S::IS_NES && S::CCS == 4) {
+        const unsigned nw = grid.x;
         const bool big = c->sig_tile_env ? c->sig_tile_env != 16
-                                         : grid.x >= (unsigned) (wide_in ? SIG_TILE64_MIN_WAVES_WIDE : SIG_TILE32_MIN_WAVES);
+                       : wide_in ? nw >= (unsigned) SIG_TILE64_MIN_WAVES_WIDE
+                       : (nw > (unsigned) SIG_TILE32_BAND_LO && nw <= (unsigned) SIG_TILE32_ONE_ROUND) || nw > (unsigned) SIG_TILE16_ONE_ROUND;
         if (in4 && big) {
 #ifndef CRTHIP_ENC_OL32
 /* dwords per row of the large sample tiles that are in LDS (RowTiles: staged when half of OT).  Measured (profiles/r06_ab_encoder_waves.txt):
